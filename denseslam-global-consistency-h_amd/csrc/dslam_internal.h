@@ -1,0 +1,159 @@
+// dslam_internal.h -- host-side objects behind the opaque handles of include/dslam_fusion.h.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <deque>
+#include <string>
+#include <vector>
+
+#include "../../include/dslam_fusion.h"
+#include "dslam_device.h"
+
+namespace dslam {
+
+void set_last_error(const std::string &msg);
+int hip_fail(hipError_t err, const char *what, const char *file, int line);
+
+#define DSLAM_HIP(call)                                                       \
+  do {                                                                        \
+    hipError_t _e = (call);                                                   \
+    if (_e != hipSuccess) return ::dslam::hip_fail(_e, #call, __FILE__, __LINE__); \
+  } while (0)
+
+#define DSLAM_REQUIRE(cond, msg)                 \
+  do {                                           \
+    if (!(cond)) {                               \
+      ::dslam::set_last_error(msg);              \
+      return DSLAM_ERR_INVALID;                  \
+    }                                            \
+  } while (0)
+
+// host inverse of a column-major 4x4 (ORUtils::Matrix4::inv); used for invM_d = pose_d->GetInvM()
+bool invert_matrix(const float *m, float *dst);
+
+// one queued per-frame visible list (block positions, device resident)
+struct VisibleList {
+  short4 *pos_dev = nullptr;  // (x, y, z, 1) per block
+  int count = 0;
+  int frame_idx = 0;
+  double timestamp = 0;
+  bool decayed = false;
+};
+
+}  // namespace dslam
+
+struct dslam_engine {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  hipStream_t copy_stream = nullptr;
+  bool async_mode = false;
+  dslam_weight_params wp{0, 1, 1.0f};
+  // scratch shared by all scenes of this engine (sized for the largest scene seen)
+  int scratch_entries = 0;
+  int scratch_local_blocks = 0;
+  unsigned *order_keys = nullptr;     // [entries] mark-phase order keys / removal flags
+  unsigned char *alloc_type = nullptr;  // [entries] entriesAllocType
+  short4 *block_coords = nullptr;     // [entries] blockCoords
+  int *tile_counts = nullptr;         // [2 * tiles] per-tile counts of the ordered compactions
+  int *tile_offsets = nullptr;        // [2 * tiles]
+  int *list_a = nullptr;              // [max(local_blocks, entries)] general purpose int lists
+  int *list_b = nullptr;
+  int *list_c = nullptr;
+  short4 *pos_scratch = nullptr;      // [local_blocks]
+  // pinned staging
+  void *pinned = nullptr;             // small host mirror for counters / stats
+  size_t pinned_bytes = 0;
+  void *staging_dev = nullptr;        // H2D staging for view uploads (rgba + depth)
+  size_t staging_bytes = 0;
+  void *staging_host = nullptr;
+  // kernel timer (bench roofline): HIP events around the integrate kernel on the engine stream
+  bool timer_enabled = false;
+  std::vector<hipEvent_t> ev_pool;
+  size_t ev_used = 0;
+  double timer_ms = 0;
+  long long timer_launches = 0;
+  long long timer_blocks = 0;
+  std::vector<const dslam_render_state *> timer_rs;
+  int sm_count = 256;
+};
+
+struct dslam_scene {
+  dslam_engine *engine = nullptr;
+  dslam_scene_params p{};
+  int n_entries = 0;
+  dslam::HashEntry *hash = nullptr;
+  uint2 *voxels = nullptr;
+  bool voxels_external = false;
+  int *alloc_list = nullptr;
+  int *excess_list = nullptr;
+  int *last_seen = nullptr;           // per voxel-block slot
+  dslam::SceneCounters *counters = nullptr;  // device
+  // queued visible lists (fusion / defusion)
+  std::deque<dslam::VisibleList> fifo[2];
+  int frame_counter = 0;
+  // ITMGlobalCache
+  unsigned char *swap_state = nullptr;  // device [entries]
+  unsigned char *has_stored = nullptr;  // host   [entries]
+  dslam_voxel *stored = nullptr;        // host   [entries * 512], lazily committed
+  uint2 *transfer_dev = nullptr;        // device [kTransferBlocks * 512]
+  dslam_voxel *transfer_host = nullptr; // pinned [kTransferBlocks * 512]
+  int *transfer_ids_host = nullptr;     // pinned [kTransferBlocks]
+  int last_swapped_in = 0, last_swapped_out = 0;
+  int shard = 0, num_shards = 1, chunk_blocks = 256;
+};
+
+struct dslam_render_state {
+  dslam_engine *engine = nullptr;
+  int w = 0, h = 0, n_entries = 0, n_local = 0;
+  int *visible_ids = nullptr;
+  unsigned char *visible_type = nullptr;
+  float2 *range = nullptr;      // renderingRangeImage (full image stride)
+  float4 *raycast = nullptr;    // raycastResult
+  uchar4 *image_rgba = nullptr; // raycastImage
+  float *image_float = nullptr;
+  float4 *icp_points = nullptr, *icp_normals = nullptr;  // allocated on first use
+  int4 *proj_boxes = nullptr;   // per visible block: render bbox (ul.x, ul.y, lr.x, lr.y)
+  float2 *proj_z = nullptr;     // per visible block: z range
+  int *proj_req = nullptr;      // per visible block: render tiles required (0 = invalid projection)
+  dslam::RenderCounters *counters = nullptr;  // device
+};
+
+struct dslam_view {
+  dslam_engine *engine = nullptr;
+  int w_rgb = 0, h_rgb = 0, w_d = 0, h_d = 0;
+  uchar4 *rgba = nullptr;
+  float *depth = nullptr;
+  short *raw_depth = nullptr;
+  double timestamp = 0;
+};
+
+namespace dslam {
+// kernels' host launchers (one translation unit per subsystem)
+int launch_scene_reset(dslam_engine *e, dslam_scene *s);
+int launch_view_convert(dslam_engine *e, dslam_view *v, const void *rgba_dev, const void *depth_dev, float a, float b);
+int launch_allocate(dslam_engine *e, dslam_scene *s, const dslam_view *v, dslam_render_state *r, const float *M_d,
+                    const float *intr, int only_update_visible_list);
+int launch_integrate(dslam_engine *e, dslam_scene *s, const dslam_view *v, const dslam_render_state *r,
+                     const float *M_d, const float *intr_d, const float *M_rgb, const float *intr_rgb,
+                     bool deintegrate);
+int launch_push_visible_list(dslam_engine *e, dslam_scene *s, const dslam_render_state *r, int which,
+                             double timestamp);
+int launch_find_visible(dslam_engine *e, const dslam_scene *s, dslam_render_state *r, const float *M,
+                        const float *intr);
+int launch_count_visible(dslam_engine *e, const dslam_scene *s, const dslam_render_state *r, int min_id, int max_id,
+                         int *out);
+int launch_expected_depths(dslam_engine *e, const dslam_scene *s, dslam_render_state *r, const float *M,
+                           const float *intr);
+int launch_render(dslam_engine *e, const dslam_scene *s, dslam_render_state *r, const float *M, const float *intr,
+                  int type);
+int launch_icp_maps(dslam_engine *e, const dslam_scene *s, dslam_render_state *r, const float *M, const float *intr);
+int launch_decay(dslam_engine *e, dslam_scene *s, dslam_render_state *r, int max_weight, int min_age, int force_all,
+                 int which);
+int launch_slide_window(dslam_engine *e, dslam_scene *s, dslam_render_state *r, int which, int keep);
+int launch_swap_in(dslam_engine *e, dslam_scene *s, dslam_render_state *r);
+int launch_swap_out(dslam_engine *e, dslam_scene *s, dslam_render_state *r, bool ignore_visibility);
+int launch_save_to_global(dslam_engine *e, dslam_scene *s);
+int ensure_scratch(dslam_engine *e, int entries, int local_blocks);
+int finish_call(dslam_engine *e);  // synchronise unless the engine is in async mode
+inline int num_tiles(int entries) { return (entries + kTileEntries - 1) / kTileEntries; }
+}  // namespace dslam

@@ -1,0 +1,302 @@
+/*
+ * dslam_fusion.h -- C ABI of libdslam_fusion.so, the MI355X (gfx950) TSDF fusion + raycast engine.
+ *
+ * This is the drop-in boundary for the voxel-block-hashing hot path of
+ * Hansry/DenseSLAM-Global-Consistency-h.  Every entry point names the ITMLib engine method it stands in
+ * for and the reference call site that reaches it (file:line under /root/reference/src/DenseSLAM).  The
+ * ITMLib-compatible C++ classes in denseslam-global-consistency-h_amd/itmlib/ (ITMDenseMapper,
+ * ITMSceneReconstructionEngine, ITMVisualisationEngine, ITMSwappingEngine, ...) are thin wrappers over
+ * these functions, so InfiniTamDriver / DenseSlam / DenseSLAMGUI compile and run unchanged on top.
+ *
+ * Conventions
+ *  - plain C, no exceptions across the boundary; every function returns a dslam_status (0 = ok).
+ *  - 4x4 matrices are float[16], COLUMN-major, exactly ORUtils::Matrix4f::m[] (InfiniTamDriver.cpp:208-226).
+ *  - intrinsics are float[4] = (fx, fy, cx, cy) = ITMIntrinsics::projectionParamsSimple.all
+ *    (InfiniTamDriver.cpp:60-67).
+ *  - "host" pointers are ordinary CPU memory, "dev" pointers are HIP device memory on the engine's device.
+ *  - the engine is used from one thread (DenseSlam's main thread); it owns one HIP stream.
+ *    In the default synchronous mode every call has completed (including D2H copies) when it returns,
+ *    which is what the reference callers assume (DenseSlam.h:151-152,162-163).  dslam_engine_set_async
+ *    lets a harness pipeline frames and synchronise explicitly.
+ */
+#ifndef DSLAM_FUSION_H
+#define DSLAM_FUSION_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DSLAM_BLOCK_SIZE 8    /* SDF_BLOCK_SIZE  */
+#define DSLAM_BLOCK_SIZE3 512 /* SDF_BLOCK_SIZE3, used at InfiniTamDriver.h:346 */
+
+/* upstream ITMLibDefines.h defaults (corroborated by the reference's memory logs) */
+#define DSLAM_DEFAULT_LOCAL_BLOCK_NUM 0x40000 /* SDF_LOCAL_BLOCK_NUM   */
+#define DSLAM_DEFAULT_BUCKET_NUM 0x100000     /* SDF_BUCKET_NUM        */
+#define DSLAM_DEFAULT_EXCESS_LIST_SIZE 0x20000 /* SDF_EXCESS_LIST_SIZE */
+#define DSLAM_TRANSFER_BLOCK_NUM 0x1000       /* SDF_TRANSFER_BLOCK_NUM */
+#define DSLAM_MAX_RENDERING_BLOCKS (65536 * 4)
+
+typedef enum {
+  DSLAM_OK = 0,
+  DSLAM_ERR_INVALID = -1,     /* bad argument (null handle, size mismatch, ...) */
+  DSLAM_ERR_HIP = -2,         /* a HIP runtime call failed; see dslam_last_error() */
+  DSLAM_ERR_UNSUPPORTED = -3, /* parameter combination outside what the kernels are built for */
+  DSLAM_ERR_NO_DEVICE = -4
+} dslam_status;
+
+/* ITMHashEntry {Vector3s pos; int offset; int ptr;}  -- 16 bytes.
+ * ptr >= 0: slot in the voxel block array; ptr == -1: swapped out; ptr < -1: unused entry.
+ * offset >= 1: next entry of the bucket lives at num_buckets + offset - 1. */
+typedef struct {
+  int16_t pos[3];
+  int16_t _pad;
+  int32_t offset;
+  int32_t ptr;
+} dslam_hash_entry;
+
+/* ITMVoxel = ITMVoxel_s_rgb {short sdf; uchar w_depth; Vector3u clr; uchar w_color;} -- 8 bytes
+ * (sizeof(ITMVoxel) at InfiniTamDriver.h:333-335).  Empty voxel: sdf 32767, everything else 0. */
+typedef struct {
+  int16_t sdf;
+  uint8_t w_depth;
+  uint8_t clr[3];
+  uint8_t w_color;
+  uint8_t _pad;
+} dslam_voxel;
+
+/* ITMSceneParams + the compile-time pool sizes of ITMLibDefines.h made runtime fields. */
+typedef struct {
+  float voxel_size;   /* metres                     (upstream default 0.005) */
+  float mu;           /* truncation band, metres    (0.02) */
+  int32_t max_w;      /* weight clamp, <= 255       (100)  */
+  float frustum_min;  /* viewFrustum_min, metres    (0.2)  */
+  float frustum_max;  /* viewFrustum_max, metres    (3.0)  */
+  int32_t stop_integrating_at_max_w;
+  int32_t num_local_blocks; /* SDF_LOCAL_BLOCK_NUM; 0 -> default */
+  int32_t num_buckets;      /* SDF_BUCKET_NUM, power of two; 0 -> default */
+  int32_t num_excess;       /* SDF_EXCESS_LIST_SIZE; 0 -> default */
+  int32_t use_swapping;     /* ITMLibSettings::useSwapping: allocate the host-side global cache */
+  int32_t history_words;    /* 64-bit words per visible-list ring per block (ring holds 64*words lists,
+                               bounds max_age / defusion maxSize); 0 -> 4 */
+} dslam_scene_params;
+
+/* ITMLib::Engine::WeightParams {depthWeighting, maxNewW, maxDistance} (SystemEntry.cpp:183-187,
+ * InfiniTamDriver.h:189,196). */
+typedef struct {
+  int32_t depth_weighting;
+  int32_t max_new_w;
+  float max_distance;
+} dslam_weight_params;
+
+/* What InfiniTamDriver reads back after every call (InfiniTamDriver.h:209-210,344-351,366-370). */
+typedef struct {
+  int32_t num_allocated_blocks; /* scene->index.getNumAllocatedVoxelBlocks() == num_local_blocks */
+  int32_t last_free_block_id;   /* scene->localVBA.lastFreeBlockId */
+  int32_t last_free_excess_id;  /* scene->index.lastFreeExcessListId */
+  int32_t no_visible_entries;   /* ITMRenderState_VH::noVisibleEntries of the render state passed */
+  int64_t decayed_block_count;  /* ITMDenseMapper::GetDecayedBlockCount() */
+  int64_t slid_block_count;     /* blocks released (or swapped out) by SlideWindow* so far */
+  int32_t frame_counter;        /* number of visible lists queued so far (fusion + defusion) */
+  int32_t fusion_fifo_len;
+  int32_t defusion_fifo_len;
+  int32_t alloc_failures;       /* blocks the last allocation wanted but could not get (pool exhausted) */
+  int32_t last_swapped_in;      /* blocks moved by the last IntegrateGlobalIntoLocal */
+  int32_t last_swapped_out;     /* blocks moved by the last SaveToGlobalMemory */
+} dslam_stats;
+
+/* ITMMainEngine::GetImageType values used by the reference (InfiniTamDriver.cpp:16-38). */
+typedef enum {
+  DSLAM_IMAGE_SHADED = 0,             /* InfiniTAM_IMAGE_FREECAMERA_SHADED */
+  DSLAM_IMAGE_COLOUR_FROM_VOLUME = 1, /* InfiniTAM_IMAGE_FREECAMERA_COLOUR_FROM_VOLUME */
+  DSLAM_IMAGE_COLOUR_FROM_NORMAL = 2, /* InfiniTAM_IMAGE_FREECAMERA_COLOUR_FROM_NORMAL */
+  DSLAM_IMAGE_DEPTH = 3               /* InfiniTAM_IMAGE_FREECAMERA_DEPTH (float metres) */
+} dslam_image_type;
+
+typedef struct dslam_engine dslam_engine;             /* device + stream + scratch: the *_HIP engines */
+typedef struct dslam_scene dslam_scene;               /* ITMScene<ITMVoxel,ITMVoxelBlockHash> (+ITMGlobalCache) */
+typedef struct dslam_render_state dslam_render_state; /* ITMRenderState_VH */
+typedef struct dslam_view dslam_view;                 /* ITMView (rgb, depth) */
+
+/* ---- engine ------------------------------------------------------------------------------------ */
+const char *dslam_last_error(void);
+const char *dslam_version(void);
+/* ITMSceneReconstructionEngineFactory / ITMVisualisationEngineFactory / ITMSwappingEngineFactory for
+ * the HIP device type (ITMMainEngine ctor, InfiniTamDriver.h:102). */
+int dslam_engine_create(int device_index, dslam_engine **out);
+int dslam_engine_destroy(dslam_engine *e);
+int dslam_engine_set_async(dslam_engine *e, int async_mode);
+int dslam_engine_synchronize(dslam_engine *e);
+/* native hipStream_t of the engine, for callers that enqueue their own work (RCCL, torch). */
+void *dslam_engine_stream(dslam_engine *e);
+
+/* ---- scene ------------------------------------------------------------------------------------- */
+/* new ITMScene(sceneParams, useSwapping, memoryType) + ResetScene.  ext_voxel_blocks_dev may be NULL
+ * (library allocates) or a caller-owned device buffer of num_local_blocks*512*8 bytes (e.g. a torch
+ * tensor used as the RCCL all-gather buffer). */
+int dslam_scene_create(dslam_engine *e, const dslam_scene_params *p, void *ext_voxel_blocks_dev,
+                       dslam_scene **out);
+int dslam_scene_destroy(dslam_scene *s);
+/* denseMapper->ResetScene(scene)  (InfiniTamDriver.h:354-360). */
+int dslam_scene_reset(dslam_engine *e, dslam_scene *s);
+int dslam_scene_get_params(const dslam_scene *s, dslam_scene_params *out);
+
+/* ---- render state / view ----------------------------------------------------------------------- */
+/* visualisationEngine->CreateRenderState(imgSize) */
+int dslam_render_state_create(dslam_engine *e, const dslam_scene *s, int width, int height,
+                              dslam_render_state **out);
+int dslam_render_state_destroy(dslam_render_state *r);
+int dslam_view_create(dslam_engine *e, int width_rgb, int height_rgb, int width_d, int height_d,
+                      dslam_view **out);
+int dslam_view_destroy(dslam_view *v);
+
+/* viewBuilder->UpdateView(&view, rgb, rawDepth, timestamp, useBilateralFilter)
+ * (InfiniTamDriver.cpp:280-288).  rgba: Vector4u per pixel as written by CvToItm (:84-103);
+ * depth_mm: int16 millimetres (:106-110); depth_m = d<=0 ? -1 : d*affine_a + affine_b with
+ * (a,b) = (1/1000, 0) from CreateItmCalib (:58,79). */
+int dslam_view_update(dslam_engine *e, dslam_view *v, const uint8_t *rgba_host, const int16_t *depth_mm_host,
+                      float affine_a, float affine_b, double timestamp, int use_bilateral_filter);
+/* same, inputs already resident in HBM (frame database kept on device). */
+int dslam_view_update_device(dslam_engine *e, dslam_view *v, const void *rgba_dev, const void *depth_mm_dev,
+                             float affine_a, float affine_b, double timestamp, int use_bilateral_filter);
+
+/* ---- fusion ------------------------------------------------------------------------------------ */
+/* denseMapper->SetFusionWeightParams(...)  (InfiniTamDriver.h:189,196) */
+int dslam_set_fusion_weight_params(dslam_engine *e, const dslam_weight_params *w);
+
+/* sceneRecoEngine->AllocateSceneFromDepth(scene, view, trackingState, renderState, onlyUpdateVisibleList)
+ * M_d = trackingState->pose_d->GetM() (world -> camera), InfiniTamDriver.h:173-178. */
+int dslam_allocate_scene_from_depth(dslam_engine *e, dslam_scene *s, const dslam_view *v,
+                                    dslam_render_state *r, const float M_d[16], const float intrinsics_d[4],
+                                    int only_update_visible_list);
+/* sceneRecoEngine->IntegrateIntoScene(scene, view, trackingState, renderState).
+ * M_rgb = calib.trafo_rgb_to_depth.calib_inv * M_d (identity calib in the reference,
+ * InfiniTamDriver.cpp:74-75); pass M_rgb = NULL for "same as M_d". */
+int dslam_integrate_into_scene(dslam_engine *e, dslam_scene *s, const dslam_view *v,
+                               const dslam_render_state *r, const float M_d[16],
+                               const float intrinsics_d[4], const float M_rgb[16],
+                               const float intrinsics_rgb[4]);
+/* denseMapper->ProcessFrame(view, trackingState, scene, renderState, onlyUpdateVisibleList, isDefusion)
+ * (InfiniTamDriver.h:187-192; DenseSlam.cpp:213,236,403): allocate + integrate, queue the frame's
+ * visible list (fusion or defusion FIFO), then swap in/out when the scene was created with swapping. */
+int dslam_process_frame(dslam_engine *e, dslam_scene *s, const dslam_view *v, dslam_render_state *r,
+                        const float M_d[16], const float intrinsics_d[4], const float M_rgb[16],
+                        const float intrinsics_rgb[4], int only_update_visible_list, int is_defusion);
+/* denseMapper->DeProcessFrame(view, trackingState, scene, renderState)
+ * (InfiniTamDriver.h:194-199; DenseSlam.cpp:393,425): visible-list-only pass at the old pose, then the
+ * inverse running average. */
+int dslam_deprocess_frame(dslam_engine *e, dslam_scene *s, const dslam_view *v, dslam_render_state *r,
+                          const float M_d[16], const float intrinsics_d[4], const float M_rgb[16],
+                          const float intrinsics_rgb[4]);
+
+/* ---- map regularisation / sliding window (the "global consistency" memory path) ------------------ */
+/* denseMapper->Decay(scene, renderState, maxWeight, minAge, forceAllVoxels) (InfiniTamDriver.h:274-282,
+ * 315-331) and DecayDefusionPart (:284-292). */
+int dslam_decay(dslam_engine *e, dslam_scene *s, dslam_render_state *r, int max_weight, int min_age,
+                int force_all_voxels);
+int dslam_decay_defusion_part(dslam_engine *e, dslam_scene *s, dslam_render_state *r, int max_weight,
+                              int min_age, int force_all_voxels);
+/* denseMapper->SlideWindow(scene, renderState, maxAge) (InfiniTamDriver.h:294-300) and
+ * SlideWindowDefusionPart(scene, renderState, maxAge, maxSize) (:302-310). */
+int dslam_slide_window(dslam_engine *e, dslam_scene *s, dslam_render_state *r, int max_age);
+int dslam_slide_window_defusion_part(dslam_engine *e, dslam_scene *s, dslam_render_state *r, int max_age,
+                                     int max_size);
+
+/* ---- swapping ---------------------------------------------------------------------------------- */
+/* ITMSwappingEngine::IntegrateGlobalIntoLocal(scene, renderState) */
+int dslam_swap_in(dslam_engine *e, dslam_scene *s, dslam_render_state *r);
+/* ITMSwappingEngine::SaveToGlobalMemory(scene, renderState): swap out blocks that left the view */
+int dslam_swap_out(dslam_engine *e, dslam_scene *s, dslam_render_state *r);
+/* Hansry's one-argument SaveToGlobalMemory(scene) (DenseSlam.h:248-251): flush every resident block */
+int dslam_save_to_global_memory(dslam_engine *e, dslam_scene *s);
+
+/* ---- visualisation / raycast ------------------------------------------------------------------- */
+/* visualisationEngine->FindVisibleBlocks(scene, pose, intrinsics, renderState) */
+int dslam_find_visible_blocks(dslam_engine *e, const dslam_scene *s, dslam_render_state *r,
+                              const float M[16], const float intrinsics[4]);
+/* visualisationEngine->CountVisibleBlocks(scene, renderState, minBlockId, maxBlockId)
+ * (mapManager->countVisibleBlocks, DenseSlam.cpp:555-556) */
+int dslam_count_visible_blocks(dslam_engine *e, const dslam_scene *s, const dslam_render_state *r,
+                               int min_block_id, int max_block_id, int *out_count);
+/* visualisationEngine->CreateExpectedDepths(scene, pose, intrinsics, renderState) */
+int dslam_create_expected_depths(dslam_engine *e, const dslam_scene *s, dslam_render_state *r,
+                                 const float M[16], const float intrinsics[4]);
+/* visualisationEngine->RenderImage(scene, pose, intrinsics, renderState, outputImage, type): raycast
+ * with the render state's range image, then shade.  Exactly one of out_rgba_host (Vector4u per pixel)
+ * / out_float_host (float per pixel, DSLAM_IMAGE_DEPTH only) may be non-NULL; both NULL leaves the
+ * result on the device (dslam_render_state_image_dev). */
+int dslam_render_image(dslam_engine *e, const dslam_scene *s, dslam_render_state *r, const float M[16],
+                       const float intrinsics[4], int image_type, uint8_t *out_rgba_host,
+                       float *out_float_host);
+/* ITMMainEngine::GetImage(out, outFloat, type, pose, intrinsics, localMap) for the FREECAMERA_* types
+ * (InfiniTamDriver.cpp:229-277): FindVisibleBlocks + CreateExpectedDepths + RenderImage. */
+int dslam_get_image(dslam_engine *e, const dslam_scene *s, dslam_render_state *r, const float M[16],
+                    const float intrinsics[4], int image_type, uint8_t *out_rgba_host,
+                    float *out_float_host);
+/* trackingController->Prepare(trackingState, scene, view, renderState) (InfiniTamDriver.h:208-220):
+ * CreateExpectedDepths + CreateICPMaps from the render state's own visible list.  Outputs are
+ * Vector4f per pixel (points: metres, world frame, w = 1 or -1; normals: w = 0 or -1); may be NULL. */
+int dslam_create_icp_maps(dslam_engine *e, const dslam_scene *s, dslam_render_state *r, const float M[16],
+                          const float intrinsics[4], float *out_points_host, float *out_normals_host);
+
+/* ---- state read-back (stats for the driver; bulk downloads for parity tests and checkpoints) ------ */
+int dslam_get_stats(dslam_engine *e, const dslam_scene *s, const dslam_render_state *r, dslam_stats *out);
+int dslam_download_hash_table(dslam_engine *e, const dslam_scene *s, dslam_hash_entry *out_host);
+int dslam_download_voxel_blocks(dslam_engine *e, const dslam_scene *s, int first_block, int num_blocks,
+                                dslam_voxel *out_host);
+int dslam_download_allocation_list(dslam_engine *e, const dslam_scene *s, int32_t *out_host);
+int dslam_download_excess_list(dslam_engine *e, const dslam_scene *s, int32_t *out_host);
+int dslam_download_visible_ids(dslam_engine *e, const dslam_render_state *r, int32_t *out_host,
+                               int capacity, int *out_count);
+int dslam_download_visible_types(dslam_engine *e, const dslam_render_state *r, uint8_t *out_host);
+int dslam_download_range_image(dslam_engine *e, const dslam_render_state *r, float *out_minmax_host);
+int dslam_download_raycast_result(dslam_engine *e, const dslam_render_state *r, float *out_xyzw_host);
+int dslam_download_view_depth(dslam_engine *e, const dslam_view *v, float *out_host);
+int dslam_download_swap_states(dslam_engine *e, const dslam_scene *s, uint8_t *out_host);
+/* per voxel-block slot: newest global list index that holds the block (-1 never, <= -2 swept by Decay) */
+int dslam_download_last_seen(dslam_engine *e, const dslam_scene *s, int32_t *out_host);
+/* ITMGlobalCache::GetStoredVoxelBlock(entry): copies the host-stored block; returns 1 if the entry has
+ * stored data, 0 if not */
+int dslam_download_stored_block(dslam_engine *e, const dslam_scene *s, int entry, dslam_voxel *out_host);
+/* scratch of the last allocation pass (entriesAllocType / blockCoords), for bit-exactness tests */
+int dslam_download_alloc_scratch(dslam_engine *e, const dslam_scene *s, uint8_t *alloc_types_host,
+                                 int16_t *block_coords_host);
+/* upload a complete map state (hash table, pool free lists, voxel blocks): checkpoint restore and the
+ * stress/roofline generator.  Any pointer may be NULL to keep that part. */
+int dslam_upload_scene_state(dslam_engine *e, dslam_scene *s, const dslam_hash_entry *hash_host,
+                             const int32_t *allocation_list_host, int last_free_block_id,
+                             const int32_t *excess_list_host, int last_free_excess_id);
+int dslam_upload_voxel_blocks(dslam_engine *e, dslam_scene *s, int first_block, int num_blocks,
+                              const dslam_voxel *host);
+int dslam_upload_visible_ids(dslam_engine *e, dslam_render_state *r, const int32_t *ids_host, int count);
+
+/* raw device pointers (HBM layout is documented in DESIGN.md) */
+void *dslam_scene_voxel_blocks_dev(dslam_scene *s);
+void *dslam_scene_hash_table_dev(dslam_scene *s);
+void *dslam_render_state_image_dev(dslam_render_state *r, int want_float);
+
+/* ---- sharded re-integration (multi-GPU) ------------------------------------------------ */
+/* Restrict the voxel-writing kernels (integrate / de-integrate) of this scene to the voxel-block slots
+ * whose chunk (slot / chunk_blocks) satisfies chunk % num_shards == shard; allocation stays global
+ * (and bit-identical on every rank).  num_shards = 1 disables sharding. */
+int dslam_scene_set_shard(dslam_scene *s, int shard, int num_shards, int chunk_blocks);
+
+/* ---- instrumentation ---------------------------------------------------------------------------- */
+/* Time `iterations` back-to-back launches of the integrate kernel alone on the engine stream with HIP
+ * events (state is restored afterwards is NOT guaranteed: use on a scratch scene).  Returns the mean
+ * milliseconds per launch and the number of visible blocks processed per launch. */
+int dslam_time_integrate(dslam_engine *e, dslam_scene *s, const dslam_view *v, const dslam_render_state *r,
+                         const float M_d[16], const float intrinsics_d[4], int iterations,
+                         float *out_ms_per_launch, int *out_visible_blocks);
+/* accumulated HIP-event time of the integrate kernel launched by dslam_process_frame /
+ * dslam_integrate_into_scene since the last reset (events are recorded only while enabled). */
+int dslam_kernel_timer_enable(dslam_engine *e, int enable);
+int dslam_kernel_timer_read(dslam_engine *e, double *out_integrate_ms, int64_t *out_launches,
+                            int64_t *out_visible_blocks);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DSLAM_FUSION_H */
