@@ -1,0 +1,743 @@
+// capi.hip -- the C ABI of include/dslam_fusion.h: object lifetime, host<->device plumbing, and the
+// composition of kernels into the ITMLib engine calls (ITMDenseMapper::ProcessFrame, ITMMainEngine::GetImage ...).
+// No arithmetic of the hot path lives here; there is no CPU fallback: without a HIP device the engine cannot be
+// created and every entry point fails.
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+
+#include "dslam_internal.h"
+
+#pragma clang fp contract(off)
+
+namespace dslam {
+
+static thread_local std::string g_last_error;
+void set_last_error(const std::string &msg) { g_last_error = msg; }
+int hip_fail(hipError_t err, const char *what, const char *file, int line) {
+  char buf[512];
+  snprintf(buf, sizeof(buf), "%s failed: %s (%s:%d)", what, hipGetErrorString(err), file, line);
+  g_last_error = buf;
+  return DSLAM_ERR_HIP;
+}
+
+// ORUtils::Matrix4::inv restated (cofactor expansion); identical expression order to the CPU oracle so both
+// derive bit-identical inverse poses.  Host code: compiled with -ffp-contract=off.
+bool invert_matrix(const float *m, float *dst) {
+  float tmp[12], src[16], det;
+  for (int i = 0; i < 4; i++) {
+    src[i] = m[i * 4];
+    src[i + 4] = m[i * 4 + 1];
+    src[i + 8] = m[i * 4 + 2];
+    src[i + 12] = m[i * 4 + 3];
+  }
+  tmp[0] = src[10] * src[15]; tmp[1] = src[11] * src[14]; tmp[2] = src[9] * src[15]; tmp[3] = src[11] * src[13];
+  tmp[4] = src[9] * src[14]; tmp[5] = src[10] * src[13]; tmp[6] = src[8] * src[15]; tmp[7] = src[11] * src[12];
+  tmp[8] = src[8] * src[14]; tmp[9] = src[10] * src[12]; tmp[10] = src[8] * src[13]; tmp[11] = src[9] * src[12];
+  dst[0] = (tmp[0] * src[5] + tmp[3] * src[6] + tmp[4] * src[7]) - (tmp[1] * src[5] + tmp[2] * src[6] + tmp[5] * src[7]);
+  dst[1] = (tmp[1] * src[4] + tmp[6] * src[6] + tmp[9] * src[7]) - (tmp[0] * src[4] + tmp[7] * src[6] + tmp[8] * src[7]);
+  dst[2] = (tmp[2] * src[4] + tmp[7] * src[5] + tmp[10] * src[7]) - (tmp[3] * src[4] + tmp[6] * src[5] + tmp[11] * src[7]);
+  dst[3] = (tmp[5] * src[4] + tmp[8] * src[5] + tmp[11] * src[6]) - (tmp[4] * src[4] + tmp[9] * src[5] + tmp[10] * src[6]);
+  dst[4] = (tmp[1] * src[1] + tmp[2] * src[2] + tmp[5] * src[3]) - (tmp[0] * src[1] + tmp[3] * src[2] + tmp[4] * src[3]);
+  dst[5] = (tmp[0] * src[0] + tmp[7] * src[2] + tmp[8] * src[3]) - (tmp[1] * src[0] + tmp[6] * src[2] + tmp[9] * src[3]);
+  dst[6] = (tmp[3] * src[0] + tmp[6] * src[1] + tmp[11] * src[3]) - (tmp[2] * src[0] + tmp[7] * src[1] + tmp[10] * src[3]);
+  dst[7] = (tmp[4] * src[0] + tmp[9] * src[1] + tmp[10] * src[2]) - (tmp[5] * src[0] + tmp[8] * src[1] + tmp[11] * src[2]);
+  tmp[0] = src[2] * src[7]; tmp[1] = src[3] * src[6]; tmp[2] = src[1] * src[7]; tmp[3] = src[3] * src[5];
+  tmp[4] = src[1] * src[6]; tmp[5] = src[2] * src[5]; tmp[6] = src[0] * src[7]; tmp[7] = src[3] * src[4];
+  tmp[8] = src[0] * src[6]; tmp[9] = src[2] * src[4]; tmp[10] = src[0] * src[5]; tmp[11] = src[1] * src[4];
+  dst[8] = (tmp[0] * src[13] + tmp[3] * src[14] + tmp[4] * src[15]) - (tmp[1] * src[13] + tmp[2] * src[14] + tmp[5] * src[15]);
+  dst[9] = (tmp[1] * src[12] + tmp[6] * src[14] + tmp[9] * src[15]) - (tmp[0] * src[12] + tmp[7] * src[14] + tmp[8] * src[15]);
+  dst[10] = (tmp[2] * src[12] + tmp[7] * src[13] + tmp[10] * src[15]) - (tmp[3] * src[12] + tmp[6] * src[13] + tmp[11] * src[15]);
+  dst[11] = (tmp[5] * src[12] + tmp[8] * src[13] + tmp[11] * src[14]) - (tmp[4] * src[12] + tmp[9] * src[13] + tmp[10] * src[14]);
+  dst[12] = (tmp[2] * src[10] + tmp[5] * src[11] + tmp[1] * src[9]) - (tmp[4] * src[11] + tmp[0] * src[9] + tmp[3] * src[10]);
+  dst[13] = (tmp[8] * src[11] + tmp[0] * src[8] + tmp[7] * src[10]) - (tmp[6] * src[10] + tmp[9] * src[11] + tmp[1] * src[8]);
+  dst[14] = (tmp[6] * src[9] + tmp[11] * src[11] + tmp[3] * src[8]) - (tmp[10] * src[11] + tmp[2] * src[8] + tmp[7] * src[9]);
+  dst[15] = (tmp[10] * src[10] + tmp[4] * src[8] + tmp[9] * src[9]) - (tmp[8] * src[9] + tmp[11] * src[10] + tmp[5] * src[8]);
+  det = src[0] * dst[0] + src[1] * dst[1] + src[2] * dst[2] + src[3] * dst[3];
+  if (det == 0.0f) {
+    for (int i = 0; i < 16; i++) dst[i] = 0.0f;
+    return false;
+  }
+  for (int i = 0; i < 16; i++) dst[i] = dst[i] * (1.0f / det);
+  return true;
+}
+
+int finish_call(dslam_engine *e) {
+  if (!e->async_mode) DSLAM_HIP(hipStreamSynchronize(e->stream));
+  return DSLAM_OK;
+}
+
+template <typename T>
+static void free_dev(T *&p) {
+  if (p) (void)hipFree(p);
+  p = nullptr;
+}
+
+int ensure_scratch(dslam_engine *e, int entries, int local_blocks) {
+  if (entries <= e->scratch_entries && local_blocks <= e->scratch_local_blocks) return DSLAM_OK;
+  DSLAM_HIP(hipStreamSynchronize(e->stream));
+  const int N = entries > e->scratch_entries ? entries : e->scratch_entries;
+  const int L = local_blocks > e->scratch_local_blocks ? local_blocks : e->scratch_local_blocks;
+  free_dev(e->order_keys); free_dev(e->block_coords); free_dev(e->tile_counts); free_dev(e->tile_offsets);
+  free_dev(e->list_a); free_dev(e->list_b); free_dev(e->list_c); free_dev(e->pos_scratch);
+  // order keys (4 B) and allocType (1 B) contiguous so one memset clears both
+  DSLAM_HIP(hipMalloc(&e->order_keys, (size_t)N * 5));
+  e->alloc_type = reinterpret_cast<unsigned char *>(e->order_keys) + (size_t)N * 4;
+  DSLAM_HIP(hipMalloc(&e->block_coords, (size_t)N * sizeof(short4)));
+  const int tiles = num_tiles(N);
+  DSLAM_HIP(hipMalloc(&e->tile_counts, (size_t)tiles * 2 * sizeof(int)));
+  DSLAM_HIP(hipMalloc(&e->tile_offsets, (size_t)tiles * 2 * sizeof(int)));
+  const size_t list_len = (size_t)(N > L ? N : L);
+  DSLAM_HIP(hipMalloc(&e->list_a, list_len * sizeof(int)));
+  DSLAM_HIP(hipMalloc(&e->list_b, list_len * sizeof(int)));
+  DSLAM_HIP(hipMalloc(&e->list_c, list_len * sizeof(int)));
+  DSLAM_HIP(hipMalloc(&e->pos_scratch, (size_t)L * sizeof(short4)));
+  e->scratch_entries = N;
+  e->scratch_local_blocks = L;
+  return DSLAM_OK;
+}
+
+static int ensure_staging(dslam_engine *e, size_t bytes) {
+  if (bytes <= e->staging_bytes) return DSLAM_OK;
+  DSLAM_HIP(hipStreamSynchronize(e->stream));
+  if (e->staging_dev) (void)hipFree(e->staging_dev);
+  if (e->staging_host) (void)hipHostFree(e->staging_host);
+  DSLAM_HIP(hipMalloc(&e->staging_dev, bytes));
+  DSLAM_HIP(hipHostMalloc(&e->staging_host, bytes, hipHostMallocDefault));
+  e->staging_bytes = bytes;
+  return DSLAM_OK;
+}
+
+}  // namespace dslam
+
+using namespace dslam;
+
+extern "C" {
+
+const char *dslam_last_error(void) { return g_last_error.c_str(); }
+const char *dslam_version(void) { return "dslam_fusion 0.1 (gfx950)"; }
+
+int dslam_engine_create(int device_index, dslam_engine **out) {
+  if (!out) return DSLAM_ERR_INVALID;
+  *out = nullptr;
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) {
+    set_last_error("no HIP device: libdslam_fusion has no CPU path");
+    return DSLAM_ERR_NO_DEVICE;
+  }
+  DSLAM_REQUIRE(device_index >= 0 && device_index < n, "device index out of range");
+  DSLAM_HIP(hipSetDevice(device_index));
+  dslam_engine *e = new dslam_engine();
+  e->device = device_index;
+  DSLAM_HIP(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
+  DSLAM_HIP(hipStreamCreateWithFlags(&e->copy_stream, hipStreamNonBlocking));
+  e->pinned_bytes = 64 * 1024;
+  DSLAM_HIP(hipHostMalloc(&e->pinned, e->pinned_bytes, hipHostMallocDefault));
+  memset(e->pinned, 0, e->pinned_bytes);
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, device_index) == hipSuccess) e->sm_count = prop.multiProcessorCount;
+  *out = e;
+  return DSLAM_OK;
+}
+
+int dslam_engine_destroy(dslam_engine *e) {
+  if (!e) return DSLAM_OK;
+  (void)hipSetDevice(e->device);
+  (void)hipStreamSynchronize(e->stream);
+  free_dev(e->order_keys); free_dev(e->block_coords); free_dev(e->tile_counts); free_dev(e->tile_offsets);
+  free_dev(e->list_a); free_dev(e->list_b); free_dev(e->list_c); free_dev(e->pos_scratch);
+  if (e->staging_dev) (void)hipFree(e->staging_dev);
+  if (e->staging_host) (void)hipHostFree(e->staging_host);
+  if (e->pinned) (void)hipHostFree(e->pinned);
+  for (auto ev : e->ev_pool) (void)hipEventDestroy(ev);
+  (void)hipStreamDestroy(e->stream);
+  (void)hipStreamDestroy(e->copy_stream);
+  delete e;
+  return DSLAM_OK;
+}
+
+int dslam_engine_set_async(dslam_engine *e, int async_mode) {
+  DSLAM_REQUIRE(e, "null engine");
+  e->async_mode = async_mode != 0;
+  return DSLAM_OK;
+}
+int dslam_engine_synchronize(dslam_engine *e) {
+  DSLAM_REQUIRE(e, "null engine");
+  DSLAM_HIP(hipStreamSynchronize(e->stream));
+  return DSLAM_OK;
+}
+void *dslam_engine_stream(dslam_engine *e) { return e ? (void *)e->stream : nullptr; }
+
+// ---- scene ---------------------------------------------------------------------------------------------------
+int dslam_scene_create(dslam_engine *e, const dslam_scene_params *p, void *ext_voxels, dslam_scene **out) {
+  DSLAM_REQUIRE(e && p && out, "null argument");
+  *out = nullptr;
+  DSLAM_HIP(hipSetDevice(e->device));
+  dslam_scene *s = new dslam_scene();
+  s->engine = e;
+  s->p = *p;
+  if (s->p.num_local_blocks <= 0) s->p.num_local_blocks = DSLAM_DEFAULT_LOCAL_BLOCK_NUM;
+  if (s->p.num_buckets <= 0) s->p.num_buckets = DSLAM_DEFAULT_BUCKET_NUM;
+  if (s->p.num_excess <= 0) s->p.num_excess = DSLAM_DEFAULT_EXCESS_LIST_SIZE;
+  if (s->p.history_words <= 0) s->p.history_words = 4;
+  s->history_words = s->p.history_words;
+  if ((s->p.num_buckets & (s->p.num_buckets - 1)) || ((s->p.num_buckets + s->p.num_excess) & 3) ||
+      s->p.max_w < 1 || s->p.max_w > 255 || !(s->p.voxel_size > 0) || !(s->p.mu > 0)) {
+    delete s;
+    set_last_error("invalid scene parameters (buckets must be a power of two, entries a multiple of 4, 1<=max_w<=255)");
+    return DSLAM_ERR_INVALID;
+  }
+  s->n_entries = s->p.num_buckets + s->p.num_excess;
+  const size_t vox_bytes = (size_t)s->p.num_local_blocks * kBlock3 * sizeof(uint2);
+  DSLAM_HIP(hipMalloc(&s->hash, (size_t)s->n_entries * sizeof(HashEntry)));
+  if (ext_voxels) {
+    s->voxels = reinterpret_cast<uint2 *>(ext_voxels);
+    s->voxels_external = true;
+  } else {
+    DSLAM_HIP(hipMalloc(&s->voxels, vox_bytes));
+  }
+  DSLAM_HIP(hipMalloc(&s->alloc_list, (size_t)s->p.num_local_blocks * sizeof(int)));
+  DSLAM_HIP(hipMalloc(&s->excess_list, (size_t)s->p.num_excess * sizeof(int)));
+  DSLAM_HIP(hipMalloc(&s->last_seen, (size_t)s->p.num_local_blocks * sizeof(int)));
+  DSLAM_HIP(hipMalloc(&s->masks, (size_t)s->p.num_local_blocks * 2 * s->history_words * sizeof(unsigned long long)));
+  DSLAM_HIP(hipMalloc(&s->counters, sizeof(SceneCounters)));
+  if (s->p.use_swapping) {
+    DSLAM_HIP(hipMalloc(&s->swap_state, s->n_entries));
+    s->has_stored = (unsigned char *)calloc(s->n_entries, 1);
+    s->stored = (dslam_voxel *)calloc((size_t)s->n_entries * kBlock3, sizeof(dslam_voxel));  // committed lazily
+    if (!s->has_stored || !s->stored) { set_last_error("host global cache allocation failed"); return DSLAM_ERR_INVALID; }
+    DSLAM_HIP(hipMalloc(&s->transfer_dev, (size_t)kTransferBlocks * kBlock3 * sizeof(uint2)));
+    DSLAM_HIP(hipHostMalloc((void **)&s->transfer_host, (size_t)kTransferBlocks * kBlock3 * sizeof(dslam_voxel),
+                            hipHostMallocDefault));
+    DSLAM_HIP(hipHostMalloc((void **)&s->transfer_ids_host, (size_t)kTransferBlocks * sizeof(int) * 2, hipHostMallocDefault));
+  }
+  int rc = ensure_scratch(e, s->n_entries, s->p.num_local_blocks);
+  if (rc) return rc;
+  rc = launch_scene_reset(e, s);
+  if (rc) return rc;
+  DSLAM_HIP(hipStreamSynchronize(e->stream));
+  *out = s;
+  return DSLAM_OK;
+}
+
+int dslam_scene_destroy(dslam_scene *s) {
+  if (!s) return DSLAM_OK;
+  (void)hipStreamSynchronize(s->engine->stream);
+  free_dev(s->hash);
+  if (!s->voxels_external) free_dev(s->voxels);
+  free_dev(s->alloc_list); free_dev(s->excess_list); free_dev(s->last_seen); free_dev(s->masks); free_dev(s->counters);
+  free_dev(s->swap_state); free_dev(s->transfer_dev);
+  if (s->transfer_host) (void)hipHostFree(s->transfer_host);
+  if (s->transfer_ids_host) (void)hipHostFree(s->transfer_ids_host);
+  free(s->has_stored);
+  free(s->stored);
+  delete s;
+  return DSLAM_OK;
+}
+
+int dslam_scene_reset(dslam_engine *e, dslam_scene *s) {
+  DSLAM_REQUIRE(e && s, "null argument");
+  int rc = launch_scene_reset(e, s);
+  if (rc) return rc;
+  for (int q = 0; q < 2; q++) { s->ring_head[q] = 0; s->ring_next[q] = 0; s->decay_cursor[q] = 0; }
+  s->frame_counter = 0;
+  s->last_swapped_in = s->last_swapped_out = 0;
+  if (s->has_stored) memset(s->has_stored, 0, s->n_entries);
+  return finish_call(e);
+}
+
+int dslam_scene_get_params(const dslam_scene *s, dslam_scene_params *out) {
+  DSLAM_REQUIRE(s && out, "null argument");
+  *out = s->p;
+  return DSLAM_OK;
+}
+
+int dslam_scene_set_shard(dslam_scene *s, int shard, int num_shards, int chunk_blocks) {
+  DSLAM_REQUIRE(s && num_shards >= 1 && shard >= 0 && shard < num_shards && chunk_blocks >= 1, "bad shard spec");
+  s->shard = shard; s->num_shards = num_shards; s->chunk_blocks = chunk_blocks;
+  return DSLAM_OK;
+}
+
+// ---- render state / view --------------------------------------------------------------------------------------
+int dslam_render_state_create(dslam_engine *e, const dslam_scene *s, int w, int h, dslam_render_state **out) {
+  DSLAM_REQUIRE(e && s && out && w > 0 && h > 0, "bad argument");
+  dslam_render_state *r = new dslam_render_state();
+  r->engine = e; r->w = w; r->h = h; r->n_entries = s->n_entries; r->n_local = s->p.num_local_blocks;
+  const size_t npix = (size_t)w * h;
+  DSLAM_HIP(hipMalloc(&r->visible_ids, (size_t)r->n_local * sizeof(int)));
+  DSLAM_HIP(hipMalloc(&r->visible_type, r->n_entries));
+  DSLAM_HIP(hipMalloc(&r->range, npix * sizeof(float2)));
+  DSLAM_HIP(hipMalloc(&r->raycast, npix * sizeof(float4)));
+  DSLAM_HIP(hipMalloc(&r->image_rgba, npix * sizeof(uchar4)));
+  DSLAM_HIP(hipMalloc(&r->image_float, npix * sizeof(float)));
+  DSLAM_HIP(hipMalloc(&r->proj_boxes, (size_t)r->n_local * sizeof(int4)));
+  DSLAM_HIP(hipMalloc(&r->proj_z, (size_t)r->n_local * sizeof(float2)));
+  DSLAM_HIP(hipMalloc(&r->proj_req, (size_t)r->n_local * sizeof(int)));
+  DSLAM_HIP(hipMalloc(&r->counters, sizeof(RenderCounters)));
+  DSLAM_HIP(hipMemsetAsync(r->visible_type, 0, r->n_entries, e->stream));
+  DSLAM_HIP(hipMemsetAsync(r->counters, 0, sizeof(RenderCounters), e->stream));
+  DSLAM_HIP(hipMemsetAsync(r->range, 0, npix * sizeof(float2), e->stream));
+  DSLAM_HIP(hipMemsetAsync(r->raycast, 0, npix * sizeof(float4), e->stream));
+  DSLAM_HIP(hipMemsetAsync(r->image_rgba, 0, npix * sizeof(uchar4), e->stream));
+  DSLAM_HIP(hipMemsetAsync(r->image_float, 0, npix * sizeof(float), e->stream));
+  DSLAM_HIP(hipStreamSynchronize(e->stream));
+  *out = r;
+  return DSLAM_OK;
+}
+
+int dslam_render_state_destroy(dslam_render_state *r) {
+  if (!r) return DSLAM_OK;
+  (void)hipStreamSynchronize(r->engine->stream);
+  free_dev(r->visible_ids); free_dev(r->visible_type); free_dev(r->range); free_dev(r->raycast);
+  free_dev(r->image_rgba); free_dev(r->image_float); free_dev(r->icp_points); free_dev(r->icp_normals);
+  free_dev(r->proj_boxes); free_dev(r->proj_z); free_dev(r->proj_req); free_dev(r->counters);
+  delete r;
+  return DSLAM_OK;
+}
+
+int dslam_view_create(dslam_engine *e, int w_rgb, int h_rgb, int w_d, int h_d, dslam_view **out) {
+  DSLAM_REQUIRE(e && out && w_rgb > 0 && h_rgb > 0 && w_d > 0 && h_d > 0, "bad argument");
+  dslam_view *v = new dslam_view();
+  v->engine = e; v->w_rgb = w_rgb; v->h_rgb = h_rgb; v->w_d = w_d; v->h_d = h_d;
+  DSLAM_HIP(hipMalloc(&v->rgba, (size_t)w_rgb * h_rgb * sizeof(uchar4)));
+  DSLAM_HIP(hipMalloc(&v->depth, (size_t)w_d * h_d * sizeof(float)));
+  DSLAM_HIP(hipMalloc(&v->raw_depth, (size_t)w_d * h_d * sizeof(short)));
+  DSLAM_HIP(hipMemsetAsync(v->rgba, 0, (size_t)w_rgb * h_rgb * sizeof(uchar4), e->stream));
+  DSLAM_HIP(hipMemsetAsync(v->raw_depth, 0, (size_t)w_d * h_d * sizeof(short), e->stream));
+  DSLAM_HIP(hipStreamSynchronize(e->stream));
+  *out = v;
+  return DSLAM_OK;
+}
+
+int dslam_view_destroy(dslam_view *v) {
+  if (!v) return DSLAM_OK;
+  (void)hipStreamSynchronize(v->engine->stream);
+  free_dev(v->rgba); free_dev(v->depth); free_dev(v->raw_depth);
+  delete v;
+  return DSLAM_OK;
+}
+
+int dslam_view_update(dslam_engine *e, dslam_view *v, const uint8_t *rgba_host, const int16_t *depth_host, float a,
+                      float b, double timestamp, int use_bilateral) {
+  DSLAM_REQUIRE(e && v && rgba_host && depth_host, "null argument");
+  if (use_bilateral) { set_last_error("bilateral depth filter is not implemented (ITMLibSettings default is off)"); return DSLAM_ERR_UNSUPPORTED; }
+  const size_t rgb_bytes = (size_t)v->w_rgb * v->h_rgb * 4, d_bytes = (size_t)v->w_d * v->h_d * 2;
+  int rc = ensure_staging(e, rgb_bytes + d_bytes);
+  if (rc) return rc;
+  // the caller may reuse its buffers right after the call (CvToItm rewrites them every frame), so stage through
+  // pinned memory; in async mode the previous upload must have drained before the staging buffer is rewritten
+  DSLAM_HIP(hipStreamSynchronize(e->stream));
+  memcpy(e->staging_host, rgba_host, rgb_bytes);
+  memcpy((char *)e->staging_host + rgb_bytes, depth_host, d_bytes);
+  DSLAM_HIP(hipMemcpyAsync(v->rgba, e->staging_host, rgb_bytes, hipMemcpyHostToDevice, e->stream));
+  DSLAM_HIP(hipMemcpyAsync(v->raw_depth, (char *)e->staging_host + rgb_bytes, d_bytes, hipMemcpyHostToDevice, e->stream));
+  rc = launch_view_convert(e, v, v->rgba, v->raw_depth, a, b);
+  if (rc) return rc;
+  v->timestamp = timestamp;
+  return finish_call(e);
+}
+
+int dslam_view_update_device(dslam_engine *e, dslam_view *v, const void *rgba_dev, const void *depth_dev, float a,
+                             float b, double timestamp, int use_bilateral) {
+  DSLAM_REQUIRE(e && v && rgba_dev && depth_dev, "null argument");
+  if (use_bilateral) { set_last_error("bilateral depth filter is not implemented"); return DSLAM_ERR_UNSUPPORTED; }
+  int rc = launch_view_convert(e, v, rgba_dev, depth_dev, a, b);
+  if (rc) return rc;
+  v->timestamp = timestamp;
+  return finish_call(e);
+}
+
+// ---- fusion --------------------------------------------------------------------------------------------------
+int dslam_set_fusion_weight_params(dslam_engine *e, const dslam_weight_params *w) {
+  DSLAM_REQUIRE(e && w, "null argument");
+  DSLAM_REQUIRE(!w->depth_weighting || (w->max_distance > 0 && w->max_new_w >= 1), "bad weight params");
+  e->wp = *w;
+  return DSLAM_OK;
+}
+
+static int check_frame_args(dslam_engine *e, dslam_scene *s, const dslam_view *v, const dslam_render_state *r,
+                            const float *M, const float *intr) {
+  DSLAM_REQUIRE(e && s && v && r && M && intr, "null argument");
+  DSLAM_REQUIRE(s->engine == e && v->engine == e && r->engine == e, "objects belong to a different engine");
+  return DSLAM_OK;
+}
+
+int dslam_allocate_scene_from_depth(dslam_engine *e, dslam_scene *s, const dslam_view *v, dslam_render_state *r,
+                                    const float M_d[16], const float intr[4], int only_visible) {
+  int rc = check_frame_args(e, s, v, r, M_d, intr);
+  if (rc) return rc;
+  rc = launch_allocate(e, s, v, r, M_d, intr, only_visible);
+  if (rc) return rc;
+  return finish_call(e);
+}
+
+int dslam_integrate_into_scene(dslam_engine *e, dslam_scene *s, const dslam_view *v, const dslam_render_state *r,
+                               const float M_d[16], const float intr_d[4], const float M_rgb[16],
+                               const float intr_rgb[4]) {
+  int rc = check_frame_args(e, s, v, r, M_d, intr_d);
+  if (rc) return rc;
+  rc = launch_integrate(e, s, v, r, M_d, intr_d, M_rgb, intr_rgb, false);
+  if (rc) return rc;
+  return finish_call(e);
+}
+
+int dslam_process_frame(dslam_engine *e, dslam_scene *s, const dslam_view *v, dslam_render_state *r,
+                        const float M_d[16], const float intr_d[4], const float M_rgb[16], const float intr_rgb[4],
+                        int only_visible, int is_defusion) {
+  int rc = check_frame_args(e, s, v, r, M_d, intr_d);
+  if (rc) return rc;
+  if ((rc = launch_allocate(e, s, v, r, M_d, intr_d, only_visible))) return rc;
+  if ((rc = launch_integrate(e, s, v, r, M_d, intr_d, M_rgb, intr_rgb, false))) return rc;
+  if ((rc = launch_push_visible_list(e, s, r, is_defusion ? 1 : 0))) return rc;
+  if (s->p.use_swapping) {
+    if ((rc = launch_swap_in(e, s, r))) return rc;
+    if ((rc = launch_swap_out(e, s, r, false))) return rc;
+  }
+  return finish_call(e);
+}
+
+int dslam_deprocess_frame(dslam_engine *e, dslam_scene *s, const dslam_view *v, dslam_render_state *r,
+                          const float M_d[16], const float intr_d[4], const float M_rgb[16], const float intr_rgb[4]) {
+  int rc = check_frame_args(e, s, v, r, M_d, intr_d);
+  if (rc) return rc;
+  if ((rc = launch_allocate(e, s, v, r, M_d, intr_d, 1))) return rc;
+  if ((rc = launch_integrate(e, s, v, r, M_d, intr_d, M_rgb, intr_rgb, true))) return rc;
+  return finish_call(e);
+}
+
+// ---- decay / sliding window ----------------------------------------------------------------------------------
+int dslam_decay(dslam_engine *e, dslam_scene *s, dslam_render_state *r, int max_weight, int min_age, int force_all) {
+  DSLAM_REQUIRE(e && s, "null argument");
+  int rc = launch_decay(e, s, r, max_weight, min_age, force_all, 0);
+  if (rc) return rc;
+  return finish_call(e);
+}
+int dslam_decay_defusion_part(dslam_engine *e, dslam_scene *s, dslam_render_state *r, int max_weight, int min_age,
+                              int force_all) {
+  DSLAM_REQUIRE(e && s, "null argument");
+  int rc = launch_decay(e, s, r, max_weight, min_age, force_all, 1);
+  if (rc) return rc;
+  return finish_call(e);
+}
+int dslam_slide_window(dslam_engine *e, dslam_scene *s, dslam_render_state *r, int max_age) {
+  DSLAM_REQUIRE(e && s, "null argument");
+  if (max_age < 0) max_age = 0;
+  while (s->ring_next[0] - s->ring_head[0] > max_age) {
+    int rc = launch_slide_pop(e, s, r, 0);
+    if (rc) return rc;
+  }
+  return finish_call(e);
+}
+int dslam_slide_window_defusion_part(dslam_engine *e, dslam_scene *s, dslam_render_state *r, int max_age, int max_size) {
+  DSLAM_REQUIRE(e && s, "null argument");
+  (void)max_age;
+  if (max_size < 0) max_size = 0;
+  while (s->ring_next[1] - s->ring_head[1] > max_size) {
+    int rc = launch_slide_pop(e, s, r, 1);
+    if (rc) return rc;
+  }
+  return finish_call(e);
+}
+
+// ---- swapping ------------------------------------------------------------------------------------------------
+int dslam_swap_in(dslam_engine *e, dslam_scene *s, dslam_render_state *r) {
+  DSLAM_REQUIRE(e && s && s->p.use_swapping, "scene was created without swapping");
+  int rc = launch_swap_in(e, s, r);
+  if (rc) return rc;
+  return finish_call(e);
+}
+int dslam_swap_out(dslam_engine *e, dslam_scene *s, dslam_render_state *r) {
+  DSLAM_REQUIRE(e && s && r && s->p.use_swapping, "scene was created without swapping");
+  int rc = launch_swap_out(e, s, r, false);
+  if (rc) return rc;
+  return finish_call(e);
+}
+int dslam_save_to_global_memory(dslam_engine *e, dslam_scene *s) {
+  DSLAM_REQUIRE(e && s && s->p.use_swapping, "scene was created without swapping");
+  int rc = launch_save_to_global(e, s);
+  if (rc) return rc;
+  return finish_call(e);
+}
+
+// ---- visualisation -------------------------------------------------------------------------------------------
+int dslam_find_visible_blocks(dslam_engine *e, const dslam_scene *s, dslam_render_state *r, const float M[16],
+                              const float intr[4]) {
+  DSLAM_REQUIRE(e && s && r && M && intr, "null argument");
+  int rc = launch_find_visible(e, s, r, M, intr);
+  if (rc) return rc;
+  return finish_call(e);
+}
+int dslam_count_visible_blocks(dslam_engine *e, const dslam_scene *s, const dslam_render_state *r, int min_id,
+                               int max_id, int *out) {
+  DSLAM_REQUIRE(e && s && r && out, "null argument");
+  return launch_count_visible(e, s, r, min_id, max_id, out);
+}
+int dslam_create_expected_depths(dslam_engine *e, const dslam_scene *s, dslam_render_state *r, const float M[16],
+                                 const float intr[4]) {
+  DSLAM_REQUIRE(e && s && r && M && intr, "null argument");
+  int rc = launch_expected_depths(e, s, r, M, intr);
+  if (rc) return rc;
+  return finish_call(e);
+}
+
+static int image_out(dslam_engine *e, dslam_render_state *r, int type, uint8_t *out_rgba, float *out_float) {
+  const size_t npix = (size_t)r->w * r->h;
+  if (out_rgba || out_float) {
+    DSLAM_REQUIRE(!(out_rgba && out_float), "pass only one output buffer");
+    if (type == DSLAM_IMAGE_DEPTH) {
+      DSLAM_REQUIRE(out_float, "DSLAM_IMAGE_DEPTH renders into the float output");
+      DSLAM_HIP(hipMemcpyAsync(out_float, r->image_float, npix * sizeof(float), hipMemcpyDeviceToHost, e->stream));
+    } else {
+      DSLAM_REQUIRE(out_rgba, "this image type renders into the rgba output");
+      DSLAM_HIP(hipMemcpyAsync(out_rgba, r->image_rgba, npix * 4, hipMemcpyDeviceToHost, e->stream));
+    }
+    DSLAM_HIP(hipStreamSynchronize(e->stream));  // host buffers are valid on return
+    return DSLAM_OK;
+  }
+  return finish_call(e);
+}
+
+int dslam_render_image(dslam_engine *e, const dslam_scene *s, dslam_render_state *r, const float M[16],
+                       const float intr[4], int type, uint8_t *out_rgba, float *out_float) {
+  DSLAM_REQUIRE(e && s && r && M && intr, "null argument");
+  DSLAM_REQUIRE(type >= 0 && type <= DSLAM_IMAGE_DEPTH, "unknown image type");
+  int rc = launch_render(e, s, r, M, intr, type);
+  if (rc) return rc;
+  return image_out(e, r, type, out_rgba, out_float);
+}
+
+int dslam_get_image(dslam_engine *e, const dslam_scene *s, dslam_render_state *r, const float M[16],
+                    const float intr[4], int type, uint8_t *out_rgba, float *out_float) {
+  DSLAM_REQUIRE(e && s && r && M && intr, "null argument");
+  DSLAM_REQUIRE(type >= 0 && type <= DSLAM_IMAGE_DEPTH, "unknown image type");
+  int rc;
+  if ((rc = launch_find_visible(e, s, r, M, intr))) return rc;
+  if ((rc = launch_expected_depths(e, s, r, M, intr))) return rc;
+  if ((rc = launch_render(e, s, r, M, intr, type))) return rc;
+  return image_out(e, r, type, out_rgba, out_float);
+}
+
+int dslam_create_icp_maps(dslam_engine *e, const dslam_scene *s, dslam_render_state *r, const float M[16],
+                          const float intr[4], float *out_points, float *out_normals) {
+  DSLAM_REQUIRE(e && s && r && M && intr, "null argument");
+  int rc;
+  if ((rc = launch_expected_depths(e, s, r, M, intr))) return rc;
+  if ((rc = launch_icp_maps(e, s, r, M, intr))) return rc;
+  const size_t bytes = (size_t)r->w * r->h * sizeof(float4);
+  if (out_points) DSLAM_HIP(hipMemcpyAsync(out_points, r->icp_points, bytes, hipMemcpyDeviceToHost, e->stream));
+  if (out_normals) DSLAM_HIP(hipMemcpyAsync(out_normals, r->icp_normals, bytes, hipMemcpyDeviceToHost, e->stream));
+  if (out_points || out_normals) { DSLAM_HIP(hipStreamSynchronize(e->stream)); return DSLAM_OK; }
+  return finish_call(e);
+}
+
+// ---- read-back -----------------------------------------------------------------------------------------------
+int dslam_get_stats(dslam_engine *e, const dslam_scene *s, const dslam_render_state *r, dslam_stats *out) {
+  DSLAM_REQUIRE(e && s && out, "null argument");
+  char *host = reinterpret_cast<char *>(e->pinned);
+  SceneCounters *sc = reinterpret_cast<SceneCounters *>(host);
+  RenderCounters *rc = reinterpret_cast<RenderCounters *>(host + 128);
+  DSLAM_HIP(hipMemcpyAsync(sc, s->counters, sizeof(SceneCounters), hipMemcpyDeviceToHost, e->stream));
+  if (r) DSLAM_HIP(hipMemcpyAsync(rc, r->counters, sizeof(RenderCounters), hipMemcpyDeviceToHost, e->stream));
+  DSLAM_HIP(hipStreamSynchronize(e->stream));
+  memset(out, 0, sizeof(*out));
+  out->num_allocated_blocks = s->p.num_local_blocks;
+  out->last_free_block_id = sc->last_free;
+  out->last_free_excess_id = sc->last_free_ex;
+  out->no_visible_entries = r ? rc->no_visible : 0;
+  out->decayed_block_count = sc->decayed_blocks;
+  out->slid_block_count = sc->slid_blocks;
+  out->frame_counter = s->frame_counter;
+  out->fusion_fifo_len = s->ring_next[0] - s->ring_head[0];
+  out->defusion_fifo_len = s->ring_next[1] - s->ring_head[1];
+  out->alloc_failures = sc->alloc_failures;
+  out->last_swapped_in = s->last_swapped_in;
+  out->last_swapped_out = s->last_swapped_out;
+  if (sc->error_flags & 1) {
+    set_last_error("allocation ray needed more steps than the order key encodes (non-rigid pose or mu/voxel_size changed?)");
+    return DSLAM_ERR_UNSUPPORTED;
+  }
+  return DSLAM_OK;
+}
+
+static int d2h(dslam_engine *e, void *dst, const void *src, size_t bytes) {
+  DSLAM_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, e->stream));
+  DSLAM_HIP(hipStreamSynchronize(e->stream));
+  return DSLAM_OK;
+}
+static int h2d(dslam_engine *e, void *dst, const void *src, size_t bytes) {
+  DSLAM_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, e->stream));
+  DSLAM_HIP(hipStreamSynchronize(e->stream));
+  return DSLAM_OK;
+}
+
+int dslam_download_hash_table(dslam_engine *e, const dslam_scene *s, dslam_hash_entry *out) {
+  DSLAM_REQUIRE(e && s && out, "null argument");
+  return d2h(e, out, s->hash, (size_t)s->n_entries * sizeof(HashEntry));
+}
+int dslam_download_voxel_blocks(dslam_engine *e, const dslam_scene *s, int first, int n, dslam_voxel *out) {
+  DSLAM_REQUIRE(e && s && out && first >= 0 && n >= 0 && first + n <= s->p.num_local_blocks, "bad block range");
+  return d2h(e, out, s->voxels + (size_t)first * kBlock3, (size_t)n * kBlock3 * sizeof(uint2));
+}
+int dslam_download_allocation_list(dslam_engine *e, const dslam_scene *s, int32_t *out) {
+  DSLAM_REQUIRE(e && s && out, "null argument");
+  return d2h(e, out, s->alloc_list, (size_t)s->p.num_local_blocks * sizeof(int));
+}
+int dslam_download_excess_list(dslam_engine *e, const dslam_scene *s, int32_t *out) {
+  DSLAM_REQUIRE(e && s && out, "null argument");
+  return d2h(e, out, s->excess_list, (size_t)s->p.num_excess * sizeof(int));
+}
+int dslam_download_visible_ids(dslam_engine *e, const dslam_render_state *r, int32_t *out, int capacity, int *count) {
+  DSLAM_REQUIRE(e && r && out, "null argument");
+  RenderCounters *rc = reinterpret_cast<RenderCounters *>(reinterpret_cast<char *>(e->pinned) + 128);
+  int st = d2h(e, rc, r->counters, sizeof(RenderCounters));
+  if (st) return st;
+  int n = rc->no_visible < capacity ? rc->no_visible : capacity;
+  if (count) *count = rc->no_visible;
+  if (n > 0) return d2h(e, out, r->visible_ids, (size_t)n * sizeof(int));
+  return DSLAM_OK;
+}
+int dslam_download_visible_types(dslam_engine *e, const dslam_render_state *r, uint8_t *out) {
+  DSLAM_REQUIRE(e && r && out, "null argument");
+  return d2h(e, out, r->visible_type, r->n_entries);
+}
+int dslam_download_range_image(dslam_engine *e, const dslam_render_state *r, float *out) {
+  DSLAM_REQUIRE(e && r && out, "null argument");
+  return d2h(e, out, r->range, (size_t)r->w * r->h * sizeof(float2));
+}
+int dslam_download_raycast_result(dslam_engine *e, const dslam_render_state *r, float *out) {
+  DSLAM_REQUIRE(e && r && out, "null argument");
+  return d2h(e, out, r->raycast, (size_t)r->w * r->h * sizeof(float4));
+}
+int dslam_download_view_depth(dslam_engine *e, const dslam_view *v, float *out) {
+  DSLAM_REQUIRE(e && v && out, "null argument");
+  return d2h(e, out, v->depth, (size_t)v->w_d * v->h_d * sizeof(float));
+}
+int dslam_download_swap_states(dslam_engine *e, const dslam_scene *s, uint8_t *out) {
+  DSLAM_REQUIRE(e && s && out && s->swap_state, "scene has no swap state");
+  return d2h(e, out, s->swap_state, s->n_entries);
+}
+int dslam_download_last_seen(dslam_engine *e, const dslam_scene *s, int32_t *out) {
+  DSLAM_REQUIRE(e && s && out, "null argument");
+  return d2h(e, out, s->last_seen, (size_t)s->p.num_local_blocks * sizeof(int));
+}
+int dslam_download_stored_block(dslam_engine *e, const dslam_scene *s, int entry, dslam_voxel *out) {
+  DSLAM_REQUIRE(e && s && s->stored && entry >= 0 && entry < s->n_entries, "bad entry / no global cache");
+  DSLAM_HIP(hipStreamSynchronize(e->stream));
+  if (out) memcpy(out, s->stored + (size_t)entry * kBlock3, kBlock3 * sizeof(dslam_voxel));
+  return s->has_stored[entry] ? 1 : 0;
+}
+int dslam_download_alloc_scratch(dslam_engine *e, const dslam_scene *s, uint8_t *types, int16_t *coords) {
+  DSLAM_REQUIRE(e && s && e->scratch_entries >= s->n_entries, "no allocation pass has run");
+  int rc = 0;
+  if (types) rc = d2h(e, types, e->alloc_type, s->n_entries);
+  if (!rc && coords) rc = d2h(e, coords, e->block_coords, (size_t)s->n_entries * sizeof(short4));
+  return rc;
+}
+
+int dslam_upload_scene_state(dslam_engine *e, dslam_scene *s, const dslam_hash_entry *hash, const int32_t *alloc_list,
+                             int last_free, const int32_t *excess_list, int last_free_ex) {
+  DSLAM_REQUIRE(e && s, "null argument");
+  int rc = 0;
+  if (hash) rc = h2d(e, s->hash, hash, (size_t)s->n_entries * sizeof(HashEntry));
+  SceneCounters *sc = reinterpret_cast<SceneCounters *>(e->pinned);
+  if (!rc && (alloc_list || excess_list)) {
+    rc = d2h(e, sc, s->counters, sizeof(SceneCounters));
+    if (!rc && alloc_list) {
+      rc = h2d(e, s->alloc_list, alloc_list, (size_t)s->p.num_local_blocks * sizeof(int));
+      sc->last_free = last_free;
+    }
+    if (!rc && excess_list) {
+      rc = h2d(e, s->excess_list, excess_list, (size_t)s->p.num_excess * sizeof(int));
+      sc->last_free_ex = last_free_ex;
+    }
+    if (!rc) rc = h2d(e, s->counters, sc, sizeof(SceneCounters));
+  }
+  return rc;
+}
+int dslam_upload_voxel_blocks(dslam_engine *e, dslam_scene *s, int first, int n, const dslam_voxel *host) {
+  DSLAM_REQUIRE(e && s && host && first >= 0 && n >= 0 && first + n <= s->p.num_local_blocks, "bad block range");
+  return h2d(e, s->voxels + (size_t)first * kBlock3, host, (size_t)n * kBlock3 * sizeof(uint2));
+}
+int dslam_upload_visible_ids(dslam_engine *e, dslam_render_state *r, const int32_t *ids, int count) {
+  DSLAM_REQUIRE(e && r && ids && count >= 0 && count <= r->n_local, "bad visible list");
+  int rc = h2d(e, r->visible_ids, ids, (size_t)count * sizeof(int));
+  if (rc) return rc;
+  RenderCounters *rcn = reinterpret_cast<RenderCounters *>(reinterpret_cast<char *>(e->pinned) + 128);
+  rc = d2h(e, rcn, r->counters, sizeof(RenderCounters));
+  if (rc) return rc;
+  rcn->no_visible = count;
+  return h2d(e, r->counters, rcn, sizeof(RenderCounters));
+}
+
+void *dslam_scene_voxel_blocks_dev(dslam_scene *s) { return s ? s->voxels : nullptr; }
+void *dslam_scene_hash_table_dev(dslam_scene *s) { return s ? s->hash : nullptr; }
+void *dslam_render_state_image_dev(dslam_render_state *r, int want_float) {
+  if (!r) return nullptr;
+  return want_float ? (void *)r->image_float : (void *)r->image_rgba;
+}
+
+// ---- instrumentation -----------------------------------------------------------------------------------------
+int dslam_time_integrate(dslam_engine *e, dslam_scene *s, const dslam_view *v, const dslam_render_state *r,
+                         const float M_d[16], const float intr[4], int iterations, float *out_ms, int *out_blocks) {
+  int rc = check_frame_args(e, s, v, r, M_d, intr);
+  if (rc) return rc;
+  DSLAM_REQUIRE(iterations > 0 && out_ms, "bad argument");
+  hipEvent_t a, b;
+  DSLAM_HIP(hipEventCreate(&a));
+  DSLAM_HIP(hipEventCreate(&b));
+  const bool saved = e->timer_enabled;
+  e->timer_enabled = false;
+  rc = launch_integrate(e, s, v, r, M_d, intr, nullptr, nullptr, false);  // warm-up
+  DSLAM_HIP(hipEventRecord(a, e->stream));
+  for (int i = 0; i < iterations && !rc; i++) rc = launch_integrate(e, s, v, r, M_d, intr, nullptr, nullptr, false);
+  DSLAM_HIP(hipEventRecord(b, e->stream));
+  DSLAM_HIP(hipEventSynchronize(b));
+  e->timer_enabled = saved;
+  float ms = 0;
+  DSLAM_HIP(hipEventElapsedTime(&ms, a, b));
+  (void)hipEventDestroy(a);
+  (void)hipEventDestroy(b);
+  *out_ms = ms / iterations;
+  if (out_blocks) {
+    RenderCounters *rcn = reinterpret_cast<RenderCounters *>(reinterpret_cast<char *>(e->pinned) + 128);
+    int st = d2h(e, rcn, r->counters, sizeof(RenderCounters));
+    if (st) return st;
+    *out_blocks = rcn->no_visible;
+  }
+  return rc;
+}
+
+int dslam_kernel_timer_enable(dslam_engine *e, int enable) {
+  DSLAM_REQUIRE(e, "null engine");
+  DSLAM_HIP(hipStreamSynchronize(e->stream));
+  if (enable && e->ev_pool.empty()) {
+    const size_t n = 2 * 8192;  // up to 8192 timed launches between reads
+    DSLAM_REQUIRE(e->pinned_bytes >= 256 + 8192 * sizeof(int), "pinned mirror too small");
+    e->ev_pool.resize(n);
+    for (size_t i = 0; i < n; i++) DSLAM_HIP(hipEventCreate(&e->ev_pool[i]));
+  }
+  e->timer_enabled = enable != 0;
+  e->ev_used = 0;
+  e->timer_ms = 0; e->timer_launches = 0; e->timer_blocks = 0;
+  return DSLAM_OK;
+}
+
+int dslam_kernel_timer_read(dslam_engine *e, double *out_ms, int64_t *out_launches, int64_t *out_blocks) {
+  DSLAM_REQUIRE(e, "null engine");
+  DSLAM_HIP(hipStreamSynchronize(e->stream));
+  const int *counts = reinterpret_cast<int *>(e->pinned) + 64;
+  for (size_t i = 0; i + 1 < e->ev_used; i += 2) {
+    float ms = 0;
+    DSLAM_HIP(hipEventElapsedTime(&ms, e->ev_pool[i], e->ev_pool[i + 1]));
+    e->timer_ms += ms;
+    e->timer_launches++;
+    e->timer_blocks += counts[i / 2];
+  }
+  e->ev_used = 0;
+  if (out_ms) *out_ms = e->timer_ms;
+  if (out_launches) *out_launches = e->timer_launches;
+  if (out_blocks) *out_blocks = e->timer_blocks;
+  return DSLAM_OK;
+}
+
+}  // extern "C"

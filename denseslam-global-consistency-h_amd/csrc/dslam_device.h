@@ -175,4 +175,77 @@ __device__ __forceinline__ int block_excl_scan(int v, int *lds_wave_sums /* [NWA
   return off + incl - v;
 }
 
+
+// ---- ordered compaction over the hash table ---------------------------------------------------------------
+// Every ordered compaction is count -> scan -> apply over tiles of kTileEntries consecutive entries (one
+// 256-thread workgroup per tile, 4 consecutive entries per thread), so output order is ascending entry index.
+
+// exclusive scan over up to `n` tile counts by ONE workgroup of 1024 threads; C interleaved channels
+template <int C>
+__device__ void scan_tiles(const int *__restrict__ counts, int *__restrict__ offsets, int n, int totals[C]) {
+  __shared__ int wave_sums[C][16];
+  __shared__ int carry[C];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (tid < C) carry[tid] = 0;
+  __syncthreads();
+  for (int base = 0; base < n; base += 1024) {
+    const int i = base + tid;
+    int v[C], incl[C];
+#pragma unroll
+    for (int c = 0; c < C; c++) {
+      v[c] = (i < n) ? counts[i * C + c] : 0;
+      incl[c] = wave_incl_scan(v[c]);
+      if (lane == 63) wave_sums[c][wave] = incl[c];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < C; c++) {
+      int off = carry[c];
+      for (int w = 0; w < wave; w++) off += wave_sums[c][w];
+      if (i < n) offsets[i * C + c] = off + incl[c] - v[c];
+    }
+    __syncthreads();
+    if (tid < C) {
+      int t = carry[tid];
+      for (int w = 0; w < 16; w++) t += wave_sums[tid][w];
+      carry[tid] = t;
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int c = 0; c < C; c++) totals[c] = carry[c];
+}
+
+// generic single-channel scan: offsets per tile, total (clipped to capacity) to *total_out
+static __global__ __launch_bounds__(1024) void k_scan_count(const int *tile_counts, int *tile_offsets, int n_tiles,
+                                                            int *total_out, int capacity) {
+  int totals[1];
+  scan_tiles<1>(tile_counts, tile_offsets, n_tiles, totals);
+  if (threadIdx.x == 0) *total_out = totals[0] < capacity ? totals[0] : capacity;
+}
+
+// pass 2 of every ordered compaction: entry index t goes to out[rank] for flags[t] > 0, ranks ascending in t
+static __global__ __launch_bounds__(256) void k_compact_apply(const unsigned char *__restrict__ flags, int n_entries,
+                                                       const int *__restrict__ tile_offsets, int *__restrict__ out,
+                                                       int capacity) {
+  __shared__ int red[4];
+  const int t0 = blockIdx.x * kTileEntries + threadIdx.x * 4;
+  unsigned char f[4] = {0, 0, 0, 0};
+  if (t0 < n_entries) {
+    const uchar4 v = *reinterpret_cast<const uchar4 *>(flags + t0);
+    f[0] = v.x; f[1] = v.y; f[2] = v.z; f[3] = v.w;
+  }
+  const int c = (f[0] > 0) + (f[1] > 0) + (f[2] > 0) + (f[3] > 0);
+  int tot;
+  int r = block_excl_scan<4>(c, red, tot);
+  if (tot == 0) return;
+  r += tile_offsets[blockIdx.x];
+#pragma unroll
+  for (int k = 0; k < 4; k++)
+    if (f[k] > 0) {
+      if (r < capacity) out[r] = t0 + k;
+      r++;
+    }
+}
+
 }  // namespace dslam

@@ -2,7 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
-#include <deque>
+#include <cstring>
 #include <string>
 #include <vector>
 
@@ -30,15 +30,6 @@ int hip_fail(hipError_t err, const char *what, const char *file, int line);
 
 // host inverse of a column-major 4x4 (ORUtils::Matrix4::inv); used for invM_d = pose_d->GetInvM()
 bool invert_matrix(const float *m, float *dst);
-
-// one queued per-frame visible list (block positions, device resident)
-struct VisibleList {
-  short4 *pos_dev = nullptr;  // (x, y, z, 1) per block
-  int count = 0;
-  int frame_idx = 0;
-  double timestamp = 0;
-  bool decayed = false;
-};
 
 }  // namespace dslam
 
@@ -88,8 +79,11 @@ struct dslam_scene {
   int *excess_list = nullptr;
   int *last_seen = nullptr;           // per voxel-block slot
   dslam::SceneCounters *counters = nullptr;  // device
-  // queued visible lists (fusion / defusion)
-  std::deque<dslam::VisibleList> fifo[2];
+  // visible-list history: per voxel-block slot two bit rings (0 fusion, 1 defusion); list k of ring q
+  // owns bit k % (64*history_words) of masks[(slot*2+q)*history_words ...]
+  int history_words = 4;
+  unsigned long long *masks = nullptr;  // device
+  int ring_head[2] = {0, 0}, ring_next[2] = {0, 0}, decay_cursor[2] = {0, 0};
   int frame_counter = 0;
   // ITMGlobalCache
   unsigned char *swap_state = nullptr;  // device [entries]
@@ -136,8 +130,7 @@ int launch_allocate(dslam_engine *e, dslam_scene *s, const dslam_view *v, dslam_
 int launch_integrate(dslam_engine *e, dslam_scene *s, const dslam_view *v, const dslam_render_state *r,
                      const float *M_d, const float *intr_d, const float *M_rgb, const float *intr_rgb,
                      bool deintegrate);
-int launch_push_visible_list(dslam_engine *e, dslam_scene *s, const dslam_render_state *r, int which,
-                             double timestamp);
+int launch_push_visible_list(dslam_engine *e, dslam_scene *s, const dslam_render_state *r, int which);
 int launch_find_visible(dslam_engine *e, const dslam_scene *s, dslam_render_state *r, const float *M,
                         const float *intr);
 int launch_count_visible(dslam_engine *e, const dslam_scene *s, const dslam_render_state *r, int min_id, int max_id,
@@ -149,7 +142,7 @@ int launch_render(dslam_engine *e, const dslam_scene *s, dslam_render_state *r, 
 int launch_icp_maps(dslam_engine *e, const dslam_scene *s, dslam_render_state *r, const float *M, const float *intr);
 int launch_decay(dslam_engine *e, dslam_scene *s, dslam_render_state *r, int max_weight, int min_age, int force_all,
                  int which);
-int launch_slide_window(dslam_engine *e, dslam_scene *s, dslam_render_state *r, int which, int keep);
+int launch_slide_pop(dslam_engine *e, dslam_scene *s, dslam_render_state *r, int which);
 int launch_swap_in(dslam_engine *e, dslam_scene *s, dslam_render_state *r);
 int launch_swap_out(dslam_engine *e, dslam_scene *s, dslam_render_state *r, bool ignore_visibility);
 int launch_save_to_global(dslam_engine *e, dslam_scene *s);

@@ -1,0 +1,246 @@
+// integrate.hip -- IntegrateIntoScene and its inverse (de-integration) for gfx950: the bandwidth kernel.
+//
+// Reference call sites: denseMapper->ProcessFrame -> IntegrateIntoScene (InfiniTamDriver.h:187-192,
+// DenseSlam.cpp:213,236,403) and denseMapper->DeProcessFrame (InfiniTamDriver.h:194-199, DenseSlam.cpp:393,425).
+// Algorithm: SURVEY.md Appendix A.5 / A.11.
+//
+// Mapping (wave64, no MFMA -- this is streaming read-modify-write):
+//   one wavefront owns one 8x8x8 voxel block = 4 KiB.  It moves the block as 4 x global_load_dwordx4 per lane
+//   (1 KiB per wave instruction, the widest coalesced shape), so a lane holds 8 voxels:
+//       load j (0..3), lane l  ->  voxels x in {2(l&3), 2(l&3)+1}, y = (l>>2)&7, z = 2j + (l>>5)
+//   A wave takes G consecutive entries of the visible list at a time: lanes 0..G-1 gather the G hash entries
+//   with one vector load each (16 B, the table stays in the Infinity Cache) and the wave then walks them with
+//   v_readlane -- no per-block dependent scalar-load chain.  Depth / RGB gathers hit L2 (1.2 MB images).
+//   Only 16-byte chunks that changed are written back.
+//   Grid = fixed 2048 workgroups of 4 waves (one full residency wave of the 256 CUs), grid-stride over the
+//   visible list whose length is read from device memory (no host round trip after allocation).
+#include "dslam_internal.h"
+
+#pragma clang fp contract(off)
+
+namespace dslam {
+
+struct IntegrateParams {
+  const int *visible_ids;
+  const RenderCounters *rc;
+  const HashEntry *hash;
+  uint4 *voxels16;  // voxel blocks as 16-byte chunks (2 voxels)
+  const float *depth;
+  const uchar4 *rgba;
+  int Wd, Hd, Wr, Hr;
+  Mat4 M_d, M_rgb;
+  float fx_d, fy_d, cx_d, cy_d;
+  float fx_r, fy_r, cx_r, cy_r;
+  float voxel_size, mu;
+  int max_w, stop_max;
+  int depth_weighting, max_new_w;
+  float max_distance;
+  int shard, num_shards, chunk_blocks;
+};
+
+__device__ __forceinline__ int new_weight(const IntegrateParams &p, float depth_measure) {
+  if (!p.depth_weighting) return 1;
+  const float dd = depth_measure < p.max_distance ? depth_measure : p.max_distance;
+  const int w = (int)roundf((float)p.max_new_w * (1.0f - dd / p.max_distance));
+  return w < 1 ? 1 : w;
+}
+
+__device__ __forceinline__ void bilinear_rgb(const uchar4 *__restrict__ rgba, float px, float py, int W, float out[3]) {
+  const int ix = (int)floorf(px), iy = (int)floorf(py);
+  const float dx = px - (float)ix, dy = py - (float)iy;
+  const uchar4 a = rgba[ix + iy * W], b = rgba[(ix + 1) + iy * W], c = rgba[ix + (iy + 1) * W],
+               d = rgba[(ix + 1) + (iy + 1) * W];
+  out[0] = ((float)a.x * (1.0f - dx) * (1.0f - dy) + (float)b.x * dx * (1.0f - dy) + (float)c.x * (1.0f - dx) * dy +
+            (float)d.x * dx * dy);
+  out[1] = ((float)a.y * (1.0f - dx) * (1.0f - dy) + (float)b.y * dx * (1.0f - dy) + (float)c.y * (1.0f - dx) * dy +
+            (float)d.y * dx * dy);
+  out[2] = ((float)a.z * (1.0f - dx) * (1.0f - dy) + (float)b.z * dx * (1.0f - dy) + (float)c.z * (1.0f - dx) * dy +
+            (float)d.z * dx * dy);
+}
+
+// ComputeUpdatedVoxelInfo<hasColor>::compute on a packed voxel (lo, hi).  Returns true if the voxel changed.
+template <bool DEINT>
+__device__ __forceinline__ bool update_voxel(unsigned &lo, unsigned &hi, const Vec4 &pm, const IntegrateParams &p) {
+  float eta;
+  bool changed = false;
+  {  // computeUpdatedVoxelDepthInfo
+    const Vec4 pc = mul(p.M_d, pm);
+    if (pc.z <= 0) return false;
+    const float u = p.fx_d * pc.x / pc.z + p.cx_d;
+    const float w = p.fy_d * pc.y / pc.z + p.cy_d;
+    if ((u < 1) || (u > p.Wd - 2) || (w < 1) || (w > p.Hd - 2)) return false;
+    const float dm = p.depth[(int)(u + 0.5f) + (int)(w + 0.5f) * p.Wd];
+    if (dm <= 0.0f) return false;
+    eta = dm - pc.z;
+    if (eta < -p.mu) return false;
+    const float oldF = sdf_to_float((short)(lo & 0xffffu));
+    const int oldW = (int)((lo >> 16) & 0xffu);
+    float newF = fminf(1.0f, eta / p.mu);
+    int newW = new_weight(p, dm);
+    if (!DEINT) {
+      newF = (float)oldW * oldF + (float)newW * newF;
+      newW = oldW + newW;
+      newF /= (float)newW;
+      newW = newW < p.max_w ? newW : p.max_w;
+      const unsigned sdf = (unsigned)(unsigned short)float_to_sdf(newF);
+      lo = (lo & 0xff000000u) | ((unsigned)newW << 16) | sdf;
+      changed = true;
+    } else if (oldW >= newW) {
+      const int remW = oldW - newW;
+      if (remW == 0) {
+        lo = (lo & 0xff000000u) | 0x7fffu;
+      } else {
+        float F = ((float)oldW * oldF - (float)newW * newF) / (float)remW;
+        F = fmaxf(-1.0f, fminf(1.0f, F));
+        const unsigned sdf = (unsigned)(unsigned short)float_to_sdf(F);
+        lo = (lo & 0xff000000u) | ((unsigned)remW << 16) | sdf;
+      }
+      changed = true;
+    }
+  }
+  if ((eta > p.mu) || (fabsf(eta / p.mu) > 0.25f)) return changed;
+  {  // computeUpdatedVoxelColorInfo
+    const Vec4 pc = mul(p.M_rgb, pm);
+    const float u = p.fx_r * pc.x / pc.z + p.cx_r;
+    const float w = p.fy_r * pc.y / pc.z + p.cy_r;
+    if ((u < 1) || (u > p.Wr - 2) || (w < 1) || (w > p.Hr - 2)) return changed;
+    float m[3];
+    bilinear_rgb(p.rgba, u, w, p.Wr, m);
+    const unsigned oc[3] = {lo >> 24, hi & 0xffu, (hi >> 8) & 0xffu};
+    const unsigned wc = (hi >> 16) & 0xffu;
+    const float oldW = (float)wc;
+    unsigned nc[3];
+    unsigned new_wc;
+    if (!DEINT) {
+      float newW = oldW + 1.0f;
+#pragma unroll
+      for (int k = 0; k < 3; k++) {
+        const float oldC = (float)oc[k] / 255.0f;
+        const float c = m[k] / 255.0f;
+        const float v = (oldC * oldW + c * 1.0f) / newW;
+        nc[k] = (unsigned)(unsigned char)(v * 255.0f);
+      }
+      newW = fminf(newW, (float)p.max_w);
+      new_wc = (unsigned)(unsigned char)newW;
+    } else {
+      if (wc < 1) return changed;
+      const float remW = oldW - 1.0f;
+      if (remW == 0.0f) {
+        nc[0] = nc[1] = nc[2] = 0;
+        new_wc = 0;
+      } else {
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+          const float oldC = (float)oc[k] / 255.0f;
+          const float c = m[k] / 255.0f;
+          float v = (oldC * oldW - c * 1.0f) / remW;
+          v = fmaxf(0.0f, fminf(1.0f, v));
+          nc[k] = (unsigned)(unsigned char)(v * 255.0f);
+        }
+        new_wc = (unsigned)(unsigned char)remW;
+      }
+    }
+    lo = (lo & 0x00ffffffu) | (nc[0] << 24);
+    hi = (hi & 0xff000000u) | nc[1] | (nc[2] << 8) | (new_wc << 16);
+    changed = true;
+  }
+  return changed;
+}
+
+constexpr int kMaxGroup = 8;
+
+template <bool DEINT>
+__global__ __launch_bounds__(256) void k_integrate(IntegrateParams p) {
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)((blockIdx.x * 256 + threadIdx.x) >> 6));
+  const int n_waves = gridDim.x * 4;
+  const int nvis = p.rc->no_visible;
+  int G = (nvis + n_waves - 1) / n_waves;
+  G = G < 1 ? 1 : (G > kMaxGroup ? kMaxGroup : G);
+
+  // lane-constant voxel coordinates inside a block
+  const int vx0 = (lane & 3) * 2, vy = (lane >> 2) & 7, vz0 = lane >> 5;
+
+  for (int base = wave * G; base < nvis; base += n_waves * G) {
+    // lanes 0..G-1 gather the group's hash entries (one 16-byte load each)
+    int e_ptr = -2, e_px = 0, e_py = 0, e_pz = 0;
+    if (lane < G && base + lane < nvis) {
+      const HashEntry e = load_entry(p.hash, p.visible_ids[base + lane]);
+      e_ptr = e.ptr; e_px = e.pos[0]; e_py = e.pos[1]; e_pz = e.pos[2];
+    }
+    for (int k = 0; k < G; k++) {
+      const int ptr = __builtin_amdgcn_readlane(e_ptr, k);
+      if (ptr < 0) continue;
+      if (p.num_shards > 1 && ((ptr / p.chunk_blocks) % p.num_shards) != p.shard) continue;
+      const int gx = __builtin_amdgcn_readlane(e_px, k) * kBlock;
+      const int gy = __builtin_amdgcn_readlane(e_py, k) * kBlock;
+      const int gz = __builtin_amdgcn_readlane(e_pz, k) * kBlock;
+      uint4 *blk = p.voxels16 + (size_t)ptr * (kBlock3 / 2);
+      uint4 v[4];
+#pragma unroll
+      for (int j = 0; j < 4; j++) v[j] = blk[j * 64 + lane];
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        const int z = j * 2 + vz0;
+        bool ch = false;
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+          unsigned &lo = h ? v[j].z : v[j].x;
+          unsigned &hi = h ? v[j].w : v[j].y;
+          if (!DEINT && p.stop_max && (int)((lo >> 16) & 0xffu) == p.max_w) continue;
+          Vec4 pm;
+          pm.x = (float)(gx + vx0 + h) * p.voxel_size;
+          pm.y = (float)(gy + vy) * p.voxel_size;
+          pm.z = (float)(gz + z) * p.voxel_size;
+          pm.w = 1.0f;
+          ch |= update_voxel<DEINT>(lo, hi, pm, p);
+        }
+        if (ch) blk[j * 64 + lane] = v[j];
+      }
+    }
+  }
+}
+
+static void fill_params(IntegrateParams &ip, dslam_engine *e, dslam_scene *s, const dslam_view *v,
+                        const dslam_render_state *r, const float *M_d, const float *intr_d, const float *M_rgb,
+                        const float *intr_rgb) {
+  ip.visible_ids = r->visible_ids; ip.rc = r->counters; ip.hash = s->hash;
+  ip.voxels16 = reinterpret_cast<uint4 *>(s->voxels);
+  ip.depth = v->depth; ip.rgba = v->rgba;
+  ip.Wd = v->w_d; ip.Hd = v->h_d; ip.Wr = v->w_rgb; ip.Hr = v->h_rgb;
+  memcpy(ip.M_d.m, M_d, 64);
+  memcpy(ip.M_rgb.m, M_rgb ? M_rgb : M_d, 64);
+  const float *kr = intr_rgb ? intr_rgb : intr_d;
+  ip.fx_d = intr_d[0]; ip.fy_d = intr_d[1]; ip.cx_d = intr_d[2]; ip.cy_d = intr_d[3];
+  ip.fx_r = kr[0]; ip.fy_r = kr[1]; ip.cx_r = kr[2]; ip.cy_r = kr[3];
+  ip.voxel_size = s->p.voxel_size; ip.mu = s->p.mu; ip.max_w = s->p.max_w;
+  ip.stop_max = s->p.stop_integrating_at_max_w;
+  ip.depth_weighting = e->wp.depth_weighting; ip.max_new_w = e->wp.max_new_w; ip.max_distance = e->wp.max_distance;
+  ip.shard = s->shard; ip.num_shards = s->num_shards; ip.chunk_blocks = s->chunk_blocks;
+}
+
+constexpr int kIntegrateGrid = 2048;
+
+int launch_integrate(dslam_engine *e, dslam_scene *s, const dslam_view *v, const dslam_render_state *r,
+                     const float *M_d, const float *intr_d, const float *M_rgb, const float *intr_rgb,
+                     bool deintegrate) {
+  IntegrateParams ip;
+  fill_params(ip, e, s, v, r, M_d, intr_d, M_rgb, intr_rgb);
+  const bool timed = e->timer_enabled && e->ev_used + 2 <= e->ev_pool.size();
+  if (timed) DSLAM_HIP(hipEventRecord(e->ev_pool[e->ev_used], e->stream));
+  if (deintegrate)
+    hipLaunchKernelGGL(k_integrate<true>, dim3(kIntegrateGrid), dim3(256), 0, e->stream, ip);
+  else
+    hipLaunchKernelGGL(k_integrate<false>, dim3(kIntegrateGrid), dim3(256), 0, e->stream, ip);
+  if (timed) {
+    DSLAM_HIP(hipEventRecord(e->ev_pool[e->ev_used + 1], e->stream));
+    // visible-block count of this launch, for the algorithmic-bytes figure (4-byte async copy, outside the events)
+    int *slot = reinterpret_cast<int *>(e->pinned) + 64 + (e->ev_used / 2);
+    DSLAM_HIP(hipMemcpyAsync(slot, &r->counters->no_visible, sizeof(int), hipMemcpyDeviceToHost, e->stream));
+    e->ev_used += 2;
+  }
+  DSLAM_HIP(hipGetLastError());
+  return DSLAM_OK;
+}
+
+}  // namespace dslam

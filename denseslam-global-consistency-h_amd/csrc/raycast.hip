@@ -1,0 +1,574 @@
+// raycast.hip -- ITMVisualisationEngine for gfx950: FindVisibleBlocks, CountVisibleBlocks,
+// CreateExpectedDepths, RenderImage (raycast + shading), CreateICPMaps.
+//
+// Reference call sites: ITMMainEngine::GetImage via InfiniTamDriver::GetImage / GetFloatImage
+// (InfiniTamDriver.cpp:229-277, types :16-38), trackingController->Prepare (InfiniTamDriver.h:208-220),
+// mapManager->countVisibleBlocks (DenseSlam.cpp:555-556).  Algorithm: SURVEY.md Appendix A.6, A.7.
+//
+// Mapping: the ray march is latency/gather bound (random 16-B hash probes + 8-B voxel reads).  One workgroup
+// renders a 16x16 pixel tile; each wavefront an 8x8 sub-tile, i.e. exactly one cell of the 1/8-resolution range
+// image, so (zmin, zmax) and -- mostly -- the marched blocks are wave-uniform and the per-lane block cache hits.
+#include "dslam_internal.h"
+
+#pragma clang fp contract(off)
+
+namespace dslam {
+
+// ---------------------------------------------------------------------------------------------------------
+// FindVisibleBlocks: ordered compaction of entries with ptr >= 0 that pass the 8-corner frustum test
+// ---------------------------------------------------------------------------------------------------------
+struct FrustumParams {
+  Mat4 M;
+  float fx, fy, cx, cy, voxel_size;
+  int W, H;
+};
+
+__global__ __launch_bounds__(256) void k_frustum_flags(const HashEntry *__restrict__ hash, int n_entries,
+                                                       FrustumParams p, unsigned char *__restrict__ flags,
+                                                       int *__restrict__ tile_counts) {
+  __shared__ int red[4];
+  const int t0 = blockIdx.x * kTileEntries + threadIdx.x * 4;
+  int c = 0;
+  if (t0 < n_entries) {
+    unsigned char f[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const HashEntry e = load_entry(hash, t0 + k);
+      bool vis = false, vis_enl = false;
+      if (e.ptr >= 0)
+        check_block_vis<false>(vis, vis_enl, e.pos[0], e.pos[1], e.pos[2], p.M, p.fx, p.fy, p.cx, p.cy, p.voxel_size, p.W,
+                               p.H);
+      f[k] = vis ? 1 : 0;
+      c += f[k];
+    }
+    *reinterpret_cast<uchar4 *>(flags + t0) = make_uchar4(f[0], f[1], f[2], f[3]);
+  }
+  int tot;
+  block_excl_scan<4>(c, red, tot);
+  if (threadIdx.x == 0) tile_counts[blockIdx.x] = tot;
+}
+
+int launch_find_visible(dslam_engine *e, const dslam_scene *s, dslam_render_state *r, const float *M,
+                        const float *intr) {
+  const int N = s->n_entries;
+  DSLAM_REQUIRE(r->n_entries == N, "render state was created for a different scene size");
+  int rc = ensure_scratch(e, N, s->p.num_local_blocks);
+  if (rc) return rc;
+  FrustumParams fp;
+  memcpy(fp.M.m, M, 64);
+  fp.fx = intr[0]; fp.fy = intr[1]; fp.cx = intr[2]; fp.cy = intr[3]; fp.voxel_size = s->p.voxel_size;
+  fp.W = r->w; fp.H = r->h;
+  const int n_tiles = num_tiles(N);
+  unsigned char *flags = reinterpret_cast<unsigned char *>(e->list_c);  // byte flags, N <= sizeof(list_c)
+  hipLaunchKernelGGL(k_frustum_flags, dim3(n_tiles), dim3(256), 0, e->stream, s->hash, N, fp, flags, e->tile_counts);
+  hipLaunchKernelGGL(k_scan_count, dim3(1), dim3(1024), 0, e->stream, e->tile_counts, e->tile_offsets, n_tiles,
+                     &r->counters->no_visible, r->n_local);
+  hipLaunchKernelGGL(k_compact_apply, dim3(n_tiles), dim3(256), 0, e->stream, flags, N, e->tile_offsets,
+                     r->visible_ids, r->n_local);
+  DSLAM_HIP(hipGetLastError());
+  return DSLAM_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// CountVisibleBlocks
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_count_visible(const int *__restrict__ ids, RenderCounters *rc,
+                                                       const HashEntry *__restrict__ hash, int min_id, int max_id) {
+  const int n = rc->no_visible;
+  int c = 0;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const int ptr = hash[ids[i]].ptr;
+    c += (ptr >= min_id && ptr <= max_id);
+  }
+  for (int d = 32; d > 0; d >>= 1) c += __shfl_down(c, d, 64);
+  if ((threadIdx.x & 63) == 0 && c) atomicAdd(&rc->count_result, c);
+}
+
+int launch_count_visible(dslam_engine *e, const dslam_scene *s, const dslam_render_state *r, int min_id, int max_id,
+                         int *out) {
+  DSLAM_HIP(hipMemsetAsync(&r->counters->count_result, 0, sizeof(int), e->stream));
+  hipLaunchKernelGGL(k_count_visible, dim3(128), dim3(256), 0, e->stream, r->visible_ids, r->counters, s->hash, min_id,
+                     max_id);
+  int *host = reinterpret_cast<int *>(e->pinned);
+  DSLAM_HIP(hipMemcpyAsync(host, &r->counters->count_result, sizeof(int), hipMemcpyDeviceToHost, e->stream));
+  DSLAM_HIP(hipStreamSynchronize(e->stream));
+  *out = *host;
+  return DSLAM_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// CreateExpectedDepths
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_init_range(float2 *range, int n, RenderCounters *rc) {
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
+    range[i] = make_float2(kFarAway, kVeryClose);
+  if (blockIdx.x == 0 && threadIdx.x == 0) rc->render_tiles = 0;
+}
+
+struct ProjParams {
+  Mat4 M;
+  float fx, fy, cx, cy, voxel_size;
+  int W, H;
+};
+
+// ProjectSingleBlock for every visible block; records bbox / z-range / required render tiles
+__global__ __launch_bounds__(256) void k_project_blocks(const int *__restrict__ ids, RenderCounters *rc,
+                                                        const HashEntry *__restrict__ hash, ProjParams p,
+                                                        int4 *__restrict__ boxes, float2 *__restrict__ zr_out,
+                                                        int *__restrict__ req_out) {
+  const int n = rc->no_visible;
+  int local_tiles = 0;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const HashEntry e = load_entry(hash, ids[i]);
+    int req = 0;
+    if (e.ptr >= 0) {
+      int ulx = p.W / 8, uly = p.H / 8, lrx = -1, lry = -1;
+      float zmin = kFarAway, zmax = kVeryClose;
+#pragma unroll
+      for (int corner = 0; corner < 8; corner++) {
+        short tx = e.pos[0], ty = e.pos[1], tz = e.pos[2];
+        tx += (corner & 1) ? 1 : 0; ty += (corner & 2) ? 1 : 0; tz += (corner & 4) ? 1 : 0;
+        Vec4 q;
+        q.x = (float)tx * (float)kBlock * p.voxel_size;
+        q.y = (float)ty * (float)kBlock * p.voxel_size;
+        q.z = (float)tz * (float)kBlock * p.voxel_size;
+        q.w = 1.0f;
+        q = mul(p.M, q);
+        if (q.z < 1e-6f) continue;
+        const float px = (p.fx * q.x / q.z + p.cx) / 8.0f;
+        const float py = (p.fy * q.y / q.z + p.cy) / 8.0f;
+        if ((float)ulx > floorf(px)) ulx = (int)floorf(px);
+        if ((float)lrx < ceilf(px)) lrx = (int)ceilf(px);
+        if ((float)uly > floorf(py)) uly = (int)floorf(py);
+        if ((float)lry < ceilf(py)) lry = (int)ceilf(py);
+        if (zmin > q.z) zmin = q.z;
+        if (zmax < q.z) zmax = q.z;
+      }
+      if (ulx < 0) ulx = 0;
+      if (uly < 0) uly = 0;
+      if (lrx >= p.W) lrx = p.W - 1;
+      if (lry >= p.H) lry = p.H - 1;
+      bool valid = !(ulx > lrx) && !(uly > lry);
+      if (zmin < kVeryClose) zmin = kVeryClose;
+      if (zmax < kVeryClose) valid = false;
+      if (valid) {
+        const int rx = (int)ceilf((float)(lrx - ulx + 1) / 16.0f), ry = (int)ceilf((float)(lry - uly + 1) / 16.0f);
+        req = rx * ry;
+        boxes[i] = make_int4(ulx, uly, lrx, lry);
+        zr_out[i] = make_float2(zmin, zmax);
+      }
+    }
+    req_out[i] = req;
+    local_tiles += req;
+  }
+  for (int d = 32; d > 0; d >>= 1) local_tiles += __shfl_down(local_tiles, d, 64);
+  if ((threadIdx.x & 63) == 0 && local_tiles) atomicAdd(&rc->render_tiles, local_tiles);
+}
+
+// The render-tile budget (MAX_RENDERING_BLOCKS) is applied in visible-list order; only when the total exceeds
+// it does the order matter, and then one lane replays the sequential rule (rare: > 262144 tiles).
+__global__ void k_cap_render_tiles(RenderCounters *rc, int *req) {
+  if (rc->render_tiles < kMaxRenderingBlocks) return;
+  if (threadIdx.x != 0) return;
+  const int n = rc->no_visible;
+  int num = 0;
+  for (int i = 0; i < n; i++) {
+    const int r = req[i];
+    if (r == 0) continue;
+    if (num + r >= kMaxRenderingBlocks) req[i] = 0;
+    else num += r;
+  }
+}
+
+// fill the range image: the render tiles of a block partition its bbox, so min/max over the bbox is identical.
+// Values are positive floats, so integer atomics on the bit patterns order correctly.
+__global__ __launch_bounds__(256) void k_fill_range(const RenderCounters *rc, const int4 *__restrict__ boxes,
+                                                    const float2 *__restrict__ zr, const int *__restrict__ req,
+                                                    float2 *range, int W) {
+  const int n = rc->no_visible;
+  // 16 lanes cooperate on one block: bbox cells are dealt round-robin
+  const int sub = threadIdx.x & 15;
+  const int group = (blockIdx.x * blockDim.x + threadIdx.x) >> 4;
+  const int n_groups = (gridDim.x * blockDim.x) >> 4;
+  for (int i = group; i < n; i += n_groups) {
+    if (req[i] == 0) continue;
+    const int4 b = boxes[i];
+    const float2 z = zr[i];
+    const int bw = b.z - b.x + 1, cells = bw * (b.w - b.y + 1);
+    const int zmin_i = __float_as_int(z.x), zmax_i = __float_as_int(z.y);
+    for (int c = sub; c < cells; c += 16) {
+      const int y = b.y + c / bw, x = b.x + c % bw;
+      int *px = reinterpret_cast<int *>(&range[x + (size_t)y * W]);
+      if (px[0] > zmin_i) atomicMin(&px[0], zmin_i);
+      if (px[1] < zmax_i) atomicMax(&px[1], zmax_i);
+    }
+  }
+}
+
+int launch_expected_depths(dslam_engine *e, const dslam_scene *s, dslam_render_state *r, const float *M,
+                           const float *intr) {
+  ProjParams pp;
+  memcpy(pp.M.m, M, 64);
+  pp.fx = intr[0]; pp.fy = intr[1]; pp.cx = intr[2]; pp.cy = intr[3]; pp.voxel_size = s->p.voxel_size;
+  pp.W = r->w; pp.H = r->h;
+  const int npix = r->w * r->h;
+  hipLaunchKernelGGL(k_init_range, dim3((npix + 255) / 256), dim3(256), 0, e->stream, r->range, npix, r->counters);
+  hipLaunchKernelGGL(k_project_blocks, dim3(512), dim3(256), 0, e->stream, r->visible_ids, r->counters, s->hash, pp,
+                     r->proj_boxes, r->proj_z, r->proj_req);
+  hipLaunchKernelGGL(k_cap_render_tiles, dim3(1), dim3(64), 0, e->stream, r->counters, r->proj_req);
+  hipLaunchKernelGGL(k_fill_range, dim3(1024), dim3(256), 0, e->stream, r->counters, r->proj_boxes, r->proj_z,
+                     r->proj_req, r->range, r->w);
+  DSLAM_HIP(hipGetLastError());
+  return DSLAM_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// voxel access
+// ---------------------------------------------------------------------------------------------------------
+struct VolumeRef {
+  const HashEntry *hash;
+  const uint2 *voxels;
+  unsigned mask;
+  int num_buckets;
+};
+
+struct IndexCache {
+  int bx, by, bz, block_ptr;
+};
+
+__device__ __forceinline__ uint2 read_voxel(const VolumeRef &vol, int px, int py, int pz, bool &found, IndexCache &c) {
+  const int bx = ((px < 0) ? px - kBlock + 1 : px) / kBlock;
+  const int by = ((py < 0) ? py - kBlock + 1 : py) / kBlock;
+  const int bz = ((pz < 0) ? pz - kBlock + 1 : pz) / kBlock;
+  const int lin = (px - bx * kBlock) + (py - by * kBlock) * kBlock + (pz - bz * kBlock) * kBlock * kBlock;
+  if (bx == c.bx && by == c.by && bz == c.bz) {
+    found = true;
+    return vol.voxels[(size_t)c.block_ptr + lin];
+  }
+  int h = hash_index(bx, by, bz, vol.mask);
+  while (true) {
+    const HashEntry e = load_entry(vol.hash, h);
+    if (e.pos[0] == bx && e.pos[1] == by && e.pos[2] == bz && e.ptr >= 0) {
+      found = true;
+      c.bx = bx; c.by = by; c.bz = bz;
+      c.block_ptr = e.ptr * kBlock3;
+      return vol.voxels[(size_t)c.block_ptr + lin];
+    }
+    if (e.offset < 1) break;
+    h = vol.num_buckets + e.offset - 1;
+  }
+  found = false;
+  return make_uint2(kEmptyVoxelLo, kEmptyVoxelHi);
+}
+
+__device__ __forceinline__ float rd_sdf(const VolumeRef &vol, int x, int y, int z, bool &found, IndexCache &c) {
+  return (float)(short)(read_voxel(vol, x, y, z, found, c).x & 0xffffu);
+}
+
+__device__ __forceinline__ int iround(float x) { return (int)((x < 0) ? (x - 0.5f) : (x + 0.5f)); }
+
+__device__ __forceinline__ float read_sdf_uninterp(const VolumeRef &vol, const Vec3 &pt, bool &found, IndexCache &c) {
+  return rd_sdf(vol, iround(pt.x), iround(pt.y), iround(pt.z), found, c) / 32767.0f;
+}
+
+__device__ __forceinline__ float read_sdf_interp(const VolumeRef &vol, const Vec3 &pt, bool &found, IndexCache &c) {
+  float res1, res2, v1, v2;
+  const float fx = floorf(pt.x), fy = floorf(pt.y), fz = floorf(pt.z);
+  const int x = (int)fx, y = (int)fy, z = (int)fz;
+  const float cx = pt.x - fx, cy = pt.y - fy, cz = pt.z - fz;
+  v1 = rd_sdf(vol, x, y, z, found, c); v2 = rd_sdf(vol, x + 1, y, z, found, c);
+  res1 = (1.0f - cx) * v1 + cx * v2;
+  v1 = rd_sdf(vol, x, y + 1, z, found, c); v2 = rd_sdf(vol, x + 1, y + 1, z, found, c);
+  res1 = (1.0f - cy) * res1 + cy * ((1.0f - cx) * v1 + cx * v2);
+  v1 = rd_sdf(vol, x, y, z + 1, found, c); v2 = rd_sdf(vol, x + 1, y, z + 1, found, c);
+  res2 = (1.0f - cx) * v1 + cx * v2;
+  v1 = rd_sdf(vol, x, y + 1, z + 1, found, c); v2 = rd_sdf(vol, x + 1, y + 1, z + 1, found, c);
+  res2 = (1.0f - cy) * res2 + cy * ((1.0f - cx) * v1 + cx * v2);
+  found = true;
+  return ((1.0f - cz) * res1 + cz * res2) / 32767.0f;
+}
+
+__device__ __forceinline__ Vec4 read_colour_interp(const VolumeRef &vol, const Vec3 &pt, IndexCache &c) {
+  const float fx = floorf(pt.x), fy = floorf(pt.y), fz = floorf(pt.z);
+  const int x = (int)fx, y = (int)fy, z = (int)fz;
+  const float cx = pt.x - fx, cy = pt.y - fy, cz = pt.z - fz;
+  float rx = 0.0f, ry = 0.0f, rz = 0.0f;
+  bool found;
+#pragma unroll
+  for (int k = 0; k < 8; k++) {
+    const int ox = k & 1, oy = (k >> 1) & 1, oz = (k >> 2) & 1;
+    const uint2 v = read_voxel(vol, x + ox, y + oy, z + oz, found, c);
+    const float wx = ox ? cx : (1.0f - cx), wy = oy ? cy : (1.0f - cy), wz = oz ? cz : (1.0f - cz);
+    const float w = wx * wy * wz;
+    rx += w * (float)(v.x >> 24);
+    ry += w * (float)(v.y & 0xffu);
+    rz += w * (float)((v.y >> 8) & 0xffu);
+  }
+  Vec4 r = {rx / 255.0f, ry / 255.0f, rz / 255.0f, 255.0f / 255.0f};
+  return r;
+}
+
+// computeSingleNormalFromSDF (un-normalised gradient)
+__device__ __forceinline__ Vec3 normal_from_sdf(const VolumeRef &vol, const Vec3 &pt, IndexCache &c) {
+  bool f;
+  Vec3 ret;
+  const float flx = floorf(pt.x), fly = floorf(pt.y), flz = floorf(pt.z);
+  const int x = (int)flx, y = (int)fly, z = (int)flz;
+  const float cx = pt.x - flx, cy = pt.y - fly, cz = pt.z - flz;
+  const float nx = 1.0f - cx, ny = 1.0f - cy, nz = 1.0f - cz;
+  Vec4 front, back, tmp;
+  front.x = rd_sdf(vol, x, y, z, f, c); front.y = rd_sdf(vol, x + 1, y, z, f, c);
+  front.z = rd_sdf(vol, x, y + 1, z, f, c); front.w = rd_sdf(vol, x + 1, y + 1, z, f, c);
+  back.x = rd_sdf(vol, x, y, z + 1, f, c); back.y = rd_sdf(vol, x + 1, y, z + 1, f, c);
+  back.z = rd_sdf(vol, x, y + 1, z + 1, f, c); back.w = rd_sdf(vol, x + 1, y + 1, z + 1, f, c);
+  float p1, p2, v1;
+  // gradient x
+  p1 = front.x * ny * nz + front.z * cy * nz + back.x * ny * cz + back.z * cy * cz;
+  tmp.x = rd_sdf(vol, x - 1, y, z, f, c); tmp.y = rd_sdf(vol, x - 1, y + 1, z, f, c);
+  tmp.z = rd_sdf(vol, x - 1, y, z + 1, f, c); tmp.w = rd_sdf(vol, x - 1, y + 1, z + 1, f, c);
+  p2 = tmp.x * ny * nz + tmp.y * cy * nz + tmp.z * ny * cz + tmp.w * cy * cz;
+  v1 = p1 * cx + p2 * nx;
+  p1 = front.y * ny * nz + front.w * cy * nz + back.y * ny * cz + back.w * cy * cz;
+  tmp.x = rd_sdf(vol, x + 2, y, z, f, c); tmp.y = rd_sdf(vol, x + 2, y + 1, z, f, c);
+  tmp.z = rd_sdf(vol, x + 2, y, z + 1, f, c); tmp.w = rd_sdf(vol, x + 2, y + 1, z + 1, f, c);
+  p2 = tmp.x * ny * nz + tmp.y * cy * nz + tmp.z * ny * cz + tmp.w * cy * cz;
+  ret.x = (p1 * nx + p2 * cx - v1) / 32767.0f;
+  // gradient y
+  p1 = front.x * nx * nz + front.y * cx * nz + back.x * nx * cz + back.y * cx * cz;
+  tmp.x = rd_sdf(vol, x, y - 1, z, f, c); tmp.y = rd_sdf(vol, x + 1, y - 1, z, f, c);
+  tmp.z = rd_sdf(vol, x, y - 1, z + 1, f, c); tmp.w = rd_sdf(vol, x + 1, y - 1, z + 1, f, c);
+  p2 = tmp.x * nx * nz + tmp.y * cx * nz + tmp.z * nx * cz + tmp.w * cx * cz;
+  v1 = p1 * cy + p2 * ny;
+  p1 = front.z * nx * nz + front.w * cx * nz + back.z * nx * cz + back.w * cx * cz;
+  tmp.x = rd_sdf(vol, x, y + 2, z, f, c); tmp.y = rd_sdf(vol, x + 1, y + 2, z, f, c);
+  tmp.z = rd_sdf(vol, x, y + 2, z + 1, f, c); tmp.w = rd_sdf(vol, x + 1, y + 2, z + 1, f, c);
+  p2 = tmp.x * nx * nz + tmp.y * cx * nz + tmp.z * nx * cz + tmp.w * cx * cz;
+  ret.y = (p1 * ny + p2 * cy - v1) / 32767.0f;
+  // gradient z
+  p1 = front.x * nx * ny + front.y * cx * ny + front.z * nx * cy + front.w * cx * cy;
+  tmp.x = rd_sdf(vol, x, y, z - 1, f, c); tmp.y = rd_sdf(vol, x + 1, y, z - 1, f, c);
+  tmp.z = rd_sdf(vol, x, y + 1, z - 1, f, c); tmp.w = rd_sdf(vol, x + 1, y + 1, z - 1, f, c);
+  p2 = tmp.x * nx * ny + tmp.y * cx * ny + tmp.z * nx * cy + tmp.w * cx * cy;
+  v1 = p1 * cz + p2 * nz;
+  p1 = back.x * nx * ny + back.y * cx * ny + back.z * nx * cy + back.w * cx * cy;
+  tmp.x = rd_sdf(vol, x, y, z + 2, f, c); tmp.y = rd_sdf(vol, x + 1, y, z + 2, f, c);
+  tmp.z = rd_sdf(vol, x, y + 1, z + 2, f, c); tmp.w = rd_sdf(vol, x + 1, y + 1, z + 2, f, c);
+  p2 = tmp.x * nx * ny + tmp.y * cx * ny + tmp.z * nx * cy + tmp.w * cx * cy;
+  ret.z = (p1 * nz + p2 * cz - v1) / 32767.0f;
+  return ret;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// castRay + shading, one kernel
+// ---------------------------------------------------------------------------------------------------------
+struct RenderParams {
+  VolumeRef vol;
+  Mat4 M, invM;
+  float inv_fx, inv_fy, cx, cy;
+  float one_over_vs, voxel_size, mu;
+  int W, H;
+  const float2 *range;
+  float4 *raycast;
+  uchar4 *out_rgba;
+  float *out_float;
+  int type;  // dslam_image_type, or -1: raycast only
+};
+
+__device__ __forceinline__ bool cast_ray(Vec4 &out, int x, int y, const RenderParams &p, const float2 minmax) {
+  Vec4 pc;
+  Vec3 ps, pe, dir, res;
+  bool hash_found;
+  float sdf = 1.0f;
+  float total, step, total_max;
+  const float step_scale = p.mu * p.one_over_vs;
+
+  pc.z = minmax.x;
+  pc.x = pc.z * (((float)x - p.cx) * p.inv_fx);
+  pc.y = pc.z * (((float)y - p.cy) * p.inv_fy);
+  pc.w = 1.0f;
+  total = sqrtf(pc.x * pc.x + pc.y * pc.y + pc.z * pc.z) * p.one_over_vs;
+  Vec4 q = mul(p.invM, pc);
+  ps.x = q.x * p.one_over_vs; ps.y = q.y * p.one_over_vs; ps.z = q.z * p.one_over_vs;
+
+  pc.z = minmax.y;
+  pc.x = pc.z * (((float)x - p.cx) * p.inv_fx);
+  pc.y = pc.z * (((float)y - p.cy) * p.inv_fy);
+  pc.w = 1.0f;
+  total_max = sqrtf(pc.x * pc.x + pc.y * pc.y + pc.z * pc.z) * p.one_over_vs;
+  q = mul(p.invM, pc);
+  pe.x = q.x * p.one_over_vs; pe.y = q.y * p.one_over_vs; pe.z = q.z * p.one_over_vs;
+
+  dir.x = pe.x - ps.x; dir.y = pe.y - ps.y; dir.z = pe.z - ps.z;
+  const float dn = 1.0f / sqrtf(dir.x * dir.x + dir.y * dir.y + dir.z * dir.z);
+  dir.x *= dn; dir.y *= dn; dir.z *= dn;
+  res = ps;
+  IndexCache cache = {0x7fffffff, 0x7fffffff, 0x7fffffff, -1};
+  while (total < total_max) {
+    sdf = read_sdf_uninterp(p.vol, res, hash_found, cache);
+    if (!hash_found) {
+      step = (float)kBlock;
+    } else {
+      if ((sdf <= 0.1f) && (sdf >= -0.5f)) sdf = read_sdf_interp(p.vol, res, hash_found, cache);
+      if (sdf <= 0.0f) break;
+      step = fmaxf(sdf * step_scale, 1.0f);
+    }
+    res.x += step * dir.x; res.y += step * dir.y; res.z += step * dir.z;
+    total += step;
+  }
+  bool pt_found;
+  if (sdf <= 0.0f) {
+    step = sdf * step_scale;
+    res.x += step * dir.x; res.y += step * dir.y; res.z += step * dir.z;
+    sdf = read_sdf_interp(p.vol, res, hash_found, cache);
+    step = sdf * step_scale;
+    res.x += step * dir.x; res.y += step * dir.y; res.z += step * dir.z;
+    pt_found = true;
+  } else {
+    pt_found = false;
+  }
+  out.x = res.x; out.y = res.y; out.z = res.z; out.w = pt_found ? 1.0f : 0.0f;
+  return pt_found;
+}
+
+__global__ __launch_bounds__(256) void k_render(RenderParams p) {
+  // 16x16 pixel tile per workgroup, 8x8 per wavefront
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int x = blockIdx.x * 16 + (wave & 1) * 8 + (lane & 7);
+  const int y = blockIdx.y * 16 + (wave >> 1) * 8 + (lane >> 3);
+  if (x >= p.W || y >= p.H) return;
+  const int loc = x + y * p.W;
+  const int loc2 = (int)floorf((float)x / 8.0f) + (int)floorf((float)y / 8.0f) * p.W;
+  Vec4 pr;
+  cast_ray(pr, x, y, p, p.range[loc2]);
+  p.raycast[loc] = make_float4(pr.x, pr.y, pr.z, pr.w);
+  if (p.type < 0) return;
+
+  const Vec3 pt = {pr.x, pr.y, pr.z};
+  bool found = pr.w > 0;
+  if (p.type == DSLAM_IMAGE_DEPTH) {
+    float d = 0.0f;
+    if (found) {
+      Vec4 pw = {pt.x * p.voxel_size, pt.y * p.voxel_size, pt.z * p.voxel_size, 1.0f};
+      d = mul(p.M, pw).z;
+    }
+    p.out_float[loc] = d;
+    return;
+  }
+  IndexCache c = {0x7fffffff, 0x7fffffff, 0x7fffffff, -1};
+  Vec3 n = {0, 0, 0};
+  float angle = 0.0f;
+  if (found) {
+    const Vec3 light = {-p.invM.m[8], -p.invM.m[9], -p.invM.m[10]};
+    n = normal_from_sdf(p.vol, pt, c);
+    const float ns = 1.0f / sqrtf(n.x * n.x + n.y * n.y + n.z * n.z);
+    n.x *= ns; n.y *= ns; n.z *= ns;
+    angle = n.x * light.x + n.y * light.y + n.z * light.z;
+    if (!(angle > 0.0f)) found = false;
+  }
+  uchar4 o = make_uchar4(0, 0, 0, 0);
+  if (found) {
+    if (p.type == DSLAM_IMAGE_COLOUR_FROM_VOLUME) {
+      const Vec4 clr = read_colour_interp(p.vol, pt, c);
+      o = make_uchar4((unsigned char)(clr.x * 255.0f), (unsigned char)(clr.y * 255.0f), (unsigned char)(clr.z * 255.0f),
+                      255);
+    } else if (p.type == DSLAM_IMAGE_COLOUR_FROM_NORMAL) {
+      o = make_uchar4((unsigned char)((0.3f + (-n.x + 1.0f) * 0.35f) * 255.0f),
+                      (unsigned char)((0.3f + (-n.y + 1.0f) * 0.35f) * 255.0f),
+                      (unsigned char)((0.3f + (-n.z + 1.0f) * 0.35f) * 255.0f), 255);
+    } else {
+      const unsigned char g = (unsigned char)((0.8f * angle + 0.2f) * 255.0f);
+      o = make_uchar4(g, g, g, g);
+    }
+  }
+  p.out_rgba[loc] = o;
+}
+
+static int fill_render_params(RenderParams &rp, const dslam_scene *s, dslam_render_state *r, const float *M,
+                              const float *intr, int type) {
+  rp.vol.hash = s->hash; rp.vol.voxels = s->voxels; rp.vol.mask = (unsigned)(s->p.num_buckets - 1);
+  rp.vol.num_buckets = s->p.num_buckets;
+  memcpy(rp.M.m, M, 64);
+  if (!invert_matrix(M, rp.invM.m)) { set_last_error("pose matrix is singular"); return DSLAM_ERR_INVALID; }
+  rp.inv_fx = 1.0f / intr[0]; rp.inv_fy = 1.0f / intr[1]; rp.cx = intr[2]; rp.cy = intr[3];
+  rp.voxel_size = s->p.voxel_size; rp.one_over_vs = 1.0f / s->p.voxel_size; rp.mu = s->p.mu;
+  rp.W = r->w; rp.H = r->h;
+  rp.range = r->range; rp.raycast = r->raycast; rp.out_rgba = r->image_rgba; rp.out_float = r->image_float;
+  rp.type = type;
+  return DSLAM_OK;
+}
+
+int launch_render(dslam_engine *e, const dslam_scene *s, dslam_render_state *r, const float *M, const float *intr,
+                  int type) {
+  RenderParams rp;
+  int rc = fill_render_params(rp, s, r, M, intr, type);
+  if (rc) return rc;
+  hipLaunchKernelGGL(k_render, dim3((r->w + 15) / 16, (r->h + 15) / 16), dim3(256), 0, e->stream, rp);
+  DSLAM_HIP(hipGetLastError());
+  return DSLAM_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// CreateICPMaps: processPixelICP<useSmoothing = true, flipNormals = false>
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_icp_maps(const float4 *__restrict__ pr, int W, int H, float vs, float lx,
+                                                  float ly, float lz, float4 *points, float4 *normals) {
+  const int x = blockIdx.x * 16 + (threadIdx.x & 15), y = blockIdx.y * 16 + (threadIdx.x >> 4);
+  if (x >= W || y >= H) return;
+  const int loc = x + y * W;
+  const float4 point = pr[loc];
+  bool found = point.w > 0.0f;
+  float nx = 0, ny = 0, nz = 0;
+  if (found && (y <= 2 || y >= H - 3 || x <= 2 || x >= W - 3)) found = false;
+  if (found) {
+    float4 xp = pr[(x + 2) + y * W], yp = pr[x + (y + 2) * W], xm = pr[(x - 2) + y * W], ym = pr[x + (y - 2) * W];
+    float4 dx = make_float4(0, 0, 0, 0), dy = make_float4(0, 0, 0, 0);
+    bool plus1 = false;
+    if (xp.w <= 0 || yp.w <= 0 || xm.w <= 0 || ym.w <= 0) plus1 = true;
+    if (!plus1) {
+      dx = make_float4(xp.x - xm.x, xp.y - xm.y, xp.z - xm.z, xp.w - xm.w);
+      dy = make_float4(yp.x - ym.x, yp.y - ym.y, yp.z - ym.z, yp.w - ym.w);
+      const float ld = fmaxf(dx.x * dx.x + dx.y * dx.y + dx.z * dx.z, dy.x * dy.x + dy.y * dy.y + dy.z * dy.z);
+      if (ld * vs * vs > (0.15f * 0.15f)) plus1 = true;
+    }
+    if (plus1) {
+      xp = pr[(x + 1) + y * W]; yp = pr[x + (y + 1) * W]; xm = pr[(x - 1) + y * W]; ym = pr[x + (y - 1) * W];
+      dx = make_float4(xp.x - xm.x, xp.y - xm.y, xp.z - xm.z, xp.w - xm.w);
+      dy = make_float4(yp.x - ym.x, yp.y - ym.y, yp.z - ym.z, yp.w - ym.w);
+      if (xp.w <= 0 || yp.w <= 0 || xm.w <= 0 || ym.w <= 0) found = false;
+    }
+    if (found) {
+      nx = -(dx.y * dy.z - dx.z * dy.y);
+      ny = -(dx.z * dy.x - dx.x * dy.z);
+      nz = -(dx.x * dy.y - dx.y * dy.x);
+      const float ns = 1.0f / sqrtf(nx * nx + ny * ny + nz * nz);
+      nx *= ns; ny *= ns; nz *= ns;
+      const float angle = nx * lx + ny * ly + nz * lz;
+      if (!(angle > 0.0f)) found = false;
+    }
+  }
+  if (found) {
+    points[loc] = make_float4(point.x * vs, point.y * vs, point.z * vs, 1.0f);
+    normals[loc] = make_float4(nx, ny, nz, 0.0f);
+  } else {
+    points[loc] = make_float4(0.0f, 0.0f, 0.0f, -1.0f);
+    normals[loc] = make_float4(0.0f, 0.0f, 0.0f, -1.0f);
+  }
+}
+
+int launch_icp_maps(dslam_engine *e, const dslam_scene *s, dslam_render_state *r, const float *M, const float *intr) {
+  if (!r->icp_points) {
+    DSLAM_HIP(hipMalloc(&r->icp_points, (size_t)r->w * r->h * sizeof(float4)));
+    DSLAM_HIP(hipMalloc(&r->icp_normals, (size_t)r->w * r->h * sizeof(float4)));
+  }
+  RenderParams rp;
+  int rc = fill_render_params(rp, s, r, M, intr, -1);
+  if (rc) return rc;
+  const dim3 grid((r->w + 15) / 16, (r->h + 15) / 16);
+  hipLaunchKernelGGL(k_render, grid, dim3(256), 0, e->stream, rp);
+  hipLaunchKernelGGL(k_icp_maps, grid, dim3(256), 0, e->stream, r->raycast, r->w, r->h, s->p.voxel_size, -rp.invM.m[8],
+                     -rp.invM.m[9], -rp.invM.m[10], r->icp_points, r->icp_normals);
+  DSLAM_HIP(hipGetLastError());
+  return DSLAM_OK;
+}
+
+}  // namespace dslam

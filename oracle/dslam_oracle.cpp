@@ -1151,6 +1151,14 @@ extern "C" int oracle_count_visible_blocks(oracle_engine *, const oracle_scene *
 namespace {
 static const float FAR_AWAY = 999999.9f, VERY_CLOSE = 0.05f;
 
+// float -> int with saturation (the GPU's v_cvt_i32_f32 saturates; x86 cvttss2si does not): only matters for
+// block corners a few micrometres in front of the camera plane, whose projection overflows int
+static inline int f2i_sat(float x) {
+  if (x >= 2147483648.0f) return INT_MAX;
+  if (x < -2147483648.0f) return INT_MIN;
+  return (int)x;
+}
+
 static bool project_single_block(const int16_t *bp, const float *M, const float *intr, int W, int H, float vs,
                                  V2i &ul, V2i &lr, V2f &zr) {
   ul.x = W / 8; ul.y = H / 8;
@@ -1165,10 +1173,10 @@ static bool project_single_block(const int16_t *bp, const float *M, const float 
     if (p.z < 1e-6f) continue;
     float px = (intr[0] * p.x / p.z + intr[2]) / 8.0f;
     float py = (intr[1] * p.y / p.z + intr[3]) / 8.0f;
-    if ((float)ul.x > floorf(px)) ul.x = (int)floorf(px);
-    if ((float)lr.x < ceilf(px)) lr.x = (int)ceilf(px);
-    if ((float)ul.y > floorf(py)) ul.y = (int)floorf(py);
-    if ((float)lr.y < ceilf(py)) lr.y = (int)ceilf(py);
+    if ((float)ul.x > floorf(px)) ul.x = f2i_sat(floorf(px));
+    if ((float)lr.x < ceilf(px)) lr.x = f2i_sat(ceilf(px));
+    if ((float)ul.y > floorf(py)) ul.y = f2i_sat(floorf(py));
+    if ((float)lr.y < ceilf(py)) lr.y = f2i_sat(ceilf(py));
     if (zr.x > p.z) zr.x = p.z;
     if (zr.y < p.z) zr.y = p.z;
   }
