@@ -397,6 +397,9 @@ int launch_allocate(dslam_engine *e, dslam_scene *s, const dslam_view *v, dslam_
   mp.mu = s->p.mu; mp.frustum_min = s->p.frustum_min; mp.frustum_max = s->p.frustum_max;
   mp.one_over_block = 1.0f / (s->p.voxel_size * kBlock);
   mp.hash = s->hash; mp.mask = (unsigned)(s->p.num_buckets - 1); mp.num_buckets = s->p.num_buckets;
+  // order keys (4 B/entry) and allocType (1 B/entry) are carved from one scratch block for THIS scene's entry
+  // count, so the single memset below clears exactly both
+  e->alloc_type = reinterpret_cast<unsigned char *>(e->order_keys) + (size_t)N * 4;
   mp.keys = e->order_keys; mp.alloc_type = e->alloc_type; mp.coords = e->block_coords; mp.vis_type = r->visible_type;
   mp.cnt = s->counters;
   // steps along the +-mu segment: ceil(2 * |segment| in blocks) = ceil(mu / (2 * voxel_size)) for a rigid pose
@@ -408,7 +411,6 @@ int launch_allocate(dslam_engine *e, dslam_scene *s, const dslam_view *v, dslam_
   }
 
   const int n_tiles = num_tiles(N);
-  // order keys + allocType are one contiguous scratch block: one memset clears both
   DSLAM_HIP(hipMemsetAsync(e->order_keys, 0, (size_t)N * 5, e->stream));
   hipLaunchKernelGGL(k_set_type3, dim3(256), dim3(256), 0, e->stream, r->visible_ids, r->counters, r->visible_type);
   const int pix_blocks = (W * H + 255) / 256;
