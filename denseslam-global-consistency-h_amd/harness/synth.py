@@ -18,12 +18,16 @@ class Box:
         self.lo, self.hi, self.inside = np.asarray(lo, np.float64), np.asarray(hi, np.float64), inside
 
     def hit(self, o, d, inv_d):
-        # o is the (single) camera centre, so (lo - o) is a 3-vector broadcast over all rays
+        # slab test per axis on 2-D arrays; o is the (single) camera centre so (lo - o) is a scalar per axis.
+        # fmin/fmax ignore the NaNs of 0 * inf (ray parallel to a slab it starts on).
+        tmin = tmax = None
         with np.errstate(invalid="ignore"):
-            t1 = (self.lo - o) * inv_d
-            t2 = (self.hi - o) * inv_d
-        tmin = np.nanmax(np.minimum(t1, t2), axis=-1)
-        tmax = np.nanmin(np.maximum(t1, t2), axis=-1)
+            for a in range(3):
+                t1 = (self.lo[a] - o[a]) * inv_d[a]
+                t2 = (self.hi[a] - o[a]) * inv_d[a]
+                lo_t, hi_t = np.fmin(t1, t2), np.fmax(t1, t2)
+                tmin = lo_t if tmin is None else np.fmax(tmin, lo_t)
+                tmax = hi_t if tmax is None else np.fmin(tmax, hi_t)
         if self.inside:  # camera inside the room: the far intersection is the wall
             t = np.where((tmax > 0) & (tmin <= tmax), tmax, np.inf)
         else:
@@ -56,7 +60,7 @@ def render(prims, intr, W, H, T_wc, colour_k=(3.1, 4.7, 2.3)):
     d = dc @ R.T
     o = np.asarray(t, np.float64)
     with np.errstate(divide="ignore"):
-        inv_d = 1.0 / d
+        inv_d = [1.0 / d[..., a] for a in range(3)]
     z = np.full((H, W), np.inf)
     for p in prims:
         z = np.minimum(z, p.hit(o, d, inv_d))
@@ -179,8 +183,8 @@ def s_street(W=640, H=480, n_cars=20, loop_at=None):
     for side in (-1.0, 1.0):
         x0 = 8.0 * side
         prims.append(Box((min(x0, x0 + 2 * side), -12.0, -50.0), (max(x0, x0 + 2 * side), 1.65, L)))
-        for k in range(0, 1400):  # relief boxes, 3 m period
-            z0 = k * 3.0
+        for k in range(0, 700):  # relief boxes, 6 m period
+            z0 = k * 6.0
             xa, xb = x0 - 0.6 * side, x0
             prims.append(Box((min(xa, xb), -6.0 + (k % 3), z0), (max(xa, xb), 1.65, z0 + 1.5)))
     rng = np.random.RandomState(7)
@@ -197,7 +201,7 @@ def s_street(W=640, H=480, n_cars=20, loop_at=None):
 
     return Workload("S-street", W, H, intr, prims, traj,
                     dict(voxel_size=0.05, mu=0.2, max_w=100, frustum_min=0.5, frustum_max=40.0), kitti_depth=True,
-                    max_depth=40.0, cull_z=(5.0, 60.0))
+                    max_depth=40.0, cull_z=(5.0, 48.0))
 
 
 def s_tiny(W=64, H=48):

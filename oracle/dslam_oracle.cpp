@@ -464,7 +464,7 @@ extern "C" int oracle_engine_set_threads(oracle_engine *e, int n) {
 }
 extern "C" int oracle_max_threads(void) {
 #ifdef _OPENMP
-  return omp_get_max_threads();
+  return omp_get_num_procs();
 #else
   return 1;
 #endif
