@@ -1,0 +1,308 @@
+// ITMMainEngine.h -- the ITMLib engine classes InfiniTamDriver derives from and calls (reference include at
+// InfiniTamDriver.h:11), implemented as thin host wrappers over the C ABI of libdslam_fusion.so.
+//
+//   ITMMainEngine(settings, calib, imgSize_rgb, imgSize_d)            InfiniTamDriver.h:102
+//   members view, settings, denseMapper, trackingController, viewBuilder, visualisationEngine, mapManager,
+//           mActiveDataManger                                         InfiniTamDriver.h:133-157,189-241,276-308,363
+//   GetPrimaryLocalMap(), GetImage(out, outFloat, type, pose, intrinsics, localMap), SaveCurrSceneToMesh
+//                                                                      InfiniTamDriver.h:146,169; InfiniTamDriver.cpp:242-275
+// Header-only; link with -ldslam_fusion.
+#pragma once
+#include <cstdio>
+#include <vector>
+
+#include "../Objects/ITMObjects.h"
+
+namespace ITMLib {
+namespace Engine {
+using namespace Objects;
+
+/// ITMLib::Engine::WeightParams (SystemEntry.cpp:183-187; InfiniTamDriver.h:101,391)
+struct WeightParams {
+  bool depthWeighting;
+  int maxNewW;
+  float maxDistance;
+  WeightParams() : depthWeighting(false), maxNewW(1), maxDistance(1.0f) {}
+};
+
+/// ITMSwappingEngine<TVoxel,TIndex>: SaveToGlobalMemory(scene) is Hansry's one-argument form (DenseSlam.h:250)
+template <class TVoxel, class TIndex> class ITMSwappingEngine {
+  dslam_engine *eng_;
+ public:
+  explicit ITMSwappingEngine(dslam_engine *e) : eng_(e) {}
+  void IntegrateGlobalIntoLocal(ITMScene<TVoxel, TIndex> *scene, ITMRenderState *rs) {
+    dslam_check(dslam_swap_in(eng_, scene->handle, rs ? rs->handle : nullptr), "dslam_swap_in");
+  }
+  void SaveToGlobalMemory(ITMScene<TVoxel, TIndex> *scene, ITMRenderState *rs) {
+    dslam_check(dslam_swap_out(eng_, scene->handle, rs->handle), "dslam_swap_out");
+    scene->refreshCounters(eng_, rs);
+  }
+  void SaveToGlobalMemory(ITMScene<TVoxel, TIndex> *scene) {
+    dslam_check(dslam_save_to_global_memory(eng_, scene->handle), "dslam_save_to_global_memory");
+    scene->refreshCounters(eng_, nullptr);
+  }
+};
+
+/// ITMDenseMapper: the fusion entry points (InfiniTamDriver.h:187-199,241,274-310,354-370)
+class ITMDenseMapper {
+  dslam_engine *eng_;
+  const ITMRGBDCalib *calib_;
+  ITMSwappingEngine<ITMVoxel, ITMVoxelIndex> *swappingEngine_;
+  long long decayedBlocks_;
+
+  void poseArgs(const ITMView *view, const ITMTrackingState *ts, Matrix4f &M_d, Matrix4f &M_rgb, Vector4f &kd, Vector4f &kr) const {
+    M_d = ts->pose_d->GetM();
+    M_rgb = view->calib->trafo_rgb_to_depth.calib_inv * M_d;
+    kd = view->calib->intrinsics_d.projectionParamsSimple.all;
+    kr = view->calib->intrinsics_rgb.projectionParamsSimple.all;
+  }
+
+ public:
+  ITMDenseMapper(dslam_engine *e, const ITMRGBDCalib *calib)
+      : eng_(e), calib_(calib), swappingEngine_(new ITMSwappingEngine<ITMVoxel, ITMVoxelIndex>(e)), decayedBlocks_(0) {}
+  ~ITMDenseMapper() { delete swappingEngine_; }
+
+  void SetFusionWeightParams(const WeightParams &p) {
+    dslam_weight_params w = {p.depthWeighting ? 1 : 0, p.maxNewW, p.maxDistance};
+    dslam_check(dslam_set_fusion_weight_params(eng_, &w), "dslam_set_fusion_weight_params");
+  }
+  void ResetScene(ITMScene<ITMVoxel, ITMVoxelIndex> *scene) {
+    dslam_check(dslam_scene_reset(eng_, scene->handle), "dslam_scene_reset");
+    scene->refreshCounters(eng_, nullptr, &decayedBlocks_);
+  }
+  void ProcessFrame(const ITMView *view, const ITMTrackingState *ts, ITMScene<ITMVoxel, ITMVoxelIndex> *scene,
+                    ITMRenderState *rs, bool onlyUpdateVisibleList = false, bool isDefusion = false) {
+    Matrix4f M_d, M_rgb; Vector4f kd, kr;
+    poseArgs(view, ts, M_d, M_rgb, kd, kr);
+    dslam_check(dslam_process_frame(eng_, scene->handle, view->handle, rs->handle, M_d.m, kd.v, M_rgb.m, kr.v,
+                                    onlyUpdateVisibleList, isDefusion), "dslam_process_frame");
+    scene->refreshCounters(eng_, rs, &decayedBlocks_);
+  }
+  void DeProcessFrame(const ITMView *view, const ITMTrackingState *ts, ITMScene<ITMVoxel, ITMVoxelIndex> *scene,
+                      ITMRenderState *rs) {
+    Matrix4f M_d, M_rgb; Vector4f kd, kr;
+    poseArgs(view, ts, M_d, M_rgb, kd, kr);
+    dslam_check(dslam_deprocess_frame(eng_, scene->handle, view->handle, rs->handle, M_d.m, kd.v, M_rgb.m, kr.v),
+                "dslam_deprocess_frame");
+    scene->refreshCounters(eng_, rs, &decayedBlocks_);
+  }
+  void Decay(ITMScene<ITMVoxel, ITMVoxelIndex> *scene, ITMRenderState *rs, int maxWeight, int minAge, bool forceAllVoxels) {
+    dslam_check(dslam_decay(eng_, scene->handle, rs ? rs->handle : nullptr, maxWeight, minAge, forceAllVoxels), "dslam_decay");
+    scene->refreshCounters(eng_, rs, &decayedBlocks_);
+  }
+  void DecayDefusionPart(ITMScene<ITMVoxel, ITMVoxelIndex> *scene, ITMRenderState *rs, int maxWeight, int minAge, bool forceAllVoxels) {
+    dslam_check(dslam_decay_defusion_part(eng_, scene->handle, rs ? rs->handle : nullptr, maxWeight, minAge, forceAllVoxels),
+                "dslam_decay_defusion_part");
+    scene->refreshCounters(eng_, rs, &decayedBlocks_);
+  }
+  void SlideWindow(ITMScene<ITMVoxel, ITMVoxelIndex> *scene, ITMRenderState *rs, int maxAge) {
+    dslam_check(dslam_slide_window(eng_, scene->handle, rs ? rs->handle : nullptr, maxAge), "dslam_slide_window");
+    scene->refreshCounters(eng_, rs, &decayedBlocks_);
+  }
+  void SlideWindowDefusionPart(ITMScene<ITMVoxel, ITMVoxelIndex> *scene, ITMRenderState *rs, int maxAge, int maxSize) {
+    dslam_check(dslam_slide_window_defusion_part(eng_, scene->handle, rs ? rs->handle : nullptr, maxAge, maxSize),
+                "dslam_slide_window_defusion_part");
+    scene->refreshCounters(eng_, rs, &decayedBlocks_);
+  }
+  size_t GetDecayedBlockCount() const { return (size_t)decayedBlocks_; }
+  ITMSwappingEngine<ITMVoxel, ITMVoxelIndex> *GetSwappingEngine() { return swappingEngine_; }
+};
+
+/// ITMViewBuilder::UpdateView(&view, rgb, rawDepth, timestamp, useBilateralFilter) (InfiniTamDriver.cpp:286)
+class ITMViewBuilder {
+  dslam_engine *eng_;
+  const ITMRGBDCalib *calib_;
+ public:
+  ITMViewBuilder(dslam_engine *e, const ITMRGBDCalib *c) : eng_(e), calib_(c) {}
+  const ITMRGBDCalib *GetCalib() const { return calib_; }  ///< InfiniTamDriver.cpp:241
+  void UpdateView(ITMView **view, ITMUChar4Image *rgb, ITMShortImage *rawDepth, double timestamp, bool useBilateralFilter) {
+    if (*view == nullptr) *view = new ITMView(calib_, rgb->noDims, rawDepth->noDims, eng_);
+    ITMView *v = *view;
+    const Vector2f ab = calib_->disparityCalib.params;
+    dslam_check(dslam_view_update(eng_, v->handle, &rgb->GetData(MEMORYDEVICE_CPU)->x, rawDepth->GetData(MEMORYDEVICE_CPU),
+                                  ab.x, ab.y, timestamp, useBilateralFilter), "dslam_view_update");
+    v->timestamp = timestamp;
+    // host mirrors: view->rgb / view->depth are read back by the driver (InfiniTamDriver.h:217-218)
+    memcpy(v->rgb->GetData(MEMORYDEVICE_CPU), rgb->GetData(MEMORYDEVICE_CPU), (size_t)rgb->noDims.x * rgb->noDims.y * 4);
+    dslam_check(dslam_download_view_depth(eng_, v->handle, v->depth->GetData(MEMORYDEVICE_CPU)), "dslam_download_view_depth");
+  }
+};
+
+/// ITMTrackingController: Prepare = raycast into ICP maps (InfiniTamDriver.h:212-215); Track (ICP) is out of scope
+/// for this path -- the reference runs with ORB-SLAM2 poses (use_orbslam_vo, SystemEntry.cpp:189).
+class ITMTrackingController {
+  dslam_engine *eng_;
+ public:
+  explicit ITMTrackingController(dslam_engine *e) : eng_(e) {}
+  void Prepare(ITMTrackingState *ts, const ITMScene<ITMVoxel, ITMVoxelIndex> *scene, const ITMView *view, ITMRenderState *rs) {
+    const Matrix4f M = ts->pose_d->GetM();
+    const Vector4f k = view->calib->intrinsics_d.projectionParamsSimple.all;
+    dslam_check(dslam_create_icp_maps(eng_, scene->handle, rs->handle, M.m, k.v, &ts->pointsMap->GetData(MEMORYDEVICE_CPU)->x,
+                                      &ts->normalsMap->GetData(MEMORYDEVICE_CPU)->x), "dslam_create_icp_maps");
+    ts->age_pointCloud = 0;
+  }
+  void Track(ITMTrackingState *, const ITMView *) {
+    throw std::runtime_error("ITMTrackingController::Track (ICP) is outside the fusion/raycast path; run with orbslam_vo: 1");
+  }
+};
+
+/// ITMVisualisationEngine (InfiniTamDriver.h:362-364)
+template <class TVoxel, class TIndex> class ITMVisualisationEngine {
+  dslam_engine *eng_;
+ public:
+  explicit ITMVisualisationEngine(dslam_engine *e) : eng_(e) {}
+  ITMRenderState *CreateRenderState(const ITMScene<TVoxel, TIndex> *scene, Vector2i sz) const { return new ITMRenderState_VH(eng_, scene->handle, sz); }
+  void FindVisibleBlocks(const ITMScene<TVoxel, TIndex> *scene, const ITMPose *pose, const ITMIntrinsics *intr, ITMRenderState *rs) const {
+    dslam_check(dslam_find_visible_blocks(eng_, scene->handle, rs->handle, pose->GetM().m, intr->projectionParamsSimple.all.v), "dslam_find_visible_blocks");
+  }
+  int CountVisibleBlocks(const ITMScene<TVoxel, TIndex> *scene, const ITMRenderState *rs, int minBlockId, int maxBlockId) const {
+    int n = 0;
+    dslam_check(dslam_count_visible_blocks(eng_, scene->handle, rs->handle, minBlockId, maxBlockId, &n), "dslam_count_visible_blocks");
+    return n;
+  }
+  void CreateExpectedDepths(const ITMScene<TVoxel, TIndex> *scene, const ITMPose *pose, const ITMIntrinsics *intr, ITMRenderState *rs) const {
+    dslam_check(dslam_create_expected_depths(eng_, scene->handle, rs->handle, pose->GetM().m, intr->projectionParamsSimple.all.v), "dslam_create_expected_depths");
+  }
+};
+
+/// ITMVoxelMapGraphManager (DenseSlam.cpp:135-152,555-556; InfiniTamDriver.h:136,269): host container of local maps
+class ITMVoxelMapGraphManager {
+  const ITMLibSettings *settings_;
+  dslam_engine *eng_;
+  Vector2i trackedImageSize_;
+  const ITMVisualisationEngine<ITMVoxel, ITMVoxelIndex> *vis_;
+  std::vector<ITMLocalMap *> maps_;
+ public:
+  ITMVoxelMapGraphManager(const ITMLibSettings *s, dslam_engine *e, const ITMVisualisationEngine<ITMVoxel, ITMVoxelIndex> *vis, Vector2i sz)
+      : settings_(s), eng_(e), trackedImageSize_(sz), vis_(vis) {}
+  ~ITMVoxelMapGraphManager() { for (auto *m : maps_) delete m; }
+  int createNewLocalMap() { maps_.push_back(new ITMLocalMap(settings_, eng_, trackedImageSize_)); return (int)maps_.size() - 1; }
+  int numLocalMaps() const { return (int)maps_.size(); }
+  ITMLocalMap *getLocalMap(int i) const { return (i < 0 || i >= (int)maps_.size()) ? nullptr : maps_[i]; }
+  void setEstimatedGlobalPose(int i, const ITMPose &pose) { maps_[i]->estimatedGlobalPose = pose; }
+  int getLocalMapSize(int i) const {
+    dslam_stats st;
+    dslam_check(dslam_get_stats(eng_, maps_[i]->scene->handle, nullptr, &st), "dslam_get_stats");
+    return st.num_allocated_blocks - st.last_free_block_id - 1;
+  }
+  int countVisibleBlocks(int i, int minBlockId, int maxBlockId, bool /*invertIDs*/) const {
+    return vis_->CountVisibleBlocks(maps_[i]->scene, maps_[i]->renderState, minBlockId, maxBlockId);
+  }
+};
+
+/// ITMActiveMapManager: only numActiveLocalMaps() is reached (InfiniTamDriver.h:264)
+class ITMActiveMapManager {
+  ITMVoxelMapGraphManager *maps_;
+ public:
+  explicit ITMActiveMapManager(ITMVoxelMapGraphManager *m) : maps_(m) {}
+  int numActiveLocalMaps() const { return maps_->numLocalMaps() > 0 ? 1 : 0; }
+};
+
+class ITMMainEngine {
+ public:
+  enum GetImageType {
+    InfiniTAM_IMAGE_ORIGINAL_RGB,
+    InfiniTAM_IMAGE_ORIGINAL_DEPTH,
+    InfiniTAM_IMAGE_SCENERAYCAST,
+    InfiniTAM_IMAGE_FREECAMERA_SHADED,
+    InfiniTAM_IMAGE_FREECAMERA_COLOUR_FROM_VOLUME,
+    InfiniTAM_IMAGE_FREECAMERA_COLOUR_FROM_NORMAL,
+    InfiniTAM_IMAGE_FREECAMERA_DEPTH,
+    InfiniTAM_IMAGE_UNKNOWN
+  };
+
+  ITMMainEngine(const ITMLibSettings *settings_, const ITMRGBDCalib *calib, Vector2i imgSize_rgb, Vector2i imgSize_d = Vector2i(-1, -1))
+      : settings(settings_), view(nullptr), engine_(nullptr), freeviewScene_(nullptr), renderState_freeview_(nullptr) {
+    if (imgSize_d.x == -1 || imgSize_d.y == -1) imgSize_d = imgSize_rgb;
+    dslam_check(dslam_engine_create(settings->hipDeviceIndex, &engine_), "dslam_engine_create");
+    denseMapper = new ITMDenseMapper(engine_, calib);
+    viewBuilder = new ITMViewBuilder(engine_, calib);
+    trackingController = new ITMTrackingController(engine_);
+    visualisationEngine = new ITMVisualisationEngine<ITMVoxel, ITMVoxelIndex>(engine_);
+    mapManager = new ITMVoxelMapGraphManager(settings, engine_, visualisationEngine, imgSize_d);
+    mActiveDataManger = new ITMActiveMapManager(mapManager);
+  }
+  virtual ~ITMMainEngine() {
+    delete renderState_freeview_;
+    delete mActiveDataManger; delete mapManager; delete visualisationEngine; delete trackingController;
+    delete viewBuilder; delete denseMapper; delete view;
+    dslam_engine_destroy(engine_);
+  }
+
+  ITMLocalMap *GetPrimaryLocalMap() const { return mapManager->getLocalMap(0); }
+
+  /// FREECAMERA_* render the given local map (primary when null; nothing before the first keyframe, B.1);
+  /// SCENERAYCAST shows the tracking raycast, which only Prepare produces; ORIGINAL_* copy the view.
+  void GetImage(ITMUChar4Image *out, ITMFloatImage *outFloat, GetImageType type, ITMPose *pose = nullptr,
+                ITMIntrinsics *intrinsics = nullptr, const ITMLocalMap *localMap = nullptr) {
+    if (view == nullptr) return;
+    if (localMap == nullptr) localMap = GetPrimaryLocalMap();
+    switch (type) {
+      case InfiniTAM_IMAGE_ORIGINAL_RGB:
+        if (out) { out->ChangeDims(view->rgb->noDims); memcpy(out->GetData(MEMORYDEVICE_CPU), view->rgb->GetData(MEMORYDEVICE_CPU), out->dataSize * 4); }
+        return;
+      case InfiniTAM_IMAGE_ORIGINAL_DEPTH:
+        if (outFloat) { outFloat->ChangeDims(view->depth->noDims); memcpy(outFloat->GetData(MEMORYDEVICE_CPU), view->depth->GetData(MEMORYDEVICE_CPU), outFloat->dataSize * 4); }
+        return;
+      case InfiniTAM_IMAGE_SCENERAYCAST:
+        if (out && localMap && localMap->renderState->raycastImage) {
+          out->ChangeDims(localMap->renderState->raycastImage->noDims);
+          memcpy(out->GetData(MEMORYDEVICE_CPU), localMap->renderState->raycastImage->GetData(MEMORYDEVICE_CPU), out->dataSize * 4);
+        }
+        return;
+      default: break;
+    }
+    if (localMap == nullptr || pose == nullptr || intrinsics == nullptr) return;
+    int t;
+    switch (type) {
+      case InfiniTAM_IMAGE_FREECAMERA_SHADED: t = DSLAM_IMAGE_SHADED; break;
+      case InfiniTAM_IMAGE_FREECAMERA_COLOUR_FROM_VOLUME: t = DSLAM_IMAGE_COLOUR_FROM_VOLUME; break;
+      case InfiniTAM_IMAGE_FREECAMERA_COLOUR_FROM_NORMAL: t = DSLAM_IMAGE_COLOUR_FROM_NORMAL; break;
+      case InfiniTAM_IMAGE_FREECAMERA_DEPTH: t = DSLAM_IMAGE_DEPTH; break;
+      default: return;
+    }
+    const Vector2i sz = (t == DSLAM_IMAGE_DEPTH) ? (outFloat ? outFloat->noDims : Vector2i(0, 0)) : (out ? out->noDims : Vector2i(0, 0));
+    if (sz.x <= 0) return;
+    if (renderState_freeview_ == nullptr || freeviewScene_ != localMap->scene || freeviewSize_.x != sz.x || freeviewSize_.y != sz.y) {
+      delete renderState_freeview_;
+      renderState_freeview_ = visualisationEngine->CreateRenderState(localMap->scene, sz);
+      freeviewScene_ = localMap->scene; freeviewSize_ = sz;
+    }
+    dslam_check(dslam_get_image(engine_, localMap->scene->handle, renderState_freeview_->handle, pose->GetM().m,
+                                intrinsics->projectionParamsSimple.all.v, t,
+                                t == DSLAM_IMAGE_DEPTH ? nullptr : &out->GetData(MEMORYDEVICE_CPU)->x,
+                                t == DSLAM_IMAGE_DEPTH ? outFloat->GetData(MEMORYDEVICE_CPU) : nullptr), "dslam_get_image");
+  }
+
+  void SaveCurrSceneToMesh(const char *objFileName, const ITMScene<ITMVoxel, ITMVoxelIndex> *) {
+    fprintf(stderr, "SaveCurrSceneToMesh(%s): meshing is an offline export outside the fusion/raycast path (SURVEY 2.1)\n", objFileName);
+  }
+
+  dslam_engine *GetDslamEngine() const { return engine_; }
+
+ protected:
+  const ITMLibSettings *settings;
+  ITMView *view;
+  ITMDenseMapper *denseMapper;
+  ITMViewBuilder *viewBuilder;
+  ITMTrackingController *trackingController;
+  ITMVisualisationEngine<ITMVoxel, ITMVoxelIndex> *visualisationEngine;
+  ITMVoxelMapGraphManager *mapManager;
+  ITMActiveMapManager *mActiveDataManger;
+
+ private:
+  dslam_engine *engine_;
+  const ITMScene<ITMVoxel, ITMVoxelIndex> *freeviewScene_;
+  ITMRenderState *renderState_freeview_;
+  Vector2i freeviewSize_;
+};
+
+}  // namespace Engine
+}  // namespace ITMLib
+
+// global names the reference uses unqualified (InfiniTamDriver.h:132-137,362; DenseSlam.h:511)
+using ITMLib::Engine::ITMActiveMapManager;
+using ITMLib::Engine::ITMLocalMap;
+using ITMLib::Engine::ITMVisualisationEngine;
+using ITMLib::Engine::ITMVoxelMapGraphManager;
+using ITMLib::Objects::ITMRenderState_VH;

@@ -1,0 +1,201 @@
+// ITMObjects.h -- ITMPose, ITMLibSettings, ITMSceneParams, ITMView, ITMTrackingState, ITMRenderState(_VH), ITMScene,
+// ITMLocalMap: the object surface InfiniTamDriver / DenseSlam touch, each holding the C-ABI
+// handle of its device-side counterpart.
+#pragma once
+#include <memory>
+#include <vector>
+
+#include "ITMRGBDCalib.h"
+
+namespace ITMLib {
+namespace Objects {
+
+/// ITMPose: M = world -> camera.  SetM/SetInvM/GetM/GetInvM/GetParams/Coerce
+/// (InfiniTamDriver.h:153,159,174-177; InfiniTamDriver.cpp:47-49; DenseSlam.cpp:139,330-337).
+class ITMPose {
+  Matrix4f M;
+  float params_[6];  // tx, ty, tz, rx, ry, rz (se3 log, DenseSlam.cpp:332-336)
+
+  void paramsFromM() {
+    const float R[3][3] = {{M.at(0, 0), M.at(1, 0), M.at(2, 0)}, {M.at(0, 1), M.at(1, 1), M.at(2, 1)}, {M.at(0, 2), M.at(1, 2), M.at(2, 2)}};
+    const float t[3] = {M.at(3, 0), M.at(3, 1), M.at(3, 2)};
+    float c = (R[0][0] + R[1][1] + R[2][2] - 1.0f) * 0.5f;
+    c = c > 1.0f ? 1.0f : (c < -1.0f ? -1.0f : c);
+    const float angle = acosf(c);
+    float w[3] = {(R[2][1] - R[1][2]) * 0.5f, (R[0][2] - R[2][0]) * 0.5f, (R[1][0] - R[0][1]) * 0.5f};
+    const float s = sqrtf(w[0] * w[0] + w[1] * w[1] + w[2] * w[2]);
+    if (s > 1e-8f) { const float k = angle / s; w[0] *= k; w[1] *= k; w[2] *= k; }
+    // t = V u  ->  u = V^-1 t with V = I + B [w]x + C [w]x^2
+    float u[3] = {t[0], t[1], t[2]};
+    if (angle > 1e-6f) {
+      const float a2 = angle * angle;
+      const float halfcot = 0.5f * angle * (sinf(angle) / (1.0f - cosf(angle)));
+      const float D = (1.0f - halfcot) / a2;
+      const float wxt[3] = {w[1] * t[2] - w[2] * t[1], w[2] * t[0] - w[0] * t[2], w[0] * t[1] - w[1] * t[0]};
+      const float wxwxt[3] = {w[1] * wxt[2] - w[2] * wxt[1], w[2] * wxt[0] - w[0] * wxt[2], w[0] * wxt[1] - w[1] * wxt[0]};
+      for (int i = 0; i < 3; i++) u[i] = t[i] - 0.5f * wxt[i] + D * wxwxt[i];
+    }
+    for (int i = 0; i < 3; i++) { params_[i] = u[i]; params_[3 + i] = w[i]; }
+  }
+
+ public:
+  ITMPose() { M.setIdentity(); for (float &p : params_) p = 0; }
+  void SetM(const Matrix4f &m) { M = m; paramsFromM(); }
+  void SetInvM(const Matrix4f &invM) { Matrix4f m; invM.inv(m); SetM(m); }
+  const Matrix4f &GetM() const { return M; }
+  Matrix4f GetInvM() const { Matrix4f r; M.inv(r); return r; }
+  const float *GetParams() const { return params_; }
+  /// re-orthonormalise the rotation part (Gram-Schmidt) and force the bottom row to (0,0,0,1)
+  void Coerce() {
+    float c0[3] = {M.m[0], M.m[1], M.m[2]}, c1[3] = {M.m[4], M.m[5], M.m[6]}, c2[3];
+    float n = sqrtf(c0[0] * c0[0] + c0[1] * c0[1] + c0[2] * c0[2]);
+    if (n > 0) for (float &v : c0) v /= n;
+    const float d = c0[0] * c1[0] + c0[1] * c1[1] + c0[2] * c1[2];
+    for (int i = 0; i < 3; i++) c1[i] -= d * c0[i];
+    n = sqrtf(c1[0] * c1[0] + c1[1] * c1[1] + c1[2] * c1[2]);
+    if (n > 0) for (float &v : c1) v /= n;
+    c2[0] = c0[1] * c1[2] - c0[2] * c1[1]; c2[1] = c0[2] * c1[0] - c0[0] * c1[2]; c2[2] = c0[0] * c1[1] - c0[1] * c1[0];
+    for (int i = 0; i < 3; i++) { M.m[i] = c0[i]; M.m[4 + i] = c1[i]; M.m[8 + i] = c2[i]; }
+    M.m[3] = M.m[7] = M.m[11] = 0.0f; M.m[15] = 1.0f;
+    paramsFromM();
+  }
+};
+
+class ITMSceneParams {
+ public:
+  float voxelSize, viewFrustum_min, viewFrustum_max, mu;
+  int maxW;
+  bool stopIntegratingAtMaxW;
+  ITMSceneParams(float mu_, int maxW_, float voxelSize_, float vfMin, float vfMax, bool stopAtMax)
+      : voxelSize(voxelSize_), viewFrustum_min(vfMin), viewFrustum_max(vfMax), mu(mu_), maxW(maxW_),
+        stopIntegratingAtMaxW(stopAtMax) {}
+};
+
+/// ITMLibSettings is default-constructed by the reference and never edited (SystemEntry.cpp:238-243).  The fork's
+/// defaults are not knowable; these are the upstream InfiniTAM v2 defaults, with the device fixed to HIP.
+class ITMLibSettings {
+ public:
+  typedef enum { DEVICE_CPU, DEVICE_CUDA, DEVICE_HIP } DeviceType;
+  DeviceType deviceType;
+  bool useSwapping, useApproximateRaycast, useBilateralFilter, modelSensorNoise, skipPoints;
+  ITMSceneParams sceneParams;
+  int hipDeviceIndex;
+  // pool sizes (ITMLibDefines.h constants upstream; runtime here)
+  int numLocalBlocks, numBuckets, numExcess;
+  ITMLibSettings()
+      : deviceType(DEVICE_HIP), useSwapping(false), useApproximateRaycast(false), useBilateralFilter(false),
+        modelSensorNoise(false), skipPoints(true), sceneParams(0.02f, 100, 0.005f, 0.2f, 3.0f, false), hipDeviceIndex(0),
+        numLocalBlocks(SDF_LOCAL_BLOCK_NUM), numBuckets(SDF_BUCKET_NUM), numExcess(SDF_EXCESS_LIST_SIZE) {}
+};
+
+class ITMView {
+ public:
+  const ITMRGBDCalib *calib;
+  ITMUChar4Image *rgb;   ///< host mirror of the colour image (InfiniTamDriver.h:217)
+  ITMFloatImage *depth;  ///< host mirror of the metric depth (InfiniTamDriver.h:218)
+  dslam_view *handle;
+  double timestamp;
+  ITMView(const ITMRGBDCalib *c, Vector2i sz_rgb, Vector2i sz_d, dslam_engine *eng) : calib(c), handle(nullptr), timestamp(0) {
+    rgb = new ITMUChar4Image(sz_rgb, true, false);
+    depth = new ITMFloatImage(sz_d, true, false);
+    dslam_check(dslam_view_create(eng, sz_rgb.x, sz_rgb.y, sz_d.x, sz_d.y, &handle), "dslam_view_create");
+  }
+  ~ITMView() { dslam_view_destroy(handle); delete rgb; delete depth; }
+};
+
+class ITMTrackingState {
+ public:
+  ITMPose *pose_d;
+  ITMFloat4Image *pointsMap, *normalsMap;  ///< ICP maps filled by trackingController->Prepare
+  int age_pointCloud;
+  explicit ITMTrackingState(Vector2i sz) : age_pointCloud(-1) {
+    pose_d = new ITMPose();
+    pointsMap = new ITMFloat4Image(sz, true, false);
+    normalsMap = new ITMFloat4Image(sz, true, false);
+  }
+  ~ITMTrackingState() { delete pose_d; delete pointsMap; delete normalsMap; }
+};
+
+class ITMRenderState {
+ public:
+  dslam_render_state *handle;
+  ITMUChar4Image *raycastImage;
+  virtual ~ITMRenderState() { dslam_render_state_destroy(handle); delete raycastImage; }
+ protected:
+  ITMRenderState() : handle(nullptr), raycastImage(nullptr) {}
+};
+
+class ITMRenderState_VH : public ITMRenderState {
+ public:
+  int noVisibleEntries;  ///< InfiniTamDriver.h:209-210
+  ITMRenderState_VH(dslam_engine *eng, const dslam_scene *scene, Vector2i sz) : noVisibleEntries(0) {
+    dslam_check(dslam_render_state_create(eng, scene, sz.x, sz.y, &handle), "dslam_render_state_create");
+    raycastImage = new ITMUChar4Image(sz, true, false);
+  }
+};
+
+class ITMLocalVBA {
+ public:
+  int lastFreeBlockId;  ///< InfiniTamDriver.h:345
+  int allocatedSize;
+};
+
+class ITMVoxelBlockHash {
+  int numBlocks_;
+ public:
+  int lastFreeExcessListId;
+  explicit ITMVoxelBlockHash(int n) : numBlocks_(n), lastFreeExcessListId(0) {}
+  int getNumAllocatedVoxelBlocks() const { return numBlocks_; }  ///< InfiniTamDriver.h:345,350
+};
+
+template <class TVoxel, class TIndex> class ITMScene {
+ public:
+  const ITMSceneParams *sceneParams;
+  TIndex index;
+  ITMLocalVBA localVBA;
+  dslam_scene *handle;
+  ITMScene(const ITMLibSettings *settings, dslam_engine *eng) : sceneParams(&settings->sceneParams), index(settings->numLocalBlocks), handle(nullptr) {
+    dslam_scene_params p;
+    memset(&p, 0, sizeof(p));
+    p.voxel_size = sceneParams->voxelSize; p.mu = sceneParams->mu; p.max_w = sceneParams->maxW;
+    p.frustum_min = sceneParams->viewFrustum_min; p.frustum_max = sceneParams->viewFrustum_max;
+    p.stop_integrating_at_max_w = sceneParams->stopIntegratingAtMaxW;
+    p.num_local_blocks = settings->numLocalBlocks; p.num_buckets = settings->numBuckets; p.num_excess = settings->numExcess;
+    p.use_swapping = settings->useSwapping;
+    dslam_check(dslam_scene_create(eng, &p, nullptr, &handle), "dslam_scene_create");
+    localVBA.allocatedSize = settings->numLocalBlocks;
+    localVBA.lastFreeBlockId = settings->numLocalBlocks - 1;
+    index.lastFreeExcessListId = settings->numExcess - 1;
+  }
+  ~ITMScene() { dslam_scene_destroy(handle); }
+  /// pull the pool counters the driver reads after every call (InfiniTamDriver.h:344-351)
+  void refreshCounters(dslam_engine *eng, ITMRenderState *rs, long long *decayed = nullptr) {
+    dslam_stats st;
+    dslam_check(dslam_get_stats(eng, handle, rs ? rs->handle : nullptr, &st), "dslam_get_stats");
+    localVBA.lastFreeBlockId = st.last_free_block_id;
+    index.lastFreeExcessListId = st.last_free_excess_id;
+    if (rs) static_cast<ITMRenderState_VH *>(rs)->noVisibleEntries = st.no_visible_entries;
+    if (decayed) *decayed = st.decayed_block_count;
+  }
+};
+
+}  // namespace Objects
+
+namespace Engine {
+using namespace Objects;
+/// ITMLocalMap {scene, renderState, trackingState, estimatedGlobalPose} (InfiniTamDriver.h:153,174,191,198,209,252-254)
+class ITMLocalMap {
+ public:
+  ITMScene<ITMVoxel, ITMVoxelIndex> *scene;
+  ITMRenderState *renderState;
+  ITMTrackingState *trackingState;
+  ITMPose estimatedGlobalPose;
+  ITMLocalMap(const ITMLibSettings *settings, dslam_engine *eng, Vector2i trackedImageSize) {
+    scene = new ITMScene<ITMVoxel, ITMVoxelIndex>(settings, eng);
+    renderState = new ITMRenderState_VH(eng, scene->handle, trackedImageSize);
+    trackingState = new ITMTrackingState(trackedImageSize);
+  }
+  ~ITMLocalMap() { delete renderState; delete trackingState; delete scene; }
+};
+}  // namespace Engine
+}  // namespace ITMLib

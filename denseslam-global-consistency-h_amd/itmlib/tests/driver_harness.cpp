@@ -1,0 +1,185 @@
+// driver_harness.cpp -- stands in for the reference's InfiniTamDriver / DenseSlam host code to prove the ITMLib shim is
+// a working drop-in: it derives from ITMLib::Engine::ITMMainEngine exactly like InfiniTamDriver
+// (InfiniTamDriver.h:90-116) and issues the same member calls with the same expressions (cited per method), minus
+// OpenCV / Eigen / Pangolin, which are not in this image.
+//
+//   driver_harness <frames.bin> <out.bin> <decay:0|1> <slide_max_age|-1>
+// frames.bin: int32 W, H, N, then per frame: uint8 rgba[W*H*4], int16 depth_mm[W*H], float M_d[16] (column-major),
+//             then float intr[4], then scene params: float voxel, mu, fmin, fmax, int32 maxW, nLocal, nBuckets, nExcess
+// out.bin:    int32 lastFreeBlockId, noVisibleEntries, usedBytesLo, decayedBlocks; uint64 fnv(hash table), fnv(voxels);
+//             float depth[W*H]; uint8 colour[W*H*4]
+#include <cstdint>
+#include <cstdio>
+#include <vector>
+
+#include "ITMLib/Engine/ITMMainEngine.h"
+
+using namespace ITMLib::Engine;
+using namespace ITMLib::Objects;
+
+struct VoxelDecayParams { bool enabled; int min_decay_age, max_decay_weight; };
+struct SlideWindowParams { bool enabled; int max_age; };
+
+class DriverHarness : public ITMMainEngine {
+ public:
+  DriverHarness(const ITMLibSettings *settings, const ITMRGBDCalib *calib, const Vector2i &sz, VoxelDecayParams d, SlideWindowParams s)
+      : ITMMainEngine(settings, calib, sz, sz), rgb_itm_(new ITMUChar4Image(sz, true, true)),
+        raw_depth_itm_(new ITMShortImage(sz, true, true)), voxel_decay_params_(d), slide_window_params_(s) {}
+  ~DriverHarness() { delete rgb_itm_; delete raw_depth_itm_; }
+
+  // InfiniTamDriver::UpdateView (InfiniTamDriver.cpp:280-288)
+  void UpdateView(const uint8_t *rgba, const int16_t *depth, double timestamp) {
+    memcpy(rgb_itm_->GetData(MEMORYDEVICE_CPU), rgba, rgb_itm_->dataSize * 4);
+    memcpy(raw_depth_itm_->GetData(MEMORYDEVICE_CPU), depth, raw_depth_itm_->dataSize * 2);
+    this->viewBuilder->UpdateView(&view, rgb_itm_, raw_depth_itm_, timestamp, settings->useBilateralFilter);
+  }
+  ITMVoxelMapGraphManager *GetMapManager() const { return this->mapManager; }  // InfiniTamDriver.h:136
+  // InfiniTamDriver::IntegrateLocalMap (InfiniTamDriver.h:187-192)
+  void IntegrateLocalMap(const ITMLocalMap *m, bool onlyUpdateVisibleList = false, bool isDefusion = false) const {
+    this->denseMapper->SetFusionWeightParams(fusion_weight_params_);
+    this->denseMapper->ProcessFrame(this->view, m->trackingState, m->scene, m->renderState, onlyUpdateVisibleList, isDefusion);
+  }
+  // InfiniTamDriver::DeIntegrateLocalMap (InfiniTamDriver.h:194-199)
+  void DeIntegrateLocalMap(const ITMLocalMap *m) const {
+    this->denseMapper->SetFusionWeightParams(fusion_weight_params_);
+    this->denseMapper->DeProcessFrame(this->view, m->trackingState, m->scene, m->renderState);
+  }
+  // InfiniTamDriver::Decay (InfiniTamDriver.h:274-282)
+  void Decay(const ITMLocalMap *m) {
+    if (voxel_decay_params_.enabled)
+      denseMapper->Decay(m->scene, m->renderState, voxel_decay_params_.max_decay_weight, voxel_decay_params_.min_decay_age, true);
+  }
+  // InfiniTamDriver::SlideWindow (InfiniTamDriver.h:294-300)
+  void SlideWindow(const ITMLocalMap *m) {
+    if (slide_window_params_.enabled) denseMapper->SlideWindow(m->scene, m->renderState, slide_window_params_.max_age);
+  }
+  // InfiniTamDriver::PrepareNextStepLocalMap (InfiniTamDriver.h:208-220)
+  void PrepareNextStepLocalMap(const ITMLocalMap *m) {
+    const ITMRenderState_VH *rs = (ITMRenderState_VH *)(m->renderState);
+    if (rs->noVisibleEntries > 0) this->trackingController->Prepare(m->trackingState, m->scene, this->view, m->renderState);
+  }
+  // InfiniTamDriver::GetLocalMapUsedMemoryBytes (InfiniTamDriver.h:344-347)
+  size_t GetLocalMapUsedMemoryBytes(ITMLocalMap *m) {
+    int num_used_blocks = m->scene->index.getNumAllocatedVoxelBlocks() - m->scene->localVBA.lastFreeBlockId;
+    return sizeof(ITMVoxel) * SDF_BLOCK_SIZE3 * num_used_blocks;
+  }
+  size_t GetSavedDecayMemoryBytes() const { return denseMapper->GetDecayedBlockCount() * sizeof(ITMVoxel) * SDF_BLOCK_SIZE3; }
+  // InfiniTamDriver::GetImage / GetFloatImage (InfiniTamDriver.cpp:229-277) with the pose given directly
+  void GetImage(ITMUChar4Image *out, ITMMainEngine::GetImageType t, ITMPose &pose, const ITMLocalMap *m) {
+    if (nullptr != this->view) {
+      ITMIntrinsics intrinsics = this->viewBuilder->GetCalib()->intrinsics_d;
+      ITMMainEngine::GetImage(out, nullptr, t, &pose, &intrinsics, m);
+    }
+  }
+  void GetFloatImage(ITMFloatImage *out, ITMPose &pose, const ITMLocalMap *m) {
+    if (nullptr != this->view) {
+      ITMIntrinsics intrinsics = this->viewBuilder->GetCalib()->intrinsics_d;
+      ITMMainEngine::GetImage(nullptr, out, ITMMainEngine::InfiniTAM_IMAGE_FREECAMERA_DEPTH, &pose, &intrinsics, m);
+    }
+  }
+  const ITMView *GetView() const { return view; }
+
+ private:
+  ITMUChar4Image *rgb_itm_;
+  ITMShortImage *raw_depth_itm_;
+  WeightParams fusion_weight_params_;
+  VoxelDecayParams voxel_decay_params_;
+  SlideWindowParams slide_window_params_;
+};
+
+static uint64_t fnv1a(const void *p, size_t n, uint64_t h = 1469598103934665603ull) {
+  const uint8_t *b = (const uint8_t *)p;
+  for (size_t i = 0; i < n; i++) { h ^= b[i]; h *= 1099511628211ull; }
+  return h;
+}
+
+int main(int argc, char **argv) {
+  if (argc < 5) { fprintf(stderr, "usage: %s frames.bin out.bin decay slide_max_age\n", argv[0]); return 2; }
+  FILE *f = fopen(argv[1], "rb");
+  if (!f) { perror("frames"); return 2; }
+  int32_t hdr[3];
+  if (fread(hdr, 4, 3, f) != 3) return 2;
+  const int W = hdr[0], H = hdr[1], N = hdr[2];
+  std::vector<std::vector<uint8_t>> rgba(N, std::vector<uint8_t>((size_t)W * H * 4));
+  std::vector<std::vector<int16_t>> depth(N, std::vector<int16_t>((size_t)W * H));
+  std::vector<Matrix4f> poses(N);
+  for (int i = 0; i < N; i++) {
+    if (fread(rgba[i].data(), 1, rgba[i].size(), f) != rgba[i].size()) return 2;
+    if (fread(depth[i].data(), 2, depth[i].size(), f) != depth[i].size()) return 2;
+    if (fread(poses[i].m, 4, 16, f) != 16) return 2;
+  }
+  float intr[4], sp[4];
+  int32_t ip[4];
+  if (fread(intr, 4, 4, f) != 4 || fread(sp, 4, 4, f) != 4 || fread(ip, 4, 4, f) != 4) return 2;
+  fclose(f);
+
+  try {
+    ITMLibSettings *settings = new ITMLibSettings();  // SystemEntry.cpp:238
+    settings->sceneParams = ITMSceneParams(sp[1], ip[0], sp[0], sp[2], sp[3], false);
+    settings->numLocalBlocks = ip[1]; settings->numBuckets = ip[2]; settings->numExcess = ip[3];
+    // CreateItmCalib (InfiniTamDriver.cpp:55-81)
+    ITMRGBDCalib *calib = new ITMRGBDCalib;
+    ITMIntrinsics intrinsics;
+    intrinsics.SetFrom(intr[0], intr[1], intr[2], intr[3], (float)W, (float)H);
+    calib->intrinsics_rgb = intrinsics; calib->intrinsics_d = intrinsics;
+    Matrix4f identity; identity.setIdentity();
+    calib->trafo_rgb_to_depth.SetFrom(identity);
+    calib->disparityCalib.SetFrom(1.0f / 1000.0f, 0.0f, ITMDisparityCalib::TRAFO_AFFINE);
+
+    VoxelDecayParams dp = {atoi(argv[3]) != 0, 2, 1};
+    SlideWindowParams sw = {atoi(argv[4]) >= 0, atoi(argv[4])};
+    DriverHarness drv(settings, calib, Vector2i(W, H), dp, sw);
+
+    // before the first keyframe: GetImage must be a no-op, not a crash
+    ITMFloatImage out_float(Vector2i(W, H), true, true);
+    ITMUChar4Image out_rgba(Vector2i(W, H), true, true);
+    ITMPose free_pose;
+    drv.GetFloatImage(&out_float, free_pose, nullptr);
+
+    // DenseSlam::ProcessFrame, first keyframe (DenseSlam.cpp:133-152)
+    int idx = drv.GetMapManager()->createNewLocalMap();
+    ITMPose tempPose;
+    drv.GetMapManager()->setEstimatedGlobalPose(idx, tempPose);
+    ITMLocalMap *currentLocalMap = drv.GetMapManager()->getLocalMap(idx);
+
+    int fused = 0;
+    for (int i = 0; i < N; i++) {
+      currentLocalMap->trackingState->pose_d->SetM(poses[i]);                 // SetPoseLocalMap (InfiniTamDriver.h:173-178)
+      drv.UpdateView(rgba[i].data(), depth[i].data(), (double)i);             // DenseSlam.cpp:212
+      drv.IntegrateLocalMap(currentLocalMap);                                 // DenseSlam.cpp:213
+      fused++;
+      if (sw.enabled && fused > sw.max_age) drv.SlideWindow(currentLocalMap);  // DenseSlam.cpp:215-225
+      drv.Decay(currentLocalMap);                                             // DenseSlam.cpp:227-232
+    }
+    free_pose.SetM(poses[N - 1]);
+    drv.GetFloatImage(&out_float, free_pose, currentLocalMap);                // DenseSlam.h:146-153
+    drv.GetImage(&out_rgba, ITMMainEngine::InfiniTAM_IMAGE_FREECAMERA_COLOUR_FROM_VOLUME, free_pose, currentLocalMap);
+    drv.PrepareNextStepLocalMap(currentLocalMap);
+
+    dslam_engine *e = drv.GetDslamEngine();
+    std::vector<dslam_hash_entry> hash((size_t)ip[2] + ip[3]);
+    std::vector<dslam_voxel> vox((size_t)ip[1] * 512);
+    ITMLib::dslam_check(dslam_download_hash_table(e, currentLocalMap->scene->handle, hash.data()), "download hash");
+    ITMLib::dslam_check(dslam_download_voxel_blocks(e, currentLocalMap->scene->handle, 0, ip[1], vox.data()), "download voxels");
+
+    FILE *o = fopen(argv[2], "wb");
+    if (!o) { perror("out"); return 2; }
+    const ITMRenderState_VH *rs = (const ITMRenderState_VH *)currentLocalMap->renderState;
+    int32_t st[4] = {currentLocalMap->scene->localVBA.lastFreeBlockId, rs->noVisibleEntries,
+                     (int32_t)(drv.GetLocalMapUsedMemoryBytes(currentLocalMap) & 0x7fffffff),
+                     (int32_t)(drv.GetSavedDecayMemoryBytes() / (sizeof(ITMVoxel) * SDF_BLOCK_SIZE3))};
+    uint64_t sums[2] = {fnv1a(hash.data(), hash.size() * sizeof(dslam_hash_entry)), fnv1a(vox.data(), vox.size() * sizeof(dslam_voxel))};
+    fwrite(st, 4, 4, o);
+    fwrite(sums, 8, 2, o);
+    fwrite(out_float.GetData(MEMORYDEVICE_CPU), 4, (size_t)W * H, o);
+    fwrite(out_rgba.GetData(MEMORYDEVICE_CPU), 4, (size_t)W * H, o);
+    fclose(o);
+    printf("driver_harness ok: %d frames, lastFreeBlockId %d, visible %d, decayed %d\n", N, st[0], st[1], st[3]);
+    delete calib;
+    delete settings;
+  } catch (const std::exception &ex) {
+    fprintf(stderr, "driver_harness failed: %s\n", ex.what());
+    return 1;
+  }
+  return 0;
+}

@@ -1219,6 +1219,9 @@ extern "C" int oracle_create_expected_depths(oracle_engine *, const oracle_scene
 }
 
 namespace {
+// debug counters (oracle_raycast_stats): ray-march steps, interpolated reads, rays
+static long long g_dbg_steps = 0, g_dbg_interp = 0, g_dbg_rays = 0, g_dbg_maxsteps = 0;
+
 // castRay
 static inline bool cast_ray(const oracle_scene *s, V4f &out, int x, int y, const float *invM, const float *intr,
                             float one_over_vs, float mu, const V2f &minmax) {
@@ -1250,12 +1253,14 @@ static inline bool cast_ray(const oracle_scene *s, V4f &out, int x, int y, const
   dir.x *= dn; dir.y *= dn; dir.z *= dn;
   res = ps;
   IndexCache cache;
+  long long nsteps = 0, ninterp = 0;
   while (total < total_max) {
+    nsteps++;
     sdf = read_sdf_uninterp(s, res, hash_found, cache);
     if (!hash_found) {
       step = (float)DSLAM_BLOCK_SIZE;
     } else {
-      if ((sdf <= 0.1f) && (sdf >= -0.5f)) sdf = read_sdf_interp(s, res, hash_found, cache);
+      if ((sdf <= 0.1f) && (sdf >= -0.5f)) { sdf = read_sdf_interp(s, res, hash_found, cache); ninterp++; }
       if (sdf <= 0.0f) break;
       step = std::max(sdf * step_scale, 1.0f);
     }
@@ -1263,6 +1268,13 @@ static inline bool cast_ray(const oracle_scene *s, V4f &out, int x, int y, const
     total += step;
   }
   bool pt_found;
+#pragma omp atomic
+  g_dbg_steps += nsteps;
+#pragma omp atomic
+  g_dbg_interp += ninterp;
+#pragma omp atomic
+  g_dbg_rays += 1;
+  if (nsteps > g_dbg_maxsteps) g_dbg_maxsteps = nsteps;
   if (sdf <= 0.0f) {
     step = sdf * step_scale;
     res.x += step * dir.x; res.y += step * dir.y; res.z += step * dir.z;
@@ -1492,6 +1504,12 @@ extern "C" int oracle_upload_voxel_blocks(oracle_engine *, oracle_scene *s, int 
 }
 extern "C" int oracle_upload_visible_ids(oracle_engine *, oracle_render_state *r, const int32_t *ids, int count) {
   memcpy(r->visible_ids.data(), ids, (size_t)count * 4); r->no_visible = count; return 0;
+}
+
+extern "C" int oracle_raycast_stats(long long *out4, int reset) {
+  out4[0] = g_dbg_steps; out4[1] = g_dbg_interp; out4[2] = g_dbg_rays; out4[3] = g_dbg_maxsteps;
+  if (reset) { g_dbg_steps = g_dbg_interp = g_dbg_rays = g_dbg_maxsteps = 0; }
+  return 0;
 }
 
 // known-answer helpers

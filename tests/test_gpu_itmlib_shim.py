@@ -1,0 +1,77 @@
+"""The ITMLib-compatible C++ layer (itmlib/) driven like the reference's InfiniTamDriver/DenseSlam drive ITMLib,
+checked against the CPU oracle running the same call sequence."""
+import os
+import struct
+import subprocess
+
+import numpy as np
+import pytest
+
+import util
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HARNESS = os.path.join(ROOT, "denseslam-global-consistency-h_amd", "itmlib", "tests", "driver_harness")
+
+
+def fnv1a(buf):
+    # 64-bit FNV-1a, vectorised per byte would be slow in python; use the multiplicative structure with numpy chunks
+    h = 1469598103934665603
+    data = np.frombuffer(buf, dtype=np.uint8)
+    for chunk in np.array_split(data, max(1, len(data) // (1 << 16))):
+        for b in chunk.tobytes():
+            h = ((h ^ b) * 1099511628211) & 0xFFFFFFFFFFFFFFFF
+    return h
+
+
+def test_harness_is_built():
+    assert os.path.exists(HARNESS), "run python __graft_entry__.py (build) first"
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("decay,slide", [(0, -1), (1, 3)])
+def test_driver_harness_matches_oracle(pkg, synth, oracle, tmp_path, decay, slide):
+    wl = synth.s_tiny()
+    n_frames = 7
+    p = util.small_params(pkg, wl, num_local_blocks=0x800, num_buckets=0x1000, num_excess=0x400)
+    frames = [wl.frame(i) for i in range(n_frames)]
+    fin, fout = tmp_path / "frames.bin", tmp_path / "out.bin"
+    with open(fin, "wb") as f:
+        f.write(struct.pack("<3i", wl.W, wl.H, n_frames))
+        for rgba, mm, M in frames:
+            f.write(rgba.tobytes()); f.write(mm.tobytes()); f.write(pkg.mat_to_abi(M).tobytes())
+        f.write(np.asarray(wl.intr, np.float32).tobytes())
+        f.write(struct.pack("<4f", p.voxel_size, p.mu, p.frustum_min, p.frustum_max))
+        f.write(struct.pack("<4i", p.max_w, p.num_local_blocks, p.num_buckets, p.num_excess))
+    res = subprocess.run([HARNESS, str(fin), str(fout), str(decay), str(slide)], capture_output=True, text=True, timeout=120)
+    assert res.returncode == 0, res.stdout + res.stderr
+
+    # same call sequence on the oracle (DenseSlam.cpp:210-232; Decay passes forceAllVoxels=true, InfiniTamDriver.h:280)
+    s = oracle.create_scene(p)
+    rs = oracle.create_render_state(s, wl.W, wl.H)
+    v = oracle.create_view(wl.W, wl.H)
+    for i, (rgba, mm, M) in enumerate(frames):
+        oracle.view_update(v, rgba, mm, timestamp=float(i))
+        oracle.process_frame(s, v, rs, M, wl.intr)
+        if slide >= 0 and i + 1 > slide:
+            oracle.slide_window(s, rs, slide)
+        if decay:
+            oracle.decay(s, rs, 1, 2, True)
+    st = oracle.stats(s, rs)
+    rs_free = oracle.create_render_state(s, wl.W, wl.H)
+    M_last = frames[-1][2]
+    depth = oracle.get_image(s, rs_free, M_last, wl.intr, pkg.IMAGE_DEPTH)
+    colour = oracle.get_image(s, rs_free, M_last, wl.intr, pkg.IMAGE_COLOUR_FROM_VOLUME)
+
+    raw = open(fout, "rb").read()
+    last_free, no_vis, used_bytes, decayed = struct.unpack_from("<4i", raw, 0)
+    h_hash, h_vox = struct.unpack_from("<2Q", raw, 16)
+    npx = wl.W * wl.H
+    g_depth = np.frombuffer(raw, np.float32, npx, 32).reshape(wl.H, wl.W)
+    g_colour = np.frombuffer(raw, np.uint8, npx * 4, 32 + npx * 4).reshape(wl.H, wl.W, 4)
+    assert last_free == st["last_free_block_id"] and no_vis == st["no_visible_entries"]
+    assert decayed == st["decayed_block_count"]
+    assert used_bytes == 8 * 512 * (p.num_local_blocks - st["last_free_block_id"])  # InfiniTamDriver.h:345-346 formula
+    assert h_hash == fnv1a(oracle.download_hash_table(s).tobytes())
+    assert h_vox == fnv1a(oracle.download_voxel_blocks(s).tobytes())
+    assert np.abs(g_depth - depth).max() <= 1e-4 and (g_depth > 0).sum() > 500
+    assert np.abs(g_colour.astype(int) - colour.astype(int)).max() <= 1
