@@ -186,6 +186,9 @@ class CApi:
     def set_shard(self, scene, shard, num_shards, chunk_blocks=256):
         self._call("scene_set_shard", scene.ptr, C.c_int(shard), C.c_int(num_shards), C.c_int(chunk_blocks))
 
+    def set_shard_range(self, scene, first_block, num_blocks):
+        self._call("scene_set_shard_range", scene.ptr, C.c_int(first_block), C.c_int(num_blocks))
+
     def create_render_state(self, scene, width, height):
         h = C.c_void_p()
         self._call("render_state_create", self._engine, scene.ptr, C.c_int(width), C.c_int(height), C.byref(h))

@@ -258,6 +258,12 @@ int dslam_scene_set_shard(dslam_scene *s, int shard, int num_shards, int chunk_b
   return DSLAM_OK;
 }
 
+int dslam_scene_set_shard_range(dslam_scene *s, int first_block, int num_blocks) {
+  DSLAM_REQUIRE(s && first_block >= 0, "bad shard range");
+  s->shard_first = first_block; s->shard_count = num_blocks;
+  return DSLAM_OK;
+}
+
 // ---- render state / view --------------------------------------------------------------------------------------
 int dslam_render_state_create(dslam_engine *e, const dslam_scene *s, int w, int h, dslam_render_state **out) {
   DSLAM_REQUIRE(e && s && out && w > 0 && h > 0, "bad argument");

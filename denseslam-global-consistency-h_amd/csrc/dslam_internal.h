@@ -94,6 +94,7 @@ struct dslam_scene {
   int *transfer_ids_host = nullptr;     // pinned [kTransferBlocks]
   int last_swapped_in = 0, last_swapped_out = 0;
   int shard = 0, num_shards = 1, chunk_blocks = 256;
+  int shard_first = 0, shard_count = -1;  // contiguous slot range (count < 0: off)
 };
 
 struct dslam_render_state {

@@ -36,6 +36,7 @@ struct IntegrateParams {
   int depth_weighting, max_new_w;
   float max_distance;
   int shard, num_shards, chunk_blocks;
+  int shard_first, shard_count;
 };
 
 __device__ __forceinline__ int new_weight(const IntegrateParams &p, float depth_measure) {
@@ -172,6 +173,7 @@ __global__ __launch_bounds__(256) void k_integrate(IntegrateParams p) {
       const int ptr = __builtin_amdgcn_readlane(e_ptr, k);
       if (ptr < 0) continue;
       if (p.num_shards > 1 && ((ptr / p.chunk_blocks) % p.num_shards) != p.shard) continue;
+      if (p.shard_count >= 0 && (ptr < p.shard_first || ptr >= p.shard_first + p.shard_count)) continue;
       const int gx = __builtin_amdgcn_readlane(e_px, k) * kBlock;
       const int gy = __builtin_amdgcn_readlane(e_py, k) * kBlock;
       const int gz = __builtin_amdgcn_readlane(e_pz, k) * kBlock;
@@ -217,6 +219,7 @@ static void fill_params(IntegrateParams &ip, dslam_engine *e, dslam_scene *s, co
   ip.stop_max = s->p.stop_integrating_at_max_w;
   ip.depth_weighting = e->wp.depth_weighting; ip.max_new_w = e->wp.max_new_w; ip.max_distance = e->wp.max_distance;
   ip.shard = s->shard; ip.num_shards = s->num_shards; ip.chunk_blocks = s->chunk_blocks;
+  ip.shard_first = s->shard_first; ip.shard_count = s->shard_count;
 }
 
 constexpr int kIntegrateGrid = 2048;

@@ -282,6 +282,9 @@ void *dslam_render_state_image_dev(dslam_render_state *r, int want_float);
  * whose chunk (slot / chunk_blocks) satisfies chunk % num_shards == shard; allocation stays global
  * (and bit-identical on every rank).  num_shards = 1 disables sharding. */
 int dslam_scene_set_shard(dslam_scene *s, int shard, int num_shards, int chunk_blocks);
+/* Same, with a contiguous slot range [first_block, first_block + num_blocks): the layout an in-place RCCL
+ * all-gather over the voxel-block array needs.  num_blocks < 0 disables. */
+int dslam_scene_set_shard_range(dslam_scene *s, int first_block, int num_blocks);
 
 /* ---- instrumentation ---------------------------------------------------------------------------- */
 /* Time `iterations` back-to-back launches of the integrate kernel alone on the engine stream with HIP

@@ -157,6 +157,7 @@ struct oracle_scene {
   std::vector<uint8_t> has_stored;
   dslam_voxel *stored;  // n_entries * 512, calloc'ed lazily by the OS
   int shard, num_shards, chunk_blocks;
+  int shard_first, shard_count;
 };
 
 struct oracle_render_state {
@@ -516,6 +517,7 @@ extern "C" int oracle_scene_create(oracle_engine *e, const dslam_scene_params *p
     if (!s->stored) { delete s; return DSLAM_ERR_INVALID; }
   }
   s->shard = 0; s->num_shards = 1; s->chunk_blocks = 256;
+  s->shard_first = 0; s->shard_count = -1;
   oracle_scene_reset(e, s);
   *out = s;
   return 0;
@@ -523,6 +525,10 @@ extern "C" int oracle_scene_create(oracle_engine *e, const dslam_scene_params *p
 extern "C" int oracle_scene_destroy(oracle_scene *s) { if (s) { free(s->stored); delete s; } return 0; }
 extern "C" int oracle_scene_set_shard(oracle_scene *s, int shard, int num_shards, int chunk_blocks) {
   s->shard = shard; s->num_shards = num_shards; s->chunk_blocks = chunk_blocks; return 0;
+}
+
+extern "C" int oracle_scene_set_shard_range(oracle_scene *s, int first, int count) {
+  s->shard_first = first; s->shard_count = count; return 0;
 }
 
 extern "C" int oracle_render_state_create(oracle_engine *, const oracle_scene *s, int w, int h, oracle_render_state **out) {
@@ -825,6 +831,7 @@ static void integrate_impl(oracle_engine *e, oracle_scene *s, const oracle_view 
     const dslam_hash_entry &he = s->hash[r->visible_ids[i]];
     if (he.ptr < 0) continue;
     if (s->num_shards > 1 && ((he.ptr / s->chunk_blocks) % s->num_shards) != s->shard) continue;
+    if (s->shard_count >= 0 && (he.ptr < s->shard_first || he.ptr >= s->shard_first + s->shard_count)) continue;
     int gx = he.pos[0] * DSLAM_BLOCK_SIZE, gy = he.pos[1] * DSLAM_BLOCK_SIZE, gz = he.pos[2] * DSLAM_BLOCK_SIZE;
     dslam_voxel *vb = &s->vba[(size_t)he.ptr * 512];
     for (int z = 0; z < 8; z++)
