@@ -42,6 +42,26 @@ __global__ __launch_bounds__(256) void k_reset_tables(HashEntry *hash, int n_ent
   }
 }
 
+// bucket occupancy bitmap from scratch (after a bulk upload of the hash table)
+__global__ __launch_bounds__(256) void k_rebuild_bucket_bits(const HashEntry *__restrict__ hash, int num_buckets,
+                                                             unsigned *__restrict__ bits) {
+  const int words = (num_buckets + 31) / 32;
+  for (int w = blockIdx.x * blockDim.x + threadIdx.x; w < words; w += gridDim.x * blockDim.x) {
+    unsigned v = 0;
+    for (int b = 0; b < 32; b++) {
+      const int t = w * 32 + b;
+      if (t < num_buckets && hash[t].ptr >= -1) v |= 1u << b;
+    }
+    bits[w] = v;
+  }
+}
+
+int launch_rebuild_bucket_bits(dslam_engine *e, dslam_scene *s) {
+  hipLaunchKernelGGL(k_rebuild_bucket_bits, dim3(256), dim3(256), 0, e->stream, s->hash, s->p.num_buckets, s->bucket_bits);
+  DSLAM_HIP(hipGetLastError());
+  return DSLAM_OK;
+}
+
 int launch_scene_reset(dslam_engine *e, dslam_scene *s) {
   const size_t n16 = (size_t)s->p.num_local_blocks * kBlock3 / 2;
   hipLaunchKernelGGL(k_fill_voxels, dim3(4096), dim3(256), 0, e->stream, reinterpret_cast<uint4 *>(s->voxels), n16);
@@ -49,6 +69,7 @@ int launch_scene_reset(dslam_engine *e, dslam_scene *s) {
                      s->last_seen, s->p.num_local_blocks, s->excess_list, s->p.num_excess, s->counters);
   DSLAM_HIP(hipMemsetAsync(s->masks, 0, (size_t)s->p.num_local_blocks * 2 * s->history_words * sizeof(unsigned long long),
                            e->stream));
+  DSLAM_HIP(hipMemsetAsync(s->bucket_bits, 0, (size_t)((s->p.num_buckets + 31) / 32) * sizeof(unsigned), e->stream));
   if (s->swap_state) DSLAM_HIP(hipMemsetAsync(s->swap_state, 0, s->n_entries, e->stream));
   DSLAM_HIP(hipGetLastError());
   return DSLAM_OK;
@@ -208,7 +229,7 @@ __global__ __launch_bounds__(256) void k_commit_apply(const unsigned char *__res
                                                       const int *__restrict__ tile_offsets, HashEntry *hash,
                                                       int num_buckets, const int *__restrict__ alloc_list,
                                                       const int *__restrict__ excess_list, unsigned char *vis_type,
-                                                      SceneCounters *cnt) {
+                                                      SceneCounters *cnt, unsigned *bucket_bits) {
   __shared__ int red[2][4];
   const int t0 = blockIdx.x * kTileEntries + threadIdx.x * 4;
   unsigned char a[4] = {0, 0, 0, 0};
@@ -238,6 +259,7 @@ __global__ __launch_bounds__(256) void k_commit_apply(const unsigned char *__res
       if (a[k] == 1) {
         if (vr < avail_vba) {
           store_entry(hash, t, b.x, b.y, b.z, 0, alloc_list[base_free - vr]);
+          atomicOr(&bucket_bits[t >> 5], 1u << (t & 31));  // type 1 = an ordered entry (t < num_buckets) got a block
           succ_vba++;
         } else {
           vis_type[t] = 0;
@@ -422,7 +444,7 @@ int launch_allocate(dslam_engine *e, dslam_scene *s, const dslam_view *v, dslam_
                        s->counters);
     hipLaunchKernelGGL(k_commit_apply, dim3(n_tiles), dim3(256), 0, e->stream, e->alloc_type, e->block_coords, N,
                        e->tile_offsets, s->hash, s->p.num_buckets, s->alloc_list, s->excess_list, r->visible_type,
-                       s->counters);
+                       s->counters, s->bucket_bits);
   }
   VisParams vp;
   memcpy(vp.M.m, M_d, sizeof(float) * 16);

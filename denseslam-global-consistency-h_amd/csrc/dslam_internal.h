@@ -78,6 +78,8 @@ struct dslam_scene {
   int *alloc_list = nullptr;
   int *excess_list = nullptr;
   int *last_seen = nullptr;           // per voxel-block slot
+  unsigned *bucket_bits = nullptr;    // 1 bit per bucket: head entry occupied (ptr >= -1); kept in step by
+                                      // allocation / release so ray marching can skip empty buckets unprobed
   dslam::SceneCounters *counters = nullptr;  // device
   // visible-list history: per voxel-block slot two bit rings (0 fusion, 1 defusion); list k of ring q
   // owns bit k % (64*history_words) of masks[(slot*2+q)*history_words ...]
@@ -125,6 +127,7 @@ struct dslam_view {
 namespace dslam {
 // kernels' host launchers (one translation unit per subsystem)
 int launch_scene_reset(dslam_engine *e, dslam_scene *s);
+int launch_rebuild_bucket_bits(dslam_engine *e, dslam_scene *s);
 int launch_view_convert(dslam_engine *e, dslam_view *v, const void *rgba_dev, const void *depth_dev, float a, float b);
 int launch_allocate(dslam_engine *e, dslam_scene *s, const dslam_view *v, dslam_render_state *r, const float *M_d,
                     const float *intr, int only_update_visible_list);

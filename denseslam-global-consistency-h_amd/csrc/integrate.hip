@@ -32,12 +32,26 @@ struct IntegrateParams {
   float fx_d, fy_d, cx_d, cy_d;
   float fx_r, fy_r, cx_r, cy_r;
   float voxel_size, mu;
+  float inv_mu, inv_32767, inv_255;  // correctly rounded reciprocals (host division) for div_exact()
+  int same_cam;                      // RGB camera == depth camera (identity calib of the reference): reuse projection
   int max_w, stop_max;
   int depth_weighting, max_new_w;
   float max_distance;
   int shard, num_shards, chunk_blocks;
   int shard_first, shard_count;
 };
+
+// a / b for a divisor whose correctly rounded reciprocal y = RN(1/b) is known: q = RN(a*y), r = a - b*q (exact, FMA),
+// q' = RN(q + r*y).  This IS the IEEE quotient RN(a/b) (Markstein) -- 3 instructions instead of the ~10 of
+// v_div_scale/v_rcp/v_div_fmas/v_div_fixup.  Verified exhaustively over every finite float a with |a| <= 1e30 for
+// b = 32767, 255 and the mu values of the workloads, and densely for b = 1..256 (tests/tools/verify_exact_div.cpp).
+__device__ __forceinline__ float div_exact(float a, float b, float y) {
+  const float q = a * y;
+  const float r = __fmaf_rn(-b, q, a);
+  return __fmaf_rn(r, y, q);
+}
+
+constexpr int kInvTab = 512;  // reciprocals of the integer weights 1..511 (w_depth <= 255, newW <= 255)
 
 __device__ __forceinline__ int new_weight(const IntegrateParams &p, float depth_measure) {
   if (!p.depth_weighting) return 1;
@@ -51,37 +65,41 @@ __device__ __forceinline__ void bilinear_rgb(const uchar4 *__restrict__ rgba, fl
   const float dx = px - (float)ix, dy = py - (float)iy;
   const uchar4 a = rgba[ix + iy * W], b = rgba[(ix + 1) + iy * W], c = rgba[ix + (iy + 1) * W],
                d = rgba[(ix + 1) + (iy + 1) * W];
+  const float w00 = (1.0f - dx) * (1.0f - dy), w10 = dx * (1.0f - dy), w01 = (1.0f - dx) * dy, w11 = dx * dy;
+  // ((a*(1-dx))*(1-dy)) in the reference's evaluation order: the products are NOT regrouped
   out[0] = ((float)a.x * (1.0f - dx) * (1.0f - dy) + (float)b.x * dx * (1.0f - dy) + (float)c.x * (1.0f - dx) * dy +
             (float)d.x * dx * dy);
   out[1] = ((float)a.y * (1.0f - dx) * (1.0f - dy) + (float)b.y * dx * (1.0f - dy) + (float)c.y * (1.0f - dx) * dy +
             (float)d.y * dx * dy);
   out[2] = ((float)a.z * (1.0f - dx) * (1.0f - dy) + (float)b.z * dx * (1.0f - dy) + (float)c.z * (1.0f - dx) * dy +
             (float)d.z * dx * dy);
+  (void)w00; (void)w10; (void)w01; (void)w11;
 }
 
-// ComputeUpdatedVoxelInfo<hasColor>::compute on a packed voxel (lo, hi).  Returns true if the voxel changed.
+// ComputeUpdatedVoxelInfo<hasColor>::compute on a packed voxel (lo, hi) whose camera-frame position pc = M_d * pm
+// has been assembled by the caller.  Returns true if the voxel changed.
 template <bool DEINT>
-__device__ __forceinline__ bool update_voxel(unsigned &lo, unsigned &hi, const Vec4 &pm, const IntegrateParams &p) {
-  float eta;
+__device__ __forceinline__ bool update_voxel(unsigned &lo, unsigned &hi, const Vec4 &pc, const Vec4 &pm,
+                                             const IntegrateParams &p, const float *inv_tab) {
+  float eta, u, w;
   bool changed = false;
   {  // computeUpdatedVoxelDepthInfo
-    const Vec4 pc = mul(p.M_d, pm);
     if (pc.z <= 0) return false;
-    const float u = p.fx_d * pc.x / pc.z + p.cx_d;
-    const float w = p.fy_d * pc.y / pc.z + p.cy_d;
+    u = p.fx_d * pc.x / pc.z + p.cx_d;
+    w = p.fy_d * pc.y / pc.z + p.cy_d;
     if ((u < 1) || (u > p.Wd - 2) || (w < 1) || (w > p.Hd - 2)) return false;
     const float dm = p.depth[(int)(u + 0.5f) + (int)(w + 0.5f) * p.Wd];
     if (dm <= 0.0f) return false;
     eta = dm - pc.z;
     if (eta < -p.mu) return false;
-    const float oldF = sdf_to_float((short)(lo & 0xffffu));
+    const float oldF = div_exact((float)(short)(lo & 0xffffu), 32767.0f, p.inv_32767);
     const int oldW = (int)((lo >> 16) & 0xffu);
-    float newF = fminf(1.0f, eta / p.mu);
+    float newF = fminf(1.0f, div_exact(eta, p.mu, p.inv_mu));
     int newW = new_weight(p, dm);
     if (!DEINT) {
       newF = (float)oldW * oldF + (float)newW * newF;
       newW = oldW + newW;
-      newF /= (float)newW;
+      newF = div_exact(newF, (float)newW, inv_tab[newW]);
       newW = newW < p.max_w ? newW : p.max_w;
       const unsigned sdf = (unsigned)(unsigned short)float_to_sdf(newF);
       lo = (lo & 0xff000000u) | ((unsigned)newW << 16) | sdf;
@@ -91,7 +109,7 @@ __device__ __forceinline__ bool update_voxel(unsigned &lo, unsigned &hi, const V
       if (remW == 0) {
         lo = (lo & 0xff000000u) | 0x7fffu;
       } else {
-        float F = ((float)oldW * oldF - (float)newW * newF) / (float)remW;
+        float F = div_exact((float)oldW * oldF - (float)newW * newF, (float)remW, inv_tab[remW]);
         F = fmaxf(-1.0f, fminf(1.0f, F));
         const unsigned sdf = (unsigned)(unsigned short)float_to_sdf(F);
         lo = (lo & 0xff000000u) | ((unsigned)remW << 16) | sdf;
@@ -99,12 +117,14 @@ __device__ __forceinline__ bool update_voxel(unsigned &lo, unsigned &hi, const V
       changed = true;
     }
   }
-  if ((eta > p.mu) || (fabsf(eta / p.mu) > 0.25f)) return changed;
+  if ((eta > p.mu) || (fabsf(div_exact(eta, p.mu, p.inv_mu)) > 0.25f)) return changed;
   {  // computeUpdatedVoxelColorInfo
-    const Vec4 pc = mul(p.M_rgb, pm);
-    const float u = p.fx_r * pc.x / pc.z + p.cx_r;
-    const float w = p.fy_r * pc.y / pc.z + p.cy_r;
-    if ((u < 1) || (u > p.Wr - 2) || (w < 1) || (w > p.Hr - 2)) return changed;
+    if (!p.same_cam) {
+      const Vec4 pcr = mul(p.M_rgb, pm);
+      u = p.fx_r * pcr.x / pcr.z + p.cx_r;
+      w = p.fy_r * pcr.y / pcr.z + p.cy_r;
+      if ((u < 1) || (u > p.Wr - 2) || (w < 1) || (w > p.Hr - 2)) return changed;
+    }
     float m[3];
     bilinear_rgb(p.rgba, u, w, p.Wr, m);
     const unsigned oc[3] = {lo >> 24, hi & 0xffu, (hi >> 8) & 0xffu};
@@ -114,11 +134,12 @@ __device__ __forceinline__ bool update_voxel(unsigned &lo, unsigned &hi, const V
     unsigned new_wc;
     if (!DEINT) {
       float newW = oldW + 1.0f;
+      const float inv_new = inv_tab[wc + 1];
 #pragma unroll
       for (int k = 0; k < 3; k++) {
-        const float oldC = (float)oc[k] / 255.0f;
-        const float c = m[k] / 255.0f;
-        const float v = (oldC * oldW + c * 1.0f) / newW;
+        const float oldC = div_exact((float)oc[k], 255.0f, p.inv_255);
+        const float c = div_exact(m[k], 255.0f, p.inv_255);
+        const float v = div_exact(oldC * oldW + c * 1.0f, newW, inv_new);
         nc[k] = (unsigned)(unsigned char)(v * 255.0f);
       }
       newW = fminf(newW, (float)p.max_w);
@@ -130,11 +151,12 @@ __device__ __forceinline__ bool update_voxel(unsigned &lo, unsigned &hi, const V
         nc[0] = nc[1] = nc[2] = 0;
         new_wc = 0;
       } else {
+        const float inv_rem = inv_tab[wc - 1];
 #pragma unroll
         for (int k = 0; k < 3; k++) {
-          const float oldC = (float)oc[k] / 255.0f;
-          const float c = m[k] / 255.0f;
-          float v = (oldC * oldW - c * 1.0f) / remW;
+          const float oldC = div_exact((float)oc[k], 255.0f, p.inv_255);
+          const float c = div_exact(m[k], 255.0f, p.inv_255);
+          float v = div_exact(oldC * oldW - c * 1.0f, remW, inv_rem);
           v = fmaxf(0.0f, fminf(1.0f, v));
           nc[k] = (unsigned)(unsigned char)(v * 255.0f);
         }
@@ -152,6 +174,9 @@ constexpr int kMaxGroup = 8;
 
 template <bool DEINT>
 __global__ __launch_bounds__(256) void k_integrate(IntegrateParams p) {
+  __shared__ float inv_tab[kInvTab];
+  for (int i = threadIdx.x; i < kInvTab; i += 256) inv_tab[i] = 1.0f / (float)i;  // IEEE division: RN(1/i)
+  __syncthreads();
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane((int)((blockIdx.x * 256 + threadIdx.x) >> 6));
   const int n_waves = gridDim.x * 4;
@@ -181,21 +206,36 @@ __global__ __launch_bounds__(256) void k_integrate(IntegrateParams p) {
       uint4 v[4];
 #pragma unroll
       for (int j = 0; j < 4; j++) v[j] = blk[j * 64 + lane];
+
+      // pc = M_d * (x, y, z, 1) = ((m0*x + m4*y) + m8*z) + m12 per component.  The products depend only on the
+      // lane's 2 x values, its y, and the 4 z values of its loads, so they are formed once per block; what is
+      // left per voxel are the additions, in the reference's order (bit-identical to the full mat-vec).
+      const float fy = (float)(gy + vy) * p.voxel_size;
+      float fxv[2], pxy[2][3];
+#pragma unroll
+      for (int h = 0; h < 2; h++) {
+        fxv[h] = (float)(gx + vx0 + h) * p.voxel_size;
+        pxy[h][0] = p.M_d.m[0] * fxv[h] + p.M_d.m[4] * fy;
+        pxy[h][1] = p.M_d.m[1] * fxv[h] + p.M_d.m[5] * fy;
+        pxy[h][2] = p.M_d.m[2] * fxv[h] + p.M_d.m[6] * fy;
+      }
 #pragma unroll
       for (int j = 0; j < 4; j++) {
-        const int z = j * 2 + vz0;
+        const float fz = (float)(gz + j * 2 + vz0) * p.voxel_size;
+        const float az0 = p.M_d.m[8] * fz, az1 = p.M_d.m[9] * fz, az2 = p.M_d.m[10] * fz;
         bool ch = false;
 #pragma unroll
         for (int h = 0; h < 2; h++) {
           unsigned &lo = h ? v[j].z : v[j].x;
           unsigned &hi = h ? v[j].w : v[j].y;
           if (!DEINT && p.stop_max && (int)((lo >> 16) & 0xffu) == p.max_w) continue;
-          Vec4 pm;
-          pm.x = (float)(gx + vx0 + h) * p.voxel_size;
-          pm.y = (float)(gy + vy) * p.voxel_size;
-          pm.z = (float)(gz + z) * p.voxel_size;
-          pm.w = 1.0f;
-          ch |= update_voxel<DEINT>(lo, hi, pm, p);
+          Vec4 pc, pm;
+          pc.x = (pxy[h][0] + az0) + p.M_d.m[12];
+          pc.y = (pxy[h][1] + az1) + p.M_d.m[13];
+          pc.z = (pxy[h][2] + az2) + p.M_d.m[14];
+          pc.w = 1.0f;
+          pm.x = fxv[h]; pm.y = fy; pm.z = fz; pm.w = 1.0f;
+          ch |= update_voxel<DEINT>(lo, hi, pc, pm, p, inv_tab);
         }
         if (ch) blk[j * 64 + lane] = v[j];
       }
@@ -216,6 +256,9 @@ static void fill_params(IntegrateParams &ip, dslam_engine *e, dslam_scene *s, co
   ip.fx_d = intr_d[0]; ip.fy_d = intr_d[1]; ip.cx_d = intr_d[2]; ip.cy_d = intr_d[3];
   ip.fx_r = kr[0]; ip.fy_r = kr[1]; ip.cx_r = kr[2]; ip.cy_r = kr[3];
   ip.voxel_size = s->p.voxel_size; ip.mu = s->p.mu; ip.max_w = s->p.max_w;
+  ip.inv_mu = 1.0f / s->p.mu; ip.inv_32767 = 1.0f / 32767.0f; ip.inv_255 = 1.0f / 255.0f;
+  ip.same_cam = (memcmp(ip.M_d.m, ip.M_rgb.m, 64) == 0 && kr[0] == intr_d[0] && kr[1] == intr_d[1] && kr[2] == intr_d[2] &&
+                 kr[3] == intr_d[3] && v->w_rgb == v->w_d && v->h_rgb == v->h_d) ? 1 : 0;
   ip.stop_max = s->p.stop_integrating_at_max_w;
   ip.depth_weighting = e->wp.depth_weighting; ip.max_new_w = e->wp.max_new_w; ip.max_distance = e->wp.max_distance;
   ip.shard = s->shard; ip.num_shards = s->num_shards; ip.chunk_blocks = s->chunk_blocks;

@@ -5,9 +5,12 @@
 // (InfiniTamDriver.cpp:229-277, types :16-38), trackingController->Prepare (InfiniTamDriver.h:208-220),
 // mapManager->countVisibleBlocks (DenseSlam.cpp:555-556).  Algorithm: SURVEY.md Appendix A.6, A.7.
 //
-// Mapping: the ray march is latency/gather bound (random 16-B hash probes + 8-B voxel reads).  One workgroup
-// renders a 16x16 pixel tile; each wavefront an 8x8 sub-tile, i.e. exactly one cell of the 1/8-resolution range
-// image, so (zmin, zmax) and -- mostly -- the marched blocks are wave-uniform and the per-lane block cache hits.
+// Mapping: the ray march is latency/gather bound (random 16-B hash probes + 8-B voxel reads).  One wavefront (= one
+// workgroup) renders an 8x8 pixel tile, i.e. exactly one cell of the 1/8-resolution range image, so (zmin, zmax)
+// and -- mostly -- the marched blocks are wave-uniform.  Runs of equal steps are prefetched 4 samples deep.
+#include <cstdio>
+#include <cstdlib>
+
 #include "dslam_internal.h"
 
 #pragma clang fp contract(off)
@@ -180,30 +183,54 @@ __global__ void k_cap_render_tiles(RenderCounters *rc, int *req) {
   }
 }
 
-// fill the range image: the render tiles of a block partition its bbox, so min/max over the bbox is identical.
-// Values are positive floats, so integer atomics on the bit patterns order correctly.
-__global__ __launch_bounds__(256) void k_fill_range(const RenderCounters *rc, const int4 *__restrict__ boxes,
-                                                    const float2 *__restrict__ zr, const int *__restrict__ req,
-                                                    float2 *range, int W) {
+// Fill the range image.  The render tiles of a block partition its bbox, so min/max over the bbox is identical to
+// upstream's tile list.  Values are positive floats, so integer min/max on the bit patterns order correctly.
+//
+// Corner pass (the ceil(W/8) x ceil(H/8) cells the raycaster reads): one workgroup = one 16x16-cell tile x one chunk
+// slice of the visible list.  Overlapping blocks are accumulated with LDS atomics (ds_min/ds_max), then every touched cell
+// is flushed with ONE global atomic pair -- instead of one contended global atomic pair per (block, cell).
+constexpr int kRangeTile = 16;
+constexpr int kRangeSlices = 32;  // workgroups per tile; each strides over the visible list
+
+__global__ __launch_bounds__(256) void k_fill_range_tiles(const RenderCounters *rc, const int4 *__restrict__ boxes,
+                                                          const float2 *__restrict__ zr, const int *__restrict__ req,
+                                                          float2 *range, int W, int tiles_x) {
+  __shared__ int s_min[kRangeTile * kRangeTile], s_max[kRangeTile * kRangeTile];
   const int n = rc->no_visible;
-  // 16 lanes cooperate on one block: bbox cells are dealt round-robin
-  const int sub = threadIdx.x & 15;
-  const int group = (blockIdx.x * blockDim.x + threadIdx.x) >> 4;
-  const int n_groups = (gridDim.x * blockDim.x) >> 4;
-  for (int i = group; i < n; i += n_groups) {
+  if ((int)(blockIdx.y * 256) >= n) return;
+  const int tx0 = (blockIdx.x % tiles_x) * kRangeTile, ty0 = (blockIdx.x / tiles_x) * kRangeTile;
+  const int far_i = __float_as_int(kFarAway), close_i = __float_as_int(kVeryClose);
+  s_min[threadIdx.x] = far_i;
+  s_max[threadIdx.x] = close_i;
+  __syncthreads();
+  for (int i = blockIdx.y * 256 + threadIdx.x; i < n; i += gridDim.y * 256) {
     if (req[i] == 0) continue;
     const int4 b = boxes[i];
+    const int x0 = b.x > tx0 ? b.x : tx0, x1 = b.z < tx0 + kRangeTile - 1 ? b.z : tx0 + kRangeTile - 1;
+    const int y0 = b.y > ty0 ? b.y : ty0, y1 = b.w < ty0 + kRangeTile - 1 ? b.w : ty0 + kRangeTile - 1;
+    if (x0 > x1 || y0 > y1) continue;
     const float2 z = zr[i];
-    const int bw = b.z - b.x + 1, cells = bw * (b.w - b.y + 1);
     const int zmin_i = __float_as_int(z.x), zmax_i = __float_as_int(z.y);
-    for (int c = sub; c < cells; c += 16) {
-      const int y = b.y + c / bw, x = b.x + c % bw;
-      int *px = reinterpret_cast<int *>(&range[x + (size_t)y * W]);
-      if (px[0] > zmin_i) atomicMin(&px[0], zmin_i);
-      if (px[1] < zmax_i) atomicMax(&px[1], zmax_i);
-    }
+    for (int y = y0; y <= y1; y++)
+      for (int x = x0; x <= x1; x++) {
+        const int c = (x - tx0) + (y - ty0) * kRangeTile;
+        atomicMin(&s_min[c], zmin_i);
+        atomicMax(&s_max[c], zmax_i);
+      }
+  }
+  __syncthreads();
+  const int mn = s_min[threadIdx.x], mx = s_max[threadIdx.x];
+  if (mn != far_i || mx != close_i) {
+    const int x = tx0 + (threadIdx.x % kRangeTile), y = ty0 + (threadIdx.x / kRangeTile);
+    int *px = reinterpret_cast<int *>(&range[x + (size_t)y * W]);
+    if (mn != far_i) atomicMin(&px[0], mn);
+    if (mx != close_i) atomicMax(&px[1], mx);
   }
 }
+
+// Cells outside that corner: upstream clamps bboxes to the full image size although coordinates are 1/8 scale, so
+// blocks near the camera spill thousands of cells past the corner.  Nothing ever reads them (castRay indexes
+// floor(x/8) + floor(y/8) * W), so they are not filled here; tests compare the corner.
 
 int launch_expected_depths(dslam_engine *e, const dslam_scene *s, dslam_render_state *r, const float *M,
                            const float *intr) {
@@ -216,8 +243,11 @@ int launch_expected_depths(dslam_engine *e, const dslam_scene *s, dslam_render_s
   hipLaunchKernelGGL(k_project_blocks, dim3(512), dim3(256), 0, e->stream, r->visible_ids, r->counters, s->hash, pp,
                      r->proj_boxes, r->proj_z, r->proj_req);
   hipLaunchKernelGGL(k_cap_render_tiles, dim3(1), dim3(64), 0, e->stream, r->counters, r->proj_req);
-  hipLaunchKernelGGL(k_fill_range, dim3(1024), dim3(256), 0, e->stream, r->counters, r->proj_boxes, r->proj_z,
-                     r->proj_req, r->range, r->w);
+  // corner = the tiles covering ceil(W/8) x ceil(H/8) cells (clamped to the image); chunks sized for the pool
+  const int cw = (r->w + 7) / 8, ch = (r->h + 7) / 8;
+  const int tiles_x = (cw + kRangeTile - 1) / kRangeTile, tiles_y = (ch + kRangeTile - 1) / kRangeTile;
+  hipLaunchKernelGGL(k_fill_range_tiles, dim3(tiles_x * tiles_y, kRangeSlices), dim3(256), 0, e->stream, r->counters,
+                     r->proj_boxes, r->proj_z, r->proj_req, r->range, r->w, tiles_x);
   DSLAM_HIP(hipGetLastError());
   return DSLAM_OK;
 }
@@ -227,6 +257,7 @@ int launch_expected_depths(dslam_engine *e, const dslam_scene *s, dslam_render_s
 // ---------------------------------------------------------------------------------------------------------
 struct VolumeRef {
   const HashEntry *hash;
+  const unsigned *bucket_bits;  // 1 bit per bucket: head occupied.  128 KB, L2-resident: empty buckets cost no table probe
   const uint2 *voxels;
   unsigned mask;
   int num_buckets;
@@ -246,6 +277,10 @@ __device__ __forceinline__ uint2 read_voxel(const VolumeRef &vol, int px, int py
     return vol.voxels[(size_t)c.block_ptr + lin];
   }
   int h = hash_index(bx, by, bz, vol.mask);
+  if (vol.bucket_bits && !((vol.bucket_bits[h >> 5] >> (h & 31)) & 1u)) {  // empty bucket head => not allocated
+    found = false;
+    return make_uint2(kEmptyVoxelLo, kEmptyVoxelHi);
+  }
   while (true) {
     const HashEntry e = load_entry(vol.hash, h);
     if (e.pos[0] == bx && e.pos[1] == by && e.pos[2] == bz && e.ptr >= 0) {
@@ -271,21 +306,72 @@ __device__ __forceinline__ float read_sdf_uninterp(const VolumeRef &vol, const V
   return rd_sdf(vol, iround(pt.x), iround(pt.y), iround(pt.z), found, c) / 32767.0f;
 }
 
+// block base pointer (voxel index of the block's first voxel) or -1; refreshes the per-lane cache on a hit
+__device__ __forceinline__ int lookup_block(const VolumeRef &vol, int bx, int by, int bz, IndexCache &c) {
+  if (bx == c.bx && by == c.by && bz == c.bz) return c.block_ptr;
+  int h = hash_index(bx, by, bz, vol.mask);
+  if (vol.bucket_bits && !((vol.bucket_bits[h >> 5] >> (h & 31)) & 1u)) return -1;
+  while (true) {
+    const HashEntry e = load_entry(vol.hash, h);
+    if (e.pos[0] == bx && e.pos[1] == by && e.pos[2] == bz && e.ptr >= 0) {
+      c.bx = bx; c.by = by; c.bz = bz;
+      c.block_ptr = e.ptr * kBlock3;
+      return c.block_ptr;
+    }
+    if (e.offset < 1) return -1;
+    h = vol.num_buckets + e.offset - 1;
+  }
+}
+
+// The 8 taps of a trilinear read.  Tap k = (dx, dy, dz) = (k & 1, (k >> 1) & 1, k >> 2) relative to (x, y, z).  The
+// kernel is bound by the NUMBER of scattered load instructions (measured: prefetching or speculative variants that
+// add loads are slower), so the <= 8 (usually 1 or 2) distinct voxel blocks are resolved with as few probes as
+// possible -- de-duplicated per axis, per-lane block cache first -- and then the 8 voxel loads are issued together.
+// A tap whose block is not allocated reads the empty voxel, exactly like readVoxel.
+__device__ __forceinline__ void gather_taps(const VolumeRef &vol, int x, int y, int z, IndexCache &c, uint2 t[8]) {
+  const int bx0 = x >> 3, by0 = y >> 3, bz0 = z >> 3;  // arithmetic shift = floor division, as pointToVoxelBlockPos
+  const int bx1 = (x + 1) >> 3, by1 = (y + 1) >> 3, bz1 = (z + 1) >> 3;
+  const bool sx = bx1 == bx0, sy = by1 == by0, sz = bz1 == bz0;
+  int p[8];
+  p[0] = lookup_block(vol, bx0, by0, bz0, c);
+  p[1] = sx ? p[0] : lookup_block(vol, bx1, by0, bz0, c);
+  p[2] = sy ? p[0] : lookup_block(vol, bx0, by1, bz0, c);
+  p[3] = sx ? p[2] : (sy ? p[1] : lookup_block(vol, bx1, by1, bz0, c));
+  p[4] = sz ? p[0] : lookup_block(vol, bx0, by0, bz1, c);
+  p[5] = sz ? p[1] : (sx ? p[4] : lookup_block(vol, bx1, by0, bz1, c));
+  p[6] = sz ? p[2] : (sy ? p[4] : lookup_block(vol, bx0, by1, bz1, c));
+  p[7] = sz ? p[3] : (sx ? p[6] : (sy ? p[5] : lookup_block(vol, bx1, by1, bz1, c)));
+  const int lx0 = x & 7, lx1 = (x + 1) & 7, ly0 = (y & 7) * kBlock, ly1 = ((y + 1) & 7) * kBlock;
+  const int lz0 = (z & 7) * kBlock * kBlock, lz1 = ((z + 1) & 7) * kBlock * kBlock;
+  const int lin[8] = {lx0 + ly0 + lz0, lx1 + ly0 + lz0, lx0 + ly1 + lz0, lx1 + ly1 + lz0,
+                      lx0 + ly0 + lz1, lx1 + ly0 + lz1, lx0 + ly1 + lz1, lx1 + ly1 + lz1};
+#pragma unroll
+  for (int k = 0; k < 8; k++) {
+    // clamp the address so the load is unconditional (and therefore batched); select afterwards
+    const uint2 v = vol.voxels[(size_t)(p[k] >= 0 ? p[k] : 0) + lin[k]];
+    t[k] = (p[k] >= 0) ? v : make_uint2(kEmptyVoxelLo, kEmptyVoxelHi);
+  }
+}
+
+__device__ __forceinline__ float trilinear_sdf(const uint2 t[8], float cx, float cy, float cz) {
+  float s[8];
+#pragma unroll
+  for (int k = 0; k < 8; k++) s[k] = (float)(short)(t[k].x & 0xffffu);
+  float res1 = (1.0f - cx) * s[0] + cx * s[1];
+  res1 = (1.0f - cy) * res1 + cy * ((1.0f - cx) * s[2] + cx * s[3]);
+  float res2 = (1.0f - cx) * s[4] + cx * s[5];
+  res2 = (1.0f - cy) * res2 + cy * ((1.0f - cx) * s[6] + cx * s[7]);
+  return ((1.0f - cz) * res1 + cz * res2) / 32767.0f;
+}
+
 __device__ __forceinline__ float read_sdf_interp(const VolumeRef &vol, const Vec3 &pt, bool &found, IndexCache &c) {
-  float res1, res2, v1, v2;
   const float fx = floorf(pt.x), fy = floorf(pt.y), fz = floorf(pt.z);
   const int x = (int)fx, y = (int)fy, z = (int)fz;
   const float cx = pt.x - fx, cy = pt.y - fy, cz = pt.z - fz;
-  v1 = rd_sdf(vol, x, y, z, found, c); v2 = rd_sdf(vol, x + 1, y, z, found, c);
-  res1 = (1.0f - cx) * v1 + cx * v2;
-  v1 = rd_sdf(vol, x, y + 1, z, found, c); v2 = rd_sdf(vol, x + 1, y + 1, z, found, c);
-  res1 = (1.0f - cy) * res1 + cy * ((1.0f - cx) * v1 + cx * v2);
-  v1 = rd_sdf(vol, x, y, z + 1, found, c); v2 = rd_sdf(vol, x + 1, y, z + 1, found, c);
-  res2 = (1.0f - cx) * v1 + cx * v2;
-  v1 = rd_sdf(vol, x, y + 1, z + 1, found, c); v2 = rd_sdf(vol, x + 1, y + 1, z + 1, found, c);
-  res2 = (1.0f - cy) * res2 + cy * ((1.0f - cx) * v1 + cx * v2);
+  uint2 t[8];
+  gather_taps(vol, x, y, z, c, t);
   found = true;
-  return ((1.0f - cz) * res1 + cz * res2) / 32767.0f;
+  return trilinear_sdf(t, cx, cy, cz);
 }
 
 __device__ __forceinline__ Vec4 read_colour_interp(const VolumeRef &vol, const Vec3 &pt, IndexCache &c) {
@@ -293,11 +379,12 @@ __device__ __forceinline__ Vec4 read_colour_interp(const VolumeRef &vol, const V
   const int x = (int)fx, y = (int)fy, z = (int)fz;
   const float cx = pt.x - fx, cy = pt.y - fy, cz = pt.z - fz;
   float rx = 0.0f, ry = 0.0f, rz = 0.0f;
-  bool found;
+  uint2 t[8];
+  gather_taps(vol, x, y, z, c, t);
 #pragma unroll
   for (int k = 0; k < 8; k++) {
     const int ox = k & 1, oy = (k >> 1) & 1, oz = (k >> 2) & 1;
-    const uint2 v = read_voxel(vol, x + ox, y + oy, z + oz, found, c);
+    const uint2 v = t[k];
     const float wx = ox ? cx : (1.0f - cx), wy = oy ? cy : (1.0f - cy), wz = oz ? cz : (1.0f - cz);
     const float w = wx * wy * wz;
     rx += w * (float)(v.x >> 24);
@@ -372,9 +459,12 @@ struct RenderParams {
   uchar4 *out_rgba;
   float *out_float;
   int type;  // dslam_image_type, or -1: raycast only
+  unsigned long long *dbg_waves;  // diagnostics only (env DSLAM_DBG_WAVETIME=<file>): per wave {cycles, max iterations}
+  int dbg_max_iter, dbg_flags;  // diagnostics only (env DSLAM_DBG_MAX_ITER / DSLAM_DBG_FLAGS); defaults never trigger
 };
 
-__device__ __forceinline__ bool cast_ray(Vec4 &out, int x, int y, const RenderParams &p, const float2 minmax) {
+__device__ __forceinline__ bool cast_ray(Vec4 &out, int x, int y, const RenderParams &p, const float2 minmax,
+                                         int &iters_out) {
   Vec4 pc;
   Vec3 ps, pe, dir, res;
   bool hash_found;
@@ -403,7 +493,9 @@ __device__ __forceinline__ bool cast_ray(Vec4 &out, int x, int y, const RenderPa
   dir.x *= dn; dir.y *= dn; dir.z *= dn;
   res = ps;
   IndexCache cache = {0x7fffffff, 0x7fffffff, 0x7fffffff, -1};
+  int iter = 0;
   while (total < total_max) {
+    ++iter;
     sdf = read_sdf_uninterp(p.vol, res, hash_found, cache);
     if (!hash_found) {
       step = (float)kBlock;
@@ -415,6 +507,7 @@ __device__ __forceinline__ bool cast_ray(Vec4 &out, int x, int y, const RenderPa
     res.x += step * dir.x; res.y += step * dir.y; res.z += step * dir.z;
     total += step;
   }
+  iters_out = iter;
   bool pt_found;
   if (sdf <= 0.0f) {
     step = sdf * step_scale;
@@ -430,16 +523,31 @@ __device__ __forceinline__ bool cast_ray(Vec4 &out, int x, int y, const RenderPa
   return pt_found;
 }
 
-__global__ __launch_bounds__(256) void k_render(RenderParams p) {
-  // 16x16 pixel tile per workgroup, 8x8 per wavefront
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int x = blockIdx.x * 16 + (wave & 1) * 8 + (lane & 7);
-  const int y = blockIdx.y * 16 + (wave >> 1) * 8 + (lane >> 3);
+template <int WAVES>
+__global__ __launch_bounds__(WAVES * 64) void k_render(RenderParams p) {
+  // one wavefront = one workgroup = an 8x8 pixel tile = exactly one cell of the 1/8-resolution range image.
+  // Single-wave workgroups let the dispatcher backfill a SIMD the moment a short tile finishes (ray lengths vary
+  // by 10x between tiles), instead of holding 4 waves until the slowest of a 16x16 tile is done.
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int x = (WAVES == 4) ? blockIdx.x * 16 + (wave & 1) * 8 + (lane & 7) : blockIdx.x * 8 + (lane & 7);
+  const int y = (WAVES == 4) ? blockIdx.y * 16 + (wave >> 1) * 8 + (lane >> 3) : blockIdx.y * 8 + (lane >> 3);
   if (x >= p.W || y >= p.H) return;
   const int loc = x + y * p.W;
   const int loc2 = (int)floorf((float)x / 8.0f) + (int)floorf((float)y / 8.0f) * p.W;
   Vec4 pr;
-  cast_ray(pr, x, y, p, p.range[loc2]);
+  int iters = 0;
+  const unsigned long long t_start = p.dbg_waves ? __builtin_amdgcn_s_memtime() : 0ull;
+  cast_ray(pr, x, y, p, p.range[loc2], iters);
+  if (p.dbg_waves) {  // diagnostic build path: never taken in normal runs
+    const unsigned long long dt = __builtin_amdgcn_s_memtime() - t_start;
+    int mx = iters;
+    for (int d = 32; d > 0; d >>= 1) { const int o = __shfl_xor(mx, d, 64); mx = mx > o ? mx : o; }
+    if (lane == 0) {
+      const int wid = (blockIdx.y * gridDim.x + blockIdx.x) * WAVES + wave;
+      p.dbg_waves[2 * wid] = dt;
+      p.dbg_waves[2 * wid + 1] = (unsigned long long)mx;
+    }
+  }
   p.raycast[loc] = make_float4(pr.x, pr.y, pr.z, pr.w);
   if (p.type < 0) return;
 
@@ -485,7 +593,7 @@ __global__ __launch_bounds__(256) void k_render(RenderParams p) {
 
 static int fill_render_params(RenderParams &rp, const dslam_scene *s, dslam_render_state *r, const float *M,
                               const float *intr, int type) {
-  rp.vol.hash = s->hash; rp.vol.voxels = s->voxels; rp.vol.mask = (unsigned)(s->p.num_buckets - 1);
+  rp.vol.hash = s->hash; rp.vol.bucket_bits = s->bucket_bits; rp.vol.voxels = s->voxels; rp.vol.mask = (unsigned)(s->p.num_buckets - 1);
   rp.vol.num_buckets = s->p.num_buckets;
   memcpy(rp.M.m, M, 64);
   if (!invert_matrix(M, rp.invM.m)) { set_last_error("pose matrix is singular"); return DSLAM_ERR_INVALID; }
@@ -494,6 +602,12 @@ static int fill_render_params(RenderParams &rp, const dslam_scene *s, dslam_rend
   rp.W = r->w; rp.H = r->h;
   rp.range = r->range; rp.raycast = r->raycast; rp.out_rgba = r->image_rgba; rp.out_float = r->image_float;
   rp.type = type;
+  static const int dbg_iter = getenv("DSLAM_DBG_MAX_ITER") ? atoi(getenv("DSLAM_DBG_MAX_ITER")) : 0x7fffffff;
+  static const int dbg_flags = getenv("DSLAM_DBG_FLAGS") ? atoi(getenv("DSLAM_DBG_FLAGS")) : 0;
+  rp.dbg_max_iter = dbg_iter; rp.dbg_flags = dbg_flags; rp.dbg_waves = nullptr;
+  // measured on MI355X: the bucket-occupancy bitmap does not pay in the ray march (125 vs 132 us: an extra load on
+  // every hit outweighs the cheaper miss), so it is off unless DSLAM_DBG_FLAGS bit 2 asks for it
+  if (!(dbg_flags & 4)) rp.vol.bucket_bits = nullptr;
   return DSLAM_OK;
 }
 
@@ -502,8 +616,26 @@ int launch_render(dslam_engine *e, const dslam_scene *s, dslam_render_state *r, 
   RenderParams rp;
   int rc = fill_render_params(rp, s, r, M, intr, type);
   if (rc) return rc;
-  hipLaunchKernelGGL(k_render, dim3((r->w + 15) / 16, (r->h + 15) / 16), dim3(256), 0, e->stream, rp);
+  static const char *dbg_file = getenv("DSLAM_DBG_WAVETIME");
+  static int dbg_calls = 0;
+  const int n_waves = ((r->w + 7) / 8) * ((r->h + 7) / 8);
+  unsigned long long *dbg_host = nullptr;
+  if (dbg_file && ++dbg_calls == 30) {  // one snapshot, well into the run
+    DSLAM_HIP(hipHostMalloc((void **)&dbg_host, (size_t)n_waves * 16, hipHostMallocDefault));
+    memset(dbg_host, 0, (size_t)n_waves * 16);
+    rp.dbg_waves = dbg_host;
+  }
+  if (rp.dbg_flags & 8)
+    hipLaunchKernelGGL(k_render<4>, dim3((r->w + 15) / 16, (r->h + 15) / 16), dim3(256), 0, e->stream, rp);
+  else
+    hipLaunchKernelGGL(k_render<1>, dim3((r->w + 7) / 8, (r->h + 7) / 8), dim3(64), 0, e->stream, rp);
   DSLAM_HIP(hipGetLastError());
+  if (dbg_host) {
+    DSLAM_HIP(hipStreamSynchronize(e->stream));
+    FILE *f = fopen(dbg_file, "wb");
+    if (f) { fwrite(dbg_host, 16, n_waves, f); fclose(f); }
+    (void)hipHostFree(dbg_host);
+  }
   return DSLAM_OK;
 }
 
@@ -564,7 +696,7 @@ int launch_icp_maps(dslam_engine *e, const dslam_scene *s, dslam_render_state *r
   int rc = fill_render_params(rp, s, r, M, intr, -1);
   if (rc) return rc;
   const dim3 grid((r->w + 15) / 16, (r->h + 15) / 16);
-  hipLaunchKernelGGL(k_render, grid, dim3(256), 0, e->stream, rp);
+  hipLaunchKernelGGL(k_render<1>, dim3((r->w + 7) / 8, (r->h + 7) / 8), dim3(64), 0, e->stream, rp);
   hipLaunchKernelGGL(k_icp_maps, grid, dim3(256), 0, e->stream, r->raycast, r->w, r->h, s->p.voxel_size, -rp.invM.m[8],
                      -rp.invM.m[9], -rp.invM.m[10], r->icp_points, r->icp_normals);
   DSLAM_HIP(hipGetLastError());

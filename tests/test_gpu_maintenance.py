@@ -41,6 +41,14 @@ def _run_pair(gpu, oracle, pkg, wl, params, n_frames, decay=None, slide=None, sw
             assert (st0["last_swapped_in"], st0["last_swapped_out"]) == (st1["last_swapped_in"], st1["last_swapped_out"])
         last = snaps
     util.check_invariants(last["gpu"], objs["gpu"][1].params)
+    # raycast the maintained maps too: exercises the engine's bucket-occupancy bitmap after releases
+    rgba, mm, M = wl.frame(n_frames - 1)
+    imgs = {}
+    for name, (api, s, rs, v) in objs.items():
+        rs_free = api.create_render_state(s, wl.W, wl.H)
+        imgs[name] = api.get_image(s, rs_free, M, wl.intr, pkg.IMAGE_DEPTH)
+    assert np.array_equal(imgs["gpu"] > 0, imgs["oracle"] > 0), "raycast hit mask differs after maintenance"
+    assert np.abs(imgs["gpu"] - imgs["oracle"]).max() <= 1e-4
     return objs, last
 
 

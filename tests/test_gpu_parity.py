@@ -86,7 +86,8 @@ def test_render_modes(pkg, synth, gpu, oracle, image_type):
         out[name] = (img, api.download_visible_ids(rs), api.download_range_image(rs), api.download_raycast_result(rs))
     (i0, v0, r0, c0), (i1, v1, r1, c1) = out["gpu"], out["oracle"]
     assert np.array_equal(v0, v1), "FindVisibleBlocks list differs"
-    assert np.array_equal(r0, r1), "expected-depth range image differs"
+    ch, cw = (rs.height + 7) // 8, (rs.width + 7) // 8  # the cells castRay reads; the rest is never consumed
+    assert np.array_equal(r0[:ch, :cw], r1[:ch, :cw]), "expected-depth range image differs"
     assert np.array_equal(c0[..., 3], c1[..., 3]), "raycast hit mask differs"
     assert np.abs(c0 - c1).max() <= 1e-3  # voxel units
     if t == pkg.IMAGE_DEPTH:
