@@ -86,23 +86,47 @@ __global__ __launch_bounds__(256) void k_convert_depth(const short *__restrict__
   }
 }
 
-int launch_view_convert(dslam_engine *e, dslam_view *v, const void *rgba_dev, const void *depth_dev, float a, float b) {
+// UpdateView on resident data costs nothing here: the view records where the frame lives; the float depth image is
+// derived by the next consumer (the allocation pass folds it into its preparation kernel).
+int launch_view_convert(dslam_engine *, dslam_view *v, const void *rgba_dev, const void *depth_dev, float a, float b) {
+  v->rgba_src = reinterpret_cast<const uchar4 *>(rgba_dev);
+  v->raw_src = reinterpret_cast<const short *>(depth_dev);
+  v->affine_a = a; v->affine_b = b;
+  v->depth_dirty = true;
+  return DSLAM_OK;
+}
+
+int ensure_view_depth(dslam_engine *e, const dslam_view *v) {
+  if (!v->depth_dirty) return DSLAM_OK;
   const int n = v->w_d * v->h_d;
-  if (rgba_dev != v->rgba)
-    DSLAM_HIP(hipMemcpyAsync(v->rgba, rgba_dev, (size_t)v->w_rgb * v->h_rgb * 4, hipMemcpyDeviceToDevice, e->stream));
-  hipLaunchKernelGGL(k_convert_depth, dim3((n + 255) / 256), dim3(256), 0, e->stream,
-                     reinterpret_cast<const short *>(depth_dev), v->depth, n, a, b);
+  hipLaunchKernelGGL(k_convert_depth, dim3((n + 255) / 256), dim3(256), 0, e->stream, v->raw_src, v->depth, n,
+                     v->affine_a, v->affine_b);
   DSLAM_HIP(hipGetLastError());
+  v->depth_dirty = false;
   return DSLAM_OK;
 }
 
 // ---------------------------------------------------------------------------------------------------------
 // AllocateSceneFromDepth
 // ---------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_set_type3(const int *__restrict__ visible_ids, const RenderCounters *rc,
-                                                   unsigned char *vis_type) {
+// One preparation kernel for the allocation pass (four independent jobs, one launch): clear the order keys +
+// allocType scratch, zero the commit tile counters, re-arm the previous visible list as type 3, and -- if the view
+// was updated since -- derive the float depth image from the raw millimetre image.
+__global__ __launch_bounds__(256) void k_alloc_prep(uint4 *scratch16, int scratch_n16, int *tile_counts, int n_counts,
+                                                    const int *__restrict__ visible_ids, const RenderCounters *rc,
+                                                    unsigned char *vis_type, const short *__restrict__ raw,
+                                                    float *__restrict__ depth, int npix, float a, float b) {
+  const int tid = blockIdx.x * blockDim.x + threadIdx.x, stride = gridDim.x * blockDim.x;
+  const uint4 z = make_uint4(0, 0, 0, 0);
+  for (int i = tid; i < scratch_n16; i += stride) scratch16[i] = z;
+  for (int i = tid; i < n_counts; i += stride) tile_counts[i] = 0;
   const int n = rc->no_visible;
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) vis_type[visible_ids[i]] = 3;
+  for (int i = tid; i < n; i += stride) vis_type[visible_ids[i]] = 3;
+  if (raw)
+    for (int i = tid; i < npix; i += stride) {
+      const int d = raw[i];
+      depth[i] = (d <= 0 || d > 32000) ? -1.0f : (float)d * a + b;
+    }
 }
 
 struct MarkParams {
@@ -120,6 +144,7 @@ struct MarkParams {
   unsigned char *vis_type;
   int step_cap;
   SceneCounters *cnt;
+  int *tile_counts;  // per-tile (type 1, type 2) request counts, accumulated by the phase-1 winners
 };
 
 // buildHashAllocAndVisibleTypePP.  PHASE 0: found entries mark visibility, misses race for the slot's order
@@ -182,6 +207,7 @@ __global__ __launch_bounds__(256) void k_mark(MarkParams p) {
         if (PHASE == 0) {
           atomicMax(&p.keys[h], key);
         } else if (p.keys[h] == key) {
+          atomicAdd(&p.tile_counts[(h / kTileEntries) * 2 + (excess ? 1 : 0)], 1);  // commit pass 1, for free
           p.alloc_type[h] = excess ? 2 : 1;
           if (!excess) p.vis_type[h] = 1;
           p.coords[h] = make_short4(bx, by, bz, 1);
@@ -194,22 +220,6 @@ __global__ __launch_bounds__(256) void k_mark(MarkParams p) {
 
 // ---- ordered compaction building blocks -------------------------------------------------------------------
 // A tile = 1024 consecutive entries handled by one 256-thread workgroup, 4 consecutive entries per thread.
-
-__global__ __launch_bounds__(256) void k_commit_count(const unsigned char *__restrict__ alloc_type, int n_entries,
-                                                      int *__restrict__ tile_counts) {
-  __shared__ int red[2][4];
-  const int t0 = blockIdx.x * kTileEntries + threadIdx.x * 4;
-  int c1 = 0, c2 = 0;
-  if (t0 < n_entries) {  // n_entries is a multiple of 4 (checked on the host)
-    const uchar4 a = *reinterpret_cast<const uchar4 *>(alloc_type + t0);
-    c1 = (a.x == 1) + (a.y == 1) + (a.z == 1) + (a.w == 1);
-    c2 = (a.x == 2) + (a.y == 2) + (a.z == 2) + (a.w == 2);
-  }
-  int t1, t2;
-  block_excl_scan<4>(c1, red[0], t1);
-  block_excl_scan<4>(c2, red[1], t2);
-  if (threadIdx.x == 0) { tile_counts[blockIdx.x * 2] = t1; tile_counts[blockIdx.x * 2 + 1] = t2; }
-}
 
 __global__ __launch_bounds__(1024) void k_commit_scan(const int *tile_counts, int *tile_offsets, int n_tiles,
                                                       SceneCounters *cnt) {
@@ -408,7 +418,7 @@ int launch_allocate(dslam_engine *e, dslam_scene *s, const dslam_view *v, dslam_
                     const float *intr, int only_update_visible_list) {
   const int W = v->w_d, H = v->h_d, N = s->n_entries;
   DSLAM_REQUIRE(r->n_entries == N, "render state was created for a different scene size");
-  DSLAM_REQUIRE((N & 3) == 0, "num_buckets + num_excess must be a multiple of 4");
+  DSLAM_REQUIRE((N & 15) == 0, "num_buckets + num_excess must be a multiple of 16");
   int rc = ensure_scratch(e, N, s->p.num_local_blocks);
   if (rc) return rc;
 
@@ -423,7 +433,7 @@ int launch_allocate(dslam_engine *e, dslam_scene *s, const dslam_view *v, dslam_
   // count, so the single memset below clears exactly both
   e->alloc_type = reinterpret_cast<unsigned char *>(e->order_keys) + (size_t)N * 4;
   mp.keys = e->order_keys; mp.alloc_type = e->alloc_type; mp.coords = e->block_coords; mp.vis_type = r->visible_type;
-  mp.cnt = s->counters;
+  mp.cnt = s->counters; mp.tile_counts = e->tile_counts;
   // steps along the +-mu segment: ceil(2 * |segment| in blocks) = ceil(mu / (2 * voxel_size)) for a rigid pose
   const int step_bound = (int)ceilf(s->p.mu / (2.0f * s->p.voxel_size)) + 2;
   mp.step_cap = ceil_pow2(step_bound + 1);
@@ -433,13 +443,15 @@ int launch_allocate(dslam_engine *e, dslam_scene *s, const dslam_view *v, dslam_
   }
 
   const int n_tiles = num_tiles(N);
-  DSLAM_HIP(hipMemsetAsync(e->order_keys, 0, (size_t)N * 5, e->stream));
-  hipLaunchKernelGGL(k_set_type3, dim3(256), dim3(256), 0, e->stream, r->visible_ids, r->counters, r->visible_type);
+  // order keys (4N bytes) + allocType (N bytes) = 5N bytes, N % 16 checked below -> whole uint4 stores
+  hipLaunchKernelGGL(k_alloc_prep, dim3(1024), dim3(256), 0, e->stream, reinterpret_cast<uint4 *>(e->order_keys),
+                     (int)(((size_t)N * 5) / 16), e->tile_counts, n_tiles * 2, r->visible_ids, r->counters, r->visible_type,
+                     v->depth_dirty ? v->raw_src : (const short *)nullptr, v->depth, W * H, v->affine_a, v->affine_b);
+  v->depth_dirty = false;
   const int pix_blocks = (W * H + 255) / 256;
   hipLaunchKernelGGL(k_mark<0>, dim3(pix_blocks), dim3(256), 0, e->stream, mp);
   hipLaunchKernelGGL(k_mark<1>, dim3(pix_blocks), dim3(256), 0, e->stream, mp);
   if (!only_update_visible_list) {
-    hipLaunchKernelGGL(k_commit_count, dim3(n_tiles), dim3(256), 0, e->stream, e->alloc_type, N, e->tile_counts);
     hipLaunchKernelGGL(k_commit_scan, dim3(1), dim3(1024), 0, e->stream, e->tile_counts, e->tile_offsets, n_tiles,
                        s->counters);
     hipLaunchKernelGGL(k_commit_apply, dim3(n_tiles), dim3(256), 0, e->stream, e->alloc_type, e->block_coords, N,
@@ -481,32 +493,19 @@ __global__ __launch_bounds__(256) void k_clear_ring_bit(unsigned long long *mask
     masks[((size_t)slot * 2 + ring) * words + (bit >> 6)] &= m;
 }
 
-__global__ __launch_bounds__(256) void k_push_list(const int *__restrict__ visible_ids, const RenderCounters *rc,
-                                                   const HashEntry *__restrict__ hash, unsigned long long *masks,
-                                                   int *last_seen, int words, int ring, int bit, int frame) {
-  const int n = rc->no_visible;
-  const unsigned long long m = 1ull << (bit & 63);
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-    const int ptr = hash[visible_ids[i]].ptr;
-    if (ptr < 0) continue;
-    masks[((size_t)ptr * 2 + ring) * words + (bit >> 6)] |= m;  // one visible entry per slot: no race
-    last_seen[ptr] = frame;
-  }
-}
-
-int launch_push_visible_list(dslam_engine *e, dslam_scene *s, const dslam_render_state *r, int q) {
+// host side of queueing a visible list on ring q: ring bookkeeping (+ the rare drop of the oldest list of a full
+// ring); the bit itself is set by the integrate kernel for every visible block it visits
+int prepare_push_visible_list(dslam_engine *e, dslam_scene *s, int q, int *bit_out, int *frame_out) {
   const int bits = 64 * s->history_words;
   if (s->ring_next[q] - s->ring_head[q] == bits) {  // full ring: drop the oldest list, release nothing
     hipLaunchKernelGGL(k_clear_ring_bit, dim3(512), dim3(256), 0, e->stream, s->masks, s->p.num_local_blocks,
                        s->history_words, q, s->ring_head[q] % bits);
+    DSLAM_HIP(hipGetLastError());
     s->ring_head[q]++;
     if (s->decay_cursor[q] < s->ring_head[q]) s->decay_cursor[q] = s->ring_head[q];
   }
-  const int bit = (s->ring_next[q]++) % bits;
-  const int frame = s->frame_counter++;
-  hipLaunchKernelGGL(k_push_list, dim3(256), dim3(256), 0, e->stream, r->visible_ids, r->counters, s->hash, s->masks,
-                     s->last_seen, s->history_words, q, bit, frame);
-  DSLAM_HIP(hipGetLastError());
+  *bit_out = (s->ring_next[q]++) % bits;
+  *frame_out = s->frame_counter++;
   return DSLAM_OK;
 }
 

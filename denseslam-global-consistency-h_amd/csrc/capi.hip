@@ -149,6 +149,7 @@ int dslam_engine_destroy(dslam_engine *e) {
   if (e->staging_dev) (void)hipFree(e->staging_dev);
   if (e->staging_host) (void)hipHostFree(e->staging_host);
   if (e->pinned) (void)hipHostFree(e->pinned);
+  if (e->timer_counts_dev) (void)hipFree(e->timer_counts_dev);
   for (auto ev : e->ev_pool) (void)hipEventDestroy(ev);
   (void)hipStreamDestroy(e->stream);
   (void)hipStreamDestroy(e->copy_stream);
@@ -181,10 +182,10 @@ int dslam_scene_create(dslam_engine *e, const dslam_scene_params *p, void *ext_v
   if (s->p.num_excess <= 0) s->p.num_excess = DSLAM_DEFAULT_EXCESS_LIST_SIZE;
   if (s->p.history_words <= 0) s->p.history_words = 4;
   s->history_words = s->p.history_words;
-  if ((s->p.num_buckets & (s->p.num_buckets - 1)) || ((s->p.num_buckets + s->p.num_excess) & 3) ||
+  if ((s->p.num_buckets & (s->p.num_buckets - 1)) || ((s->p.num_buckets + s->p.num_excess) & 15) ||
       s->p.max_w < 1 || s->p.max_w > 255 || !(s->p.voxel_size > 0) || !(s->p.mu > 0)) {
     delete s;
-    set_last_error("invalid scene parameters (buckets must be a power of two, entries a multiple of 4, 1<=max_w<=255)");
+    set_last_error("invalid scene parameters (buckets must be a power of two, entries a multiple of 16, 1<=max_w<=255)");
     return DSLAM_ERR_INVALID;
   }
   s->n_entries = s->p.num_buckets + s->p.num_excess;
@@ -309,7 +310,9 @@ int dslam_view_create(dslam_engine *e, int w_rgb, int h_rgb, int w_d, int h_d, d
   DSLAM_HIP(hipMalloc(&v->rgba, (size_t)w_rgb * h_rgb * sizeof(uchar4)));
   DSLAM_HIP(hipMalloc(&v->depth, (size_t)w_d * h_d * sizeof(float)));
   DSLAM_HIP(hipMalloc(&v->raw_depth, (size_t)w_d * h_d * sizeof(short)));
+  v->rgba_src = v->rgba; v->raw_src = v->raw_depth;
   DSLAM_HIP(hipMemsetAsync(v->rgba, 0, (size_t)w_rgb * h_rgb * sizeof(uchar4), e->stream));
+  DSLAM_HIP(hipMemsetAsync(v->depth, 0, (size_t)w_d * h_d * sizeof(float), e->stream));
   DSLAM_HIP(hipMemsetAsync(v->raw_depth, 0, (size_t)w_d * h_d * sizeof(short), e->stream));
   DSLAM_HIP(hipStreamSynchronize(e->stream));
   *out = v;
@@ -394,8 +397,7 @@ int dslam_process_frame(dslam_engine *e, dslam_scene *s, const dslam_view *v, ds
   int rc = check_frame_args(e, s, v, r, M_d, intr_d);
   if (rc) return rc;
   if ((rc = launch_allocate(e, s, v, r, M_d, intr_d, only_visible))) return rc;
-  if ((rc = launch_integrate(e, s, v, r, M_d, intr_d, M_rgb, intr_rgb, false))) return rc;
-  if ((rc = launch_push_visible_list(e, s, r, is_defusion ? 1 : 0))) return rc;
+  if ((rc = launch_integrate(e, s, v, r, M_d, intr_d, M_rgb, intr_rgb, false, is_defusion ? 1 : 0))) return rc;
   if (s->p.use_swapping) {
     if ((rc = launch_swap_in(e, s, r))) return rc;
     if ((rc = launch_swap_out(e, s, r, false))) return rc;
@@ -617,6 +619,8 @@ int dslam_download_raycast_result(dslam_engine *e, const dslam_render_state *r, 
 }
 int dslam_download_view_depth(dslam_engine *e, const dslam_view *v, float *out) {
   DSLAM_REQUIRE(e && v && out, "null argument");
+  int rc = ensure_view_depth(e, v);
+  if (rc) return rc;
   return d2h(e, out, v->depth, (size_t)v->w_d * v->h_d * sizeof(float));
 }
 int dslam_download_swap_states(dslam_engine *e, const dslam_scene *s, uint8_t *out) {
@@ -724,6 +728,7 @@ int dslam_kernel_timer_enable(dslam_engine *e, int enable) {
   if (enable && e->ev_pool.empty()) {
     const size_t n = 2 * 8192;  // up to 8192 timed launches between reads
     DSLAM_REQUIRE(e->pinned_bytes >= 256 + 8192 * sizeof(int), "pinned mirror too small");
+    DSLAM_HIP(hipMalloc(&e->timer_counts_dev, 8192 * sizeof(int)));
     e->ev_pool.resize(n);
     for (size_t i = 0; i < n; i++) DSLAM_HIP(hipEventCreate(&e->ev_pool[i]));
   }
@@ -736,7 +741,11 @@ int dslam_kernel_timer_enable(dslam_engine *e, int enable) {
 int dslam_kernel_timer_read(dslam_engine *e, double *out_ms, int64_t *out_launches, int64_t *out_blocks) {
   DSLAM_REQUIRE(e, "null engine");
   DSLAM_HIP(hipStreamSynchronize(e->stream));
-  const int *counts = reinterpret_cast<int *>(e->pinned) + 64;
+  int *counts = reinterpret_cast<int *>(e->pinned) + 64;
+  if (e->ev_used > 0) {
+    DSLAM_HIP(hipMemcpyAsync(counts, e->timer_counts_dev, (e->ev_used / 2) * sizeof(int), hipMemcpyDeviceToHost, e->stream));
+    DSLAM_HIP(hipStreamSynchronize(e->stream));
+  }
   for (size_t i = 0; i + 1 < e->ev_used; i += 2) {
     float ms = 0;
     DSLAM_HIP(hipEventElapsedTime(&ms, e->ev_pool[i], e->ev_pool[i + 1]));

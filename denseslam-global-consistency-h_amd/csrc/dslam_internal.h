@@ -64,7 +64,7 @@ struct dslam_engine {
   double timer_ms = 0;
   long long timer_launches = 0;
   long long timer_blocks = 0;
-  std::vector<const dslam_render_state *> timer_rs;
+  int *timer_counts_dev = nullptr;    // visible-block count of each timed launch (written by the kernel)
   int sm_count = 256;
 };
 
@@ -118,9 +118,14 @@ struct dslam_render_state {
 struct dslam_view {
   dslam_engine *engine = nullptr;
   int w_rgb = 0, h_rgb = 0, w_d = 0, h_d = 0;
-  uchar4 *rgba = nullptr;
+  uchar4 *rgba = nullptr;       // own buffers (host uploads land here)
   float *depth = nullptr;
   short *raw_depth = nullptr;
+  // what the kernels read: own buffers, or the caller's resident frame (dslam_view_update_device: no copy)
+  const uchar4 *rgba_src = nullptr;
+  const short *raw_src = nullptr;
+  float affine_a = 0.001f, affine_b = 0.0f;
+  mutable bool depth_dirty = false;  // float depth not yet derived from raw_src (done by the next consumer)
   double timestamp = 0;
 };
 
@@ -131,10 +136,12 @@ int launch_rebuild_bucket_bits(dslam_engine *e, dslam_scene *s);
 int launch_view_convert(dslam_engine *e, dslam_view *v, const void *rgba_dev, const void *depth_dev, float a, float b);
 int launch_allocate(dslam_engine *e, dslam_scene *s, const dslam_view *v, dslam_render_state *r, const float *M_d,
                     const float *intr, int only_update_visible_list);
+// push_ring >= 0: also queue the frame's visible list on that ring (fused into the integrate kernel)
 int launch_integrate(dslam_engine *e, dslam_scene *s, const dslam_view *v, const dslam_render_state *r,
                      const float *M_d, const float *intr_d, const float *M_rgb, const float *intr_rgb,
-                     bool deintegrate);
-int launch_push_visible_list(dslam_engine *e, dslam_scene *s, const dslam_render_state *r, int which);
+                     bool deintegrate, int push_ring = -1);
+int ensure_view_depth(dslam_engine *e, const dslam_view *v);
+int prepare_push_visible_list(dslam_engine *e, dslam_scene *s, int q, int *bit_out, int *frame_out);
 int launch_find_visible(dslam_engine *e, const dslam_scene *s, dslam_render_state *r, const float *M,
                         const float *intr);
 int launch_count_visible(dslam_engine *e, const dslam_scene *s, const dslam_render_state *r, int min_id, int max_id,

@@ -39,6 +39,11 @@ struct IntegrateParams {
   float max_distance;
   int shard, num_shards, chunk_blocks;
   int shard_first, shard_count;
+  // visible-list ring push fused into this kernel (push_words == 0: off)
+  unsigned long long *masks;
+  int *last_seen;
+  int push_words, push_ring, push_bit, push_frame;
+  int *timer_slot;  // bench instrumentation: where to record this launch's visible-block count (or null)
 };
 
 // a / b for a divisor whose correctly rounded reciprocal y = RN(1/b) is known: q = RN(a*y), r = a - b*q (exact, FMA),
@@ -181,6 +186,7 @@ __global__ __launch_bounds__(256) void k_integrate(IntegrateParams p) {
   const int wave = __builtin_amdgcn_readfirstlane((int)((blockIdx.x * 256 + threadIdx.x) >> 6));
   const int n_waves = gridDim.x * 4;
   const int nvis = p.rc->no_visible;
+  if (p.timer_slot && blockIdx.x == 0 && threadIdx.x == 0) *p.timer_slot = nvis;
   int G = (nvis + n_waves - 1) / n_waves;
   G = G < 1 ? 1 : (G > kMaxGroup ? kMaxGroup : G);
 
@@ -197,6 +203,10 @@ __global__ __launch_bounds__(256) void k_integrate(IntegrateParams p) {
     for (int k = 0; k < G; k++) {
       const int ptr = __builtin_amdgcn_readlane(e_ptr, k);
       if (ptr < 0) continue;
+      if (p.push_words && lane == 0) {  // queue this block on the visible-list ring (one wave per block: no race)
+        p.masks[((size_t)ptr * 2 + p.push_ring) * p.push_words + (p.push_bit >> 6)] |= 1ull << (p.push_bit & 63);
+        p.last_seen[ptr] = p.push_frame;
+      }
       if (p.num_shards > 1 && ((ptr / p.chunk_blocks) % p.num_shards) != p.shard) continue;
       if (p.shard_count >= 0 && (ptr < p.shard_first || ptr >= p.shard_first + p.shard_count)) continue;
       const int gx = __builtin_amdgcn_readlane(e_px, k) * kBlock;
@@ -248,7 +258,7 @@ static void fill_params(IntegrateParams &ip, dslam_engine *e, dslam_scene *s, co
                         const float *intr_rgb) {
   ip.visible_ids = r->visible_ids; ip.rc = r->counters; ip.hash = s->hash;
   ip.voxels16 = reinterpret_cast<uint4 *>(s->voxels);
-  ip.depth = v->depth; ip.rgba = v->rgba;
+  ip.depth = v->depth; ip.rgba = v->rgba_src;
   ip.Wd = v->w_d; ip.Hd = v->h_d; ip.Wr = v->w_rgb; ip.Hr = v->h_rgb;
   memcpy(ip.M_d.m, M_d, 64);
   memcpy(ip.M_rgb.m, M_rgb ? M_rgb : M_d, 64);
@@ -269,20 +279,28 @@ constexpr int kIntegrateGrid = 2048;
 
 int launch_integrate(dslam_engine *e, dslam_scene *s, const dslam_view *v, const dslam_render_state *r,
                      const float *M_d, const float *intr_d, const float *M_rgb, const float *intr_rgb,
-                     bool deintegrate) {
+                     bool deintegrate, int push_ring) {
+  int rc = ensure_view_depth(e, v);
+  if (rc) return rc;
   IntegrateParams ip;
   fill_params(ip, e, s, v, r, M_d, intr_d, M_rgb, intr_rgb);
+  ip.masks = s->masks; ip.last_seen = s->last_seen; ip.push_words = 0; ip.push_ring = 0; ip.push_bit = 0; ip.push_frame = 0;
+  if (push_ring >= 0) {
+    if ((rc = prepare_push_visible_list(e, s, push_ring, &ip.push_bit, &ip.push_frame))) return rc;
+    ip.push_words = s->history_words; ip.push_ring = push_ring;
+  }
+  ip.timer_slot = nullptr;
   const bool timed = e->timer_enabled && e->ev_used + 2 <= e->ev_pool.size();
-  if (timed) DSLAM_HIP(hipEventRecord(e->ev_pool[e->ev_used], e->stream));
+  if (timed) {
+    ip.timer_slot = e->timer_counts_dev + (e->ev_used / 2);
+    DSLAM_HIP(hipEventRecord(e->ev_pool[e->ev_used], e->stream));
+  }
   if (deintegrate)
     hipLaunchKernelGGL(k_integrate<true>, dim3(kIntegrateGrid), dim3(256), 0, e->stream, ip);
   else
     hipLaunchKernelGGL(k_integrate<false>, dim3(kIntegrateGrid), dim3(256), 0, e->stream, ip);
   if (timed) {
     DSLAM_HIP(hipEventRecord(e->ev_pool[e->ev_used + 1], e->stream));
-    // visible-block count of this launch, for the algorithmic-bytes figure (4-byte async copy, outside the events)
-    int *slot = reinterpret_cast<int *>(e->pinned) + 64 + (e->ev_used / 2);
-    DSLAM_HIP(hipMemcpyAsync(slot, &r->counters->no_visible, sizeof(int), hipMemcpyDeviceToHost, e->stream));
     e->ev_used += 2;
   }
   DSLAM_HIP(hipGetLastError());

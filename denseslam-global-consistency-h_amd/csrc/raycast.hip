@@ -102,12 +102,6 @@ int launch_count_visible(dslam_engine *e, const dslam_scene *s, const dslam_rend
 // ---------------------------------------------------------------------------------------------------------
 // CreateExpectedDepths
 // ---------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_init_range(float2 *range, int n, RenderCounters *rc) {
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
-    range[i] = make_float2(kFarAway, kVeryClose);
-  if (blockIdx.x == 0 && threadIdx.x == 0) rc->render_tiles = 0;
-}
-
 struct ProjParams {
   Mat4 M;
   float fx, fy, cx, cy, voxel_size;
@@ -118,7 +112,10 @@ struct ProjParams {
 __global__ __launch_bounds__(256) void k_project_blocks(const int *__restrict__ ids, RenderCounters *rc,
                                                         const HashEntry *__restrict__ hash, ProjParams p,
                                                         int4 *__restrict__ boxes, float2 *__restrict__ zr_out,
-                                                        int *__restrict__ req_out) {
+                                                        int *__restrict__ req_out, float2 *range, int npix) {
+  // (independent job in the same launch) reset the range image to (FAR_AWAY, VERY_CLOSE)
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < npix; i += gridDim.x * blockDim.x)
+    range[i] = make_float2(kFarAway, kVeryClose);
   const int n = rc->no_visible;
   int local_tiles = 0;
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
@@ -197,6 +194,8 @@ __global__ __launch_bounds__(256) void k_fill_range_tiles(const RenderCounters *
                                                           float2 *range, int W, int tiles_x) {
   __shared__ int s_min[kRangeTile * kRangeTile], s_max[kRangeTile * kRangeTile];
   const int n = rc->no_visible;
+  // render_tiles was consumed by k_cap_render_tiles; re-arm it for the next CreateExpectedDepths (stream order)
+  if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) const_cast<RenderCounters *>(rc)->render_tiles = 0;
   if ((int)(blockIdx.y * 256) >= n) return;
   const int tx0 = (blockIdx.x % tiles_x) * kRangeTile, ty0 = (blockIdx.x / tiles_x) * kRangeTile;
   const int far_i = __float_as_int(kFarAway), close_i = __float_as_int(kVeryClose);
@@ -239,9 +238,8 @@ int launch_expected_depths(dslam_engine *e, const dslam_scene *s, dslam_render_s
   pp.fx = intr[0]; pp.fy = intr[1]; pp.cx = intr[2]; pp.cy = intr[3]; pp.voxel_size = s->p.voxel_size;
   pp.W = r->w; pp.H = r->h;
   const int npix = r->w * r->h;
-  hipLaunchKernelGGL(k_init_range, dim3((npix + 255) / 256), dim3(256), 0, e->stream, r->range, npix, r->counters);
   hipLaunchKernelGGL(k_project_blocks, dim3(512), dim3(256), 0, e->stream, r->visible_ids, r->counters, s->hash, pp,
-                     r->proj_boxes, r->proj_z, r->proj_req);
+                     r->proj_boxes, r->proj_z, r->proj_req, r->range, npix);
   hipLaunchKernelGGL(k_cap_render_tiles, dim3(1), dim3(64), 0, e->stream, r->counters, r->proj_req);
   // corner = the tiles covering ceil(W/8) x ceil(H/8) cells (clamped to the image); chunks sized for the pool
   const int cw = (r->w + 7) / 8, ch = (r->h + 7) / 8;

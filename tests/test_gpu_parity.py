@@ -149,7 +149,7 @@ def test_depth_weighting_parity(pkg, synth, gpu, oracle):
 
 def test_pool_exhaustion_matches_sequential_rule(pkg, synth, gpu, oracle):
     wl = synth.s_tiny()
-    for over in (dict(num_local_blocks=300), dict(num_excess=8, num_buckets=0x400), dict(num_local_blocks=200, num_excess=12, num_buckets=0x400)):
+    for over in (dict(num_local_blocks=300), dict(num_excess=16, num_buckets=0x400), dict(num_local_blocks=200, num_excess=16, num_buckets=0x400)):
         p = util.small_params(pkg, wl, **over)
         res = {}
         for name, api in _both(gpu, oracle):
