@@ -221,22 +221,9 @@ __global__ __launch_bounds__(256) void k_mark(MarkParams p) {
 // ---- ordered compaction building blocks -------------------------------------------------------------------
 // A tile = 1024 consecutive entries handled by one 256-thread workgroup, 4 consecutive entries per thread.
 
-__global__ __launch_bounds__(1024) void k_commit_scan(const int *tile_counts, int *tile_offsets, int n_tiles,
-                                                      SceneCounters *cnt) {
-  int totals[2];
-  scan_tiles<2>(tile_counts, tile_offsets, n_tiles, totals);
-  if (threadIdx.x == 0) {
-    cnt->base_free = cnt->last_free;
-    cnt->base_free_ex = cnt->last_free_ex;
-    cnt->commit_succ_vba = 0;
-    cnt->commit_succ_ex = 0;
-    cnt->commit_requests = totals[0] + totals[1];
-  }
-}
-
 __global__ __launch_bounds__(256) void k_commit_apply(const unsigned char *__restrict__ alloc_type,
                                                       const short4 *__restrict__ coords, int n_entries,
-                                                      const int *__restrict__ tile_offsets, HashEntry *hash,
+                                                      const int *__restrict__ tile_counts, HashEntry *hash,
                                                       int num_buckets, const int *__restrict__ alloc_list,
                                                       const int *__restrict__ excess_list, unsigned char *vis_type,
                                                       SceneCounters *cnt, unsigned *bucket_bits) {
@@ -254,9 +241,11 @@ __global__ __launch_bounds__(256) void k_commit_apply(const unsigned char *__res
   int r1 = block_excl_scan<4>(c1, red[0], tot1);
   int r2 = block_excl_scan<4>(c2, red[1], tot2);
   if (tot1 + tot2 == 0) return;
-  r1 += tile_offsets[blockIdx.x * 2];
-  r2 += tile_offsets[blockIdx.x * 2 + 1];
-  const int base_free = cnt->base_free, base_free_ex = cnt->base_free_ex;
+  // exclusive tile offsets = sums of the preceding tiles' request counts (accumulated by the mark pass)
+  r1 += block_sum_strided(tile_counts, blockIdx.x, 2, red[0]);
+  r2 += block_sum_strided(tile_counts + 1, blockIdx.x, 2, red[1]);
+  // the pool tops are not modified during this kernel (the next kernel folds the success counts into them)
+  const int base_free = cnt->last_free, base_free_ex = cnt->last_free_ex;
   const int avail_vba = base_free + 1, avail_ex = base_free_ex + 1;
   int succ_vba = 0, succ_ex = 0;
 #pragma unroll
@@ -302,8 +291,24 @@ struct VisParams {
 template <bool SWAPPING>
 __global__ __launch_bounds__(256) void k_visible_count(unsigned char *vis_type, const HashEntry *__restrict__ hash,
                                                        unsigned char *swap_state, int n_entries, VisParams p,
-                                                       int *__restrict__ tile_counts) {
+                                                       int *__restrict__ tile_counts, SceneCounters *cnt,
+                                                       const int *__restrict__ commit_counts, int n_commit_counts,
+                                                       int finalize_commit) {
   __shared__ int red[4];
+  if (blockIdx.x == 0) {  // fold the commit pass' results into the pool tops (nobody else reads them in this kernel)
+    const int requests = finalize_commit ? block_sum_strided(commit_counts, n_commit_counts, 1, red) : 0;
+    if (threadIdx.x == 0) {
+      if (finalize_commit) {
+        cnt->last_free -= cnt->commit_succ_vba;
+        cnt->last_free_ex -= cnt->commit_succ_ex;
+        cnt->alloc_failures = requests - cnt->commit_succ_vba;
+        cnt->commit_succ_vba = 0;
+        cnt->commit_succ_ex = 0;
+      } else {
+        cnt->alloc_failures = 0;
+      }
+    }
+  }
   const int t0 = blockIdx.x * kTileEntries + threadIdx.x * 4;
   int c = 0;
   if (t0 < n_entries) {
@@ -327,24 +332,6 @@ __global__ __launch_bounds__(256) void k_visible_count(unsigned char *vis_type, 
   int tot;
   block_excl_scan<4>(c, red, tot);
   if (threadIdx.x == 0) tile_counts[blockIdx.x] = tot;
-}
-
-// single-workgroup scan of the per-tile counts; also folds the commit pass' success counters into the pool tops
-__global__ __launch_bounds__(1024) void k_visible_scan(const int *tile_counts, int *tile_offsets, int n_tiles,
-                                                       SceneCounters *cnt, RenderCounters *rc, int finalize_commit,
-                                                       int capacity) {
-  int totals[1];
-  scan_tiles<1>(tile_counts, tile_offsets, n_tiles, totals);
-  if (threadIdx.x == 0) {
-    rc->no_visible = totals[0] < capacity ? totals[0] : capacity;
-    if (finalize_commit) {
-      cnt->last_free = cnt->base_free - cnt->commit_succ_vba;
-      cnt->last_free_ex = cnt->base_free_ex - cnt->commit_succ_ex;
-      cnt->alloc_failures = cnt->commit_requests - cnt->commit_succ_vba;
-    } else if (cnt) {
-      cnt->alloc_failures = 0;
-    }
-  }
 }
 
 // reallocate swapped-out blocks that came back into view (useSwapping only): one pool, so the r-th request in
@@ -452,25 +439,23 @@ int launch_allocate(dslam_engine *e, dslam_scene *s, const dslam_view *v, dslam_
   hipLaunchKernelGGL(k_mark<0>, dim3(pix_blocks), dim3(256), 0, e->stream, mp);
   hipLaunchKernelGGL(k_mark<1>, dim3(pix_blocks), dim3(256), 0, e->stream, mp);
   if (!only_update_visible_list) {
-    hipLaunchKernelGGL(k_commit_scan, dim3(1), dim3(1024), 0, e->stream, e->tile_counts, e->tile_offsets, n_tiles,
-                       s->counters);
     hipLaunchKernelGGL(k_commit_apply, dim3(n_tiles), dim3(256), 0, e->stream, e->alloc_type, e->block_coords, N,
-                       e->tile_offsets, s->hash, s->p.num_buckets, s->alloc_list, s->excess_list, r->visible_type,
+                       e->tile_counts, s->hash, s->p.num_buckets, s->alloc_list, s->excess_list, r->visible_type,
                        s->counters, s->bucket_bits);
   }
+  const int fin = only_update_visible_list ? 0 : 1;
   VisParams vp;
   memcpy(vp.M.m, M_d, sizeof(float) * 16);
   vp.fx = intr[0]; vp.fy = intr[1]; vp.cx = intr[2]; vp.cy = intr[3]; vp.voxel_size = s->p.voxel_size; vp.W = W; vp.H = H;
   if (s->p.use_swapping)
     hipLaunchKernelGGL(k_visible_count<true>, dim3(n_tiles), dim3(256), 0, e->stream, r->visible_type, s->hash,
-                       s->swap_state, N, vp, e->tile_counts);
+                       s->swap_state, N, vp, e->tile_offsets, s->counters, e->tile_counts, n_tiles * 2, fin);
   else
     hipLaunchKernelGGL(k_visible_count<false>, dim3(n_tiles), dim3(256), 0, e->stream, r->visible_type, s->hash,
-                       (unsigned char *)nullptr, N, vp, e->tile_counts);
-  hipLaunchKernelGGL(k_visible_scan, dim3(1), dim3(1024), 0, e->stream, e->tile_counts, e->tile_offsets, n_tiles,
-                     s->counters, r->counters, only_update_visible_list ? 0 : 1, r->n_local);
-  hipLaunchKernelGGL(k_compact_apply, dim3(n_tiles), dim3(256), 0, e->stream, r->visible_type, N, e->tile_offsets,
-                     r->visible_ids, r->n_local);
+                       (unsigned char *)nullptr, N, vp, e->tile_offsets, s->counters, e->tile_counts, n_tiles * 2, fin);
+  // (tile_offsets holds the visible counts here: the commit request counts in tile_counts are still being read)
+  hipLaunchKernelGGL(k_compact_apply_fused, dim3(n_tiles), dim3(256), 0, e->stream, r->visible_type, N, e->tile_offsets,
+                     r->visible_ids, r->n_local, &r->counters->no_visible);
   if (s->p.use_swapping) {
     hipLaunchKernelGGL(k_realloc_count, dim3(n_tiles), dim3(256), 0, e->stream, r->visible_type, s->hash, N,
                        e->tile_counts);

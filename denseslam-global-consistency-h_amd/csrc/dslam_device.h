@@ -224,6 +224,49 @@ static __global__ __launch_bounds__(1024) void k_scan_count(const int *tile_coun
   if (threadIdx.x == 0) *total_out = totals[0] < capacity ? totals[0] : capacity;
 }
 
+// Sum of a strided int array over [0, n) by a 256-thread workgroup (every thread gets the result).  Lets each
+// apply-workgroup derive its own exclusive tile offset from the (L2-hot, <= a few thousand) per-tile counts, which
+// removes the single-workgroup scan kernel -- one ~4.5 us kernel boundary -- from every ordered compaction.
+__device__ __forceinline__ int block_sum_strided(const int *__restrict__ v, int n, int stride, int *lds4) {
+  int s = 0;
+  for (int i = threadIdx.x; i < n; i += 256) s += v[i * stride];
+  for (int d = 32; d > 0; d >>= 1) s += __shfl_xor(s, d, 64);
+  if ((threadIdx.x & 63) == 0) lds4[threadIdx.x >> 6] = s;
+  __syncthreads();
+  const int tot = lds4[0] + lds4[1] + lds4[2] + lds4[3];
+  __syncthreads();
+  return tot;
+}
+
+// fused pass 2: like k_compact_apply, but the tile's exclusive offset is the sum of the preceding tile counts,
+// computed here; the last tile also publishes the (capacity-clipped) total
+static __global__ __launch_bounds__(256) void k_compact_apply_fused(const unsigned char *__restrict__ flags,
+                                                                  int n_entries,
+                                                                  const int *__restrict__ tile_counts, int *out,
+                                                                  int capacity, int *total_out) {
+  __shared__ int red[4];
+  const int t0 = blockIdx.x * kTileEntries + threadIdx.x * 4;
+  unsigned char f[4] = {0, 0, 0, 0};
+  if (t0 < n_entries) {
+    const uchar4 v = *reinterpret_cast<const uchar4 *>(flags + t0);
+    f[0] = v.x; f[1] = v.y; f[2] = v.z; f[3] = v.w;
+  }
+  const int c = (f[0] > 0) + (f[1] > 0) + (f[2] > 0) + (f[3] > 0);
+  int tot;
+  int r = block_excl_scan<4>(c, red, tot);
+  const bool last = blockIdx.x == gridDim.x - 1;
+  if (tot == 0 && !last) return;
+  const int offset = block_sum_strided(tile_counts, blockIdx.x, 1, red);
+  if (last && threadIdx.x == 0) *total_out = (offset + tot) < capacity ? (offset + tot) : capacity;
+  r += offset;
+#pragma unroll
+  for (int k = 0; k < 4; k++)
+    if (f[k] > 0) {
+      if (r < capacity) out[r] = t0 + k;
+      r++;
+    }
+}
+
 // pass 2 of every ordered compaction: entry index t goes to out[rank] for flags[t] > 0, ranks ascending in t
 static __global__ __launch_bounds__(256) void k_compact_apply(const unsigned char *__restrict__ flags, int n_entries,
                                                        const int *__restrict__ tile_offsets, int *__restrict__ out,

@@ -64,10 +64,8 @@ int launch_find_visible(dslam_engine *e, const dslam_scene *s, dslam_render_stat
   const int n_tiles = num_tiles(N);
   unsigned char *flags = reinterpret_cast<unsigned char *>(e->list_c);  // byte flags, N <= sizeof(list_c)
   hipLaunchKernelGGL(k_frustum_flags, dim3(n_tiles), dim3(256), 0, e->stream, s->hash, N, fp, flags, e->tile_counts);
-  hipLaunchKernelGGL(k_scan_count, dim3(1), dim3(1024), 0, e->stream, e->tile_counts, e->tile_offsets, n_tiles,
-                     &r->counters->no_visible, r->n_local);
-  hipLaunchKernelGGL(k_compact_apply, dim3(n_tiles), dim3(256), 0, e->stream, flags, N, e->tile_offsets,
-                     r->visible_ids, r->n_local);
+  hipLaunchKernelGGL(k_compact_apply_fused, dim3(n_tiles), dim3(256), 0, e->stream, flags, N, e->tile_counts,
+                     r->visible_ids, r->n_local, &r->counters->no_visible);
   DSLAM_HIP(hipGetLastError());
   return DSLAM_OK;
 }
@@ -494,11 +492,46 @@ __device__ __forceinline__ bool cast_ray(Vec4 &out, int x, int y, const RenderPa
   int iter = 0;
   while (total < total_max) {
     ++iter;
-    sdf = read_sdf_uninterp(p.vol, res, hash_found, cache);
-    if (!hash_found) {
+    // Measured on MI355X: the memory system is nearly idle during the march (TA ~16 % busy); a wave's time is its
+    // count of SERIALISED load round trips (~600 cycles each), and added scattered loads (bucket bitmap, prefetch
+    // of next heads, speculative multi-step batches) cost more than they save.  What does pay: once the block of
+    // the nearest voxel ROUND(p) is resolved, the taps of the trilinear cell floor(p)..floor(p)+1 that lie in the
+    // SAME block (all 8 at 67 % of the positions; ROUND(p) is always one of them) ride in the same round trip, so
+    // near the surface the interpolated value needs no second lookup + gather.
+    const int vx = iround(res.x), vy = iround(res.y), vz = iround(res.z);
+    const int bx = vx >> 3, by = vy >> 3, bz = vz >> 3;
+    const int base = lookup_block(p.vol, bx, by, bz, cache);
+    if (base < 0) {
+      sdf = 1.0f;  // empty voxel: 32767 / 32767
       step = (float)kBlock;
     } else {
-      if ((sdf <= 0.1f) && (sdf >= -0.5f)) sdf = read_sdf_interp(p.vol, res, hash_found, cache);
+      const float f0x = floorf(res.x), f0y = floorf(res.y), f0z = floorf(res.z);
+      const int x0 = (int)f0x, y0 = (int)f0y, z0 = (int)f0z;
+      unsigned raw[8];
+      bool all_in = true;
+#pragma unroll
+      for (int k = 0; k < 8; k++) {
+        const int tx = x0 + (k & 1), ty = y0 + ((k >> 1) & 1), tz = z0 + (k >> 2);
+        const bool in = ((tx >> 3) == bx) && ((ty >> 3) == by) && ((tz >> 3) == bz);
+        all_in = all_in && in;
+        const int lin = (tx & 7) + (ty & 7) * kBlock + (tz & 7) * kBlock * kBlock;
+        raw[k] = p.vol.voxels[(size_t)base + (in ? lin : 0)].x;  // unconditional, batched; out-of-block taps ignored
+      }
+      const int near = (vx - x0) | ((vy - y0) << 1) | ((vz - z0) << 2);
+      unsigned rn = raw[0];
+#pragma unroll
+      for (int k = 1; k < 8; k++) rn = (near == k) ? raw[k] : rn;
+      sdf = (float)(short)(rn & 0xffffu) / 32767.0f;
+      if ((sdf <= 0.1f) && (sdf >= -0.5f)) {
+        if (all_in) {
+          uint2 t[8];
+#pragma unroll
+          for (int k = 0; k < 8; k++) t[k] = make_uint2(raw[k], 0u);
+          sdf = trilinear_sdf(t, res.x - f0x, res.y - f0y, res.z - f0z);
+        } else {
+          sdf = read_sdf_interp(p.vol, res, hash_found, cache);
+        }
+      }
       if (sdf <= 0.0f) break;
       step = fmaxf(sdf * step_scale, 1.0f);
     }
