@@ -83,7 +83,7 @@ __device__ __forceinline__ void bilinear_rgb(const uchar4 *__restrict__ rgba, fl
 
 // ComputeUpdatedVoxelInfo<hasColor>::compute on a packed voxel (lo, hi) whose camera-frame position pc = M_d * pm
 // has been assembled by the caller.  Returns true if the voxel changed.
-template <bool DEINT>
+template <bool DEINT, bool SAME_CAM>
 __device__ __forceinline__ bool update_voxel(unsigned &lo, unsigned &hi, const Vec4 &pc, const Vec4 &pm,
                                              const IntegrateParams &p, const float *inv_tab) {
   float eta, u, w;
@@ -124,7 +124,7 @@ __device__ __forceinline__ bool update_voxel(unsigned &lo, unsigned &hi, const V
   }
   if ((eta > p.mu) || (fabsf(div_exact(eta, p.mu, p.inv_mu)) > 0.25f)) return changed;
   {  // computeUpdatedVoxelColorInfo
-    if (!p.same_cam) {
+    if (!SAME_CAM) {
       const Vec4 pcr = mul(p.M_rgb, pm);
       u = p.fx_r * pcr.x / pcr.z + p.cx_r;
       w = p.fy_r * pcr.y / pcr.z + p.cy_r;
@@ -177,7 +177,10 @@ __device__ __forceinline__ bool update_voxel(unsigned &lo, unsigned &hi, const V
 
 constexpr int kMaxGroup = 8;
 
-template <bool DEINT>
+// SAME_CAM: the RGB camera is the depth camera (identity calib, as the reference sets it up): the colour update
+// reuses the depth projection, and the kernel carries one matrix instead of two (the scalar register file does not
+// hold both without spilling to VGPR lanes).
+template <bool DEINT, bool SAME_CAM>
 __global__ __launch_bounds__(256, 8) void k_integrate(IntegrateParams p) {
   __shared__ float inv_tab[kInvTab];
   for (int i = threadIdx.x; i < kInvTab; i += 256) inv_tab[i] = 1.0f / (float)i;  // IEEE division: RN(1/i)
@@ -250,7 +253,7 @@ __global__ __launch_bounds__(256, 8) void k_integrate(IntegrateParams p) {
           pc.z = (pxy[h][2] + az2) + p.M_d.m[14];
           pc.w = 1.0f;
           pm.x = fxv[h]; pm.y = fy; pm.z = fz; pm.w = 1.0f;
-          ch |= update_voxel<DEINT>(lo, hi, pc, pm, p, inv_tab);
+          ch |= update_voxel<DEINT, SAME_CAM>(lo, hi, pc, pm, p, inv_tab);
         }
         if (ch) blk[j * 64 + lane] = v[jj];
       }
@@ -301,10 +304,13 @@ int launch_integrate(dslam_engine *e, dslam_scene *s, const dslam_view *v, const
     ip.timer_slot = e->timer_counts_dev + (e->ev_used / 2);
     DSLAM_HIP(hipEventRecord(e->ev_pool[e->ev_used], e->stream));
   }
-  if (deintegrate)
-    hipLaunchKernelGGL(k_integrate<true>, dim3(kIntegrateGrid), dim3(256), 0, e->stream, ip);
-  else
-    hipLaunchKernelGGL(k_integrate<false>, dim3(kIntegrateGrid), dim3(256), 0, e->stream, ip);
+  if (deintegrate) {
+    if (ip.same_cam) hipLaunchKernelGGL((k_integrate<true, true>), dim3(kIntegrateGrid), dim3(256), 0, e->stream, ip);
+    else hipLaunchKernelGGL((k_integrate<true, false>), dim3(kIntegrateGrid), dim3(256), 0, e->stream, ip);
+  } else {
+    if (ip.same_cam) hipLaunchKernelGGL((k_integrate<false, true>), dim3(kIntegrateGrid), dim3(256), 0, e->stream, ip);
+    else hipLaunchKernelGGL((k_integrate<false, false>), dim3(kIntegrateGrid), dim3(256), 0, e->stream, ip);
+  }
   if (timed) {
     DSLAM_HIP(hipEventRecord(e->ev_pool[e->ev_used + 1], e->stream));
     e->ev_used += 2;
