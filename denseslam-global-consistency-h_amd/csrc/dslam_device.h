@@ -77,9 +77,13 @@ __device__ __forceinline__ int hash_index(int bx, int by, int bz, unsigned mask)
   return (int)((((unsigned)bx * 73856093u) ^ ((unsigned)by * 19349669u) ^ ((unsigned)bz * 83492791u)) & mask);
 }
 
+// native 4 x u32 vector: hipcc keeps a load of this type as ONE global_load_dwordx4, whereas HIP's uint4 struct is
+// scalarised into dword + dwordx2 + dword when its fields are consumed separately (checked in the ISA)
+typedef unsigned __attribute__((ext_vector_type(4))) u32x4;
+
 __device__ __forceinline__ HashEntry load_entry(const HashEntry *table, int idx) {
   // one 16-byte load
-  const uint4 raw = *reinterpret_cast<const uint4 *>(table + idx);
+  const u32x4 raw = *reinterpret_cast<const u32x4 *>(table + idx);
   HashEntry e;
   e.pos[0] = (short)(raw.x & 0xffff);
   e.pos[1] = (short)(raw.x >> 16);
@@ -91,12 +95,12 @@ __device__ __forceinline__ HashEntry load_entry(const HashEntry *table, int idx)
 }
 
 __device__ __forceinline__ void store_entry(HashEntry *table, int idx, int px, int py, int pz, int offset, int ptr) {
-  uint4 raw;
+  u32x4 raw;
   raw.x = ((unsigned)px & 0xffffu) | ((unsigned)py << 16);
   raw.y = ((unsigned)pz & 0xffffu);
   raw.z = (unsigned)offset;
   raw.w = (unsigned)ptr;
-  *reinterpret_cast<uint4 *>(table + idx) = raw;
+  *reinterpret_cast<u32x4 *>(table + idx) = raw;
 }
 
 // voxel packing: lo = sdf | w_depth<<16 | clr0<<24 ; hi = clr1 | clr2<<8 | w_color<<16 | pad<<24
