@@ -84,6 +84,8 @@ def main():
     ap.add_argument("--height", type=int, default=480)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--reint", type=int, default=32, help="keyframes in the sharded re-integration batch (0 = skip)")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="initialise torch.distributed (RCCL) and run the all-gather path even with one rank (plumbing check)")
     ap.add_argument("--sync", action="store_true", help="synchronous calls (reference driver behaviour) instead of pipelined")
     args = ap.parse_args()
 
@@ -96,9 +98,11 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: libdslam_fusion has no CPU path")
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    use_dist = world > 1 or args.force_dist
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     pkg = ge.load_package()
     from dslam_amd.harness import synth
@@ -181,11 +185,11 @@ def main():
             batch = reint.Batch([("dev", rgba_d.data_ptr() + i * rgba_stride, depth_d.data_ptr() + i * depth_stride) for i in ids],
                                 [Ms[i] for i in ids], new_poses, wl.intr)
             chunk = 64
-            ag = reint.make_torch_all_gather(vox_t, dist, chunk, eng.synchronize) if world > 1 else None
+            ag = reint.make_torch_all_gather(vox_t, dist, chunk, eng.synchronize) if use_dist else None
             timers = {}
             barrier()
             reint.reintegrate(eng, scene, view, rs, batch, rank=rank, world=world, chunk_blocks=chunk, all_gather=ag,
-                              timers=timers)
+                              timers=timers, force_collective=use_dist)
             barrier()
             tt = torch.tensor([timers["total_s"], timers["reintegrate_s"], timers["all_gather_s"]], device=dev,
                               dtype=torch.float64)
@@ -194,7 +198,7 @@ def main():
             tot, rei, agt = [float(x) for x in tt.tolist()]
             reint_out = {"keyframes": Kre, "keyframes_per_s": Kre / tot, "total_ms": tot * 1e3, "compute_ms": rei * 1e3,
                          "all_gather_ms": agt * 1e3, "gathered_bytes": timers["gathered_bytes"],
-                         "all_gather_GBps": (timers["gathered_bytes"] / agt / 1e9) if (world > 1 and agt > 0) else None,
+                         "all_gather_GBps": (timers["gathered_bytes"] / agt / 1e9) if (use_dist and agt > 0) else None,
                          "scaling": "strong (fixed batch; allocation replicated on every rank, voxel blocks sharded)"}
         except Exception as ex:  # never lose the main line over the auxiliary measurement
             reint_out = {"error": repr(ex)}
@@ -244,7 +248,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline(pkg, wl, params, frames)
             out["cpu_baseline"]["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -56,9 +56,12 @@ def _update_view(api, view, frame, ts):
         api.view_update(view, frame[1], frame[2], timestamp=ts)
 
 
-def reintegrate(api, scene, view, rs, batch, rank=0, world=1, chunk_blocks=64, all_gather=None, timers=None):
-    """Run the batch on this rank; `all_gather(lo, groups)` performs the collective (None when world == 1)."""
+def reintegrate(api, scene, view, rs, batch, rank=0, world=1, chunk_blocks=64, all_gather=None, timers=None,
+                force_collective=False):
+    """Run the batch on this rank; `all_gather(lo, groups)` performs the collective (None when world == 1;
+    force_collective runs it even for a single rank, as a plumbing check)."""
     t0 = time.perf_counter()
+    collective = (world > 1 or force_collective) and all_gather is not None
     if world > 1:
         api.set_shard(scene, rank, world, chunk_blocks)
     for k in range(len(batch)):
@@ -68,14 +71,15 @@ def reintegrate(api, scene, view, rs, batch, rank=0, world=1, chunk_blocks=64, a
     st = api.stats(scene, rs)  # synchronises; identical on every rank
     t1 = time.perf_counter()
     lo = groups = None
-    if world > 1:
+    if collective:
         lo, groups = plan_region(st["last_free_block_id"], scene.params.num_local_blocks, world, chunk_blocks)
         all_gather(lo, groups)
+    if world > 1:
         api.set_shard(scene, 0, 1, chunk_blocks)
     t2 = time.perf_counter()
     if timers is not None:
         timers.update(reintegrate_s=t1 - t0, all_gather_s=t2 - t1, total_s=t2 - t0,
-                      gathered_bytes=0 if world == 1 else groups * world * chunk_blocks * BLOCK_BYTES)
+                      gathered_bytes=0 if not collective else groups * world * chunk_blocks * BLOCK_BYTES)
     return lo, groups
 
 
