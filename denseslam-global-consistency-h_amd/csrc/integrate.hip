@@ -32,7 +32,7 @@ struct IntegrateParams {
   float fx_d, fy_d, cx_d, cy_d;
   float fx_r, fy_r, cx_r, cy_r;
   float voxel_size, mu;
-  float inv_mu, inv_32767, inv_255;  // correctly rounded reciprocals (host division) for div_exact()
+  float inv_32767, inv_255;  // correctly rounded reciprocals (host division) for div_exact()
   int same_cam;                      // RGB camera == depth camera (identity calib of the reference): reuse projection
   int max_w, stop_max;
   int depth_weighting, max_new_w;
@@ -47,9 +47,10 @@ struct IntegrateParams {
 };
 
 // a / b for a divisor whose correctly rounded reciprocal y = RN(1/b) is known: q = RN(a*y), r = a - b*q (exact, FMA),
-// q' = RN(q + r*y).  This IS the IEEE quotient RN(a/b) (Markstein) -- 3 instructions instead of the ~10 of
-// v_div_scale/v_rcp/v_div_fmas/v_div_fixup.  Verified exhaustively over every finite float a with |a| <= 1e30 for
-// b = 32767, 255 and the mu values of the workloads, and densely for b = 1..256 (tests/tools/verify_exact_div.cpp).
+// q' = RN(q + r*y) -- 3 instructions instead of the ~10 of v_div_scale/v_rcp/v_div_fmas/v_div_fixup.  This equals
+// the IEEE quotient RN(a/b) only for suitable divisors: tests/tools/verify_exact_div.cpp shows 0 mismatches over
+// EVERY finite float a for b = 32767 and b = 255 and for the integer weights b = 1..256 over the operand range, but
+// 0.06-0.2 % one-ulp mismatches for b = 0.2, 0.02, ... -- so it is used for those constants only, never for mu.
 __device__ __forceinline__ float div_exact(float a, float b, float y) {
   const float q = a * y;
   const float r = __fmaf_rn(-b, q, a);
@@ -86,7 +87,7 @@ __device__ __forceinline__ void bilinear_rgb(const uchar4 *__restrict__ rgba, fl
 template <bool DEINT, bool SAME_CAM>
 __device__ __forceinline__ bool update_voxel(unsigned &lo, unsigned &hi, const Vec4 &pc, const Vec4 &pm,
                                              const IntegrateParams &p, const float *inv_tab) {
-  float eta, u, w;
+  float eta, eta_mu, u, w;
   bool changed = false;
   {  // computeUpdatedVoxelDepthInfo
     if (pc.z <= 0) return false;
@@ -99,7 +100,8 @@ __device__ __forceinline__ bool update_voxel(unsigned &lo, unsigned &hi, const V
     if (eta < -p.mu) return false;
     const float oldF = div_exact((float)(short)(lo & 0xffffu), 32767.0f, p.inv_32767);
     const int oldW = (int)((lo >> 16) & 0xffu);
-    float newF = fminf(1.0f, div_exact(eta, p.mu, p.inv_mu));
+    eta_mu = eta / p.mu;  // true IEEE division: the 3-instruction form is NOT exact for arbitrary mu
+    float newF = fminf(1.0f, eta_mu);
     int newW = new_weight(p, dm);
     if (!DEINT) {
       newF = (float)oldW * oldF + (float)newW * newF;
@@ -122,7 +124,7 @@ __device__ __forceinline__ bool update_voxel(unsigned &lo, unsigned &hi, const V
       changed = true;
     }
   }
-  if ((eta > p.mu) || (fabsf(div_exact(eta, p.mu, p.inv_mu)) > 0.25f)) return changed;
+  if ((eta > p.mu) || (fabsf(eta_mu) > 0.25f)) return changed;
   {  // computeUpdatedVoxelColorInfo
     if (!SAME_CAM) {
       const Vec4 pcr = mul(p.M_rgb, pm);
@@ -275,7 +277,7 @@ static void fill_params(IntegrateParams &ip, dslam_engine *e, dslam_scene *s, co
   ip.fx_d = intr_d[0]; ip.fy_d = intr_d[1]; ip.cx_d = intr_d[2]; ip.cy_d = intr_d[3];
   ip.fx_r = kr[0]; ip.fy_r = kr[1]; ip.cx_r = kr[2]; ip.cy_r = kr[3];
   ip.voxel_size = s->p.voxel_size; ip.mu = s->p.mu; ip.max_w = s->p.max_w;
-  ip.inv_mu = 1.0f / s->p.mu; ip.inv_32767 = 1.0f / 32767.0f; ip.inv_255 = 1.0f / 255.0f;
+  ip.inv_32767 = 1.0f / 32767.0f; ip.inv_255 = 1.0f / 255.0f;
   ip.same_cam = (memcmp(ip.M_d.m, ip.M_rgb.m, 64) == 0 && kr[0] == intr_d[0] && kr[1] == intr_d[1] && kr[2] == intr_d[2] &&
                  kr[3] == intr_d[3] && v->w_rgb == v->w_d && v->h_rgb == v->h_d) ? 1 : 0;
   ip.stop_max = s->p.stop_integrating_at_max_w;
