@@ -226,8 +226,8 @@ __global__ __launch_bounds__(256) void k_commit_apply(const unsigned char *__res
                                                       const int *__restrict__ tile_counts, HashEntry *hash,
                                                       int num_buckets, const int *__restrict__ alloc_list,
                                                       const int *__restrict__ excess_list, unsigned char *vis_type,
-                                                      SceneCounters *cnt, unsigned *bucket_bits) {
-  __shared__ int red[2][4];
+                                                      SceneCounters *cnt, unsigned *bucket_bits, int n_tiles) {
+  __shared__ int red[2][8];
   const int t0 = blockIdx.x * kTileEntries + threadIdx.x * 4;
   unsigned char a[4] = {0, 0, 0, 0};
   if (t0 < n_entries) {
@@ -242,11 +242,17 @@ __global__ __launch_bounds__(256) void k_commit_apply(const unsigned char *__res
   int r2 = block_excl_scan<4>(c2, red[1], tot2);
   if (tot1 + tot2 == 0) return;
   // exclusive tile offsets = sums of the preceding tiles' request counts (accumulated by the mark pass)
-  r1 += block_sum_strided(tile_counts, blockIdx.x, 2, red[0]);
-  r2 += block_sum_strided(tile_counts + 1, blockIdx.x, 2, red[1]);
+  int pre1, pre2, all1, all2;
+  block_prefix_and_total(tile_counts, blockIdx.x, n_tiles, 2, red[0], pre1, all1);
+  block_prefix_and_total(tile_counts + 1, blockIdx.x, n_tiles, 2, red[1], pre2, all2);
+  r1 += pre1;
+  r2 += pre2;
   // the pool tops are not modified during this kernel (the next kernel folds the success counts into them)
   const int base_free = cnt->last_free, base_free_ex = cnt->last_free_ex;
   const int avail_vba = base_free + 1, avail_ex = base_free_ex + 1;
+  // unless the voxel-block pool runs out during this pass, the success counts follow from the totals in closed
+  // form (k_visible_count folds them in); only the exhausted regime counts them with (same-address) atomics
+  const bool exhausted = all1 + (all2 < avail_ex ? all2 : avail_ex) > avail_vba;
   int succ_vba = 0, succ_ex = 0;
 #pragma unroll
   for (int k = 0; k < 4; k++) {
@@ -277,8 +283,10 @@ __global__ __launch_bounds__(256) void k_commit_apply(const unsigned char *__res
       }
     }
   }
-  if (succ_vba) atomicAdd(&cnt->commit_succ_vba, succ_vba);
-  if (succ_ex) atomicAdd(&cnt->commit_succ_ex, succ_ex);
+  if (exhausted) {
+    if (succ_vba) atomicAdd(&cnt->commit_succ_vba, succ_vba);
+    if (succ_ex) atomicAdd(&cnt->commit_succ_ex, succ_ex);
+  }
 }
 
 struct VisParams {
@@ -296,9 +304,17 @@ __global__ __launch_bounds__(256) void k_visible_count(unsigned char *vis_type, 
                                                        int finalize_commit) {
   __shared__ int red[4];
   if (blockIdx.x == 0) {  // fold the commit pass' results into the pool tops (nobody else reads them in this kernel)
-    const int requests = finalize_commit ? block_sum_strided(commit_counts, n_commit_counts, 1, red) : 0;
+    const int all1 = finalize_commit ? block_sum_strided(commit_counts, n_commit_counts / 2, 2, red) : 0;
+    const int all2 = finalize_commit ? block_sum_strided(commit_counts + 1, n_commit_counts / 2, 2, red) : 0;
     if (threadIdx.x == 0) {
       if (finalize_commit) {
+        const int avail_vba = cnt->last_free + 1, avail_ex = cnt->last_free_ex + 1;
+        const int ex_ok = all2 < avail_ex ? all2 : avail_ex;
+        if (!(all1 + ex_ok > avail_vba)) {  // same test as k_commit_apply: nothing ran out of voxel blocks
+          cnt->commit_succ_vba = all1 + ex_ok;
+          cnt->commit_succ_ex = ex_ok;
+        }
+        const int requests = all1 + all2;
         cnt->last_free -= cnt->commit_succ_vba;
         cnt->last_free_ex -= cnt->commit_succ_ex;
         cnt->alloc_failures = requests - cnt->commit_succ_vba;
@@ -441,7 +457,7 @@ int launch_allocate(dslam_engine *e, dslam_scene *s, const dslam_view *v, dslam_
   if (!only_update_visible_list) {
     hipLaunchKernelGGL(k_commit_apply, dim3(n_tiles), dim3(256), 0, e->stream, e->alloc_type, e->block_coords, N,
                        e->tile_counts, s->hash, s->p.num_buckets, s->alloc_list, s->excess_list, r->visible_type,
-                       s->counters, s->bucket_bits);
+                       s->counters, s->bucket_bits, n_tiles);
   }
   const int fin = only_update_visible_list ? 0 : 1;
   VisParams vp;

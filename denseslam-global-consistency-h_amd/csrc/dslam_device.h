@@ -242,6 +242,23 @@ __device__ __forceinline__ int block_sum_strided(const int *__restrict__ v, int 
   return tot;
 }
 
+// both the sum over [0, n_prefix) and over [0, n_total) of a strided int array (n_prefix <= n_total), one pass
+__device__ __forceinline__ void block_prefix_and_total(const int *__restrict__ v, int n_prefix, int n_total, int stride,
+                                                       int *lds8, int &prefix, int &total) {
+  int sp = 0, st = 0;
+  for (int i = threadIdx.x; i < n_total; i += 256) {
+    const int x = v[i * stride];
+    st += x;
+    if (i < n_prefix) sp += x;
+  }
+  for (int d = 32; d > 0; d >>= 1) { sp += __shfl_xor(sp, d, 64); st += __shfl_xor(st, d, 64); }
+  if ((threadIdx.x & 63) == 0) { lds8[threadIdx.x >> 6] = sp; lds8[4 + (threadIdx.x >> 6)] = st; }
+  __syncthreads();
+  prefix = lds8[0] + lds8[1] + lds8[2] + lds8[3];
+  total = lds8[4] + lds8[5] + lds8[6] + lds8[7];
+  __syncthreads();
+}
+
 // fused pass 2: like k_compact_apply, but the tile's exclusive offset is the sum of the preceding tile counts,
 // computed here; the last tile also publishes the (capacity-clipped) total
 static __global__ __launch_bounds__(256) void k_compact_apply_fused(const unsigned char *__restrict__ flags,
