@@ -84,6 +84,9 @@ def main():
     ap.add_argument("--height", type=int, default=480)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--reint", type=int, default=32, help="keyframes in the sharded re-integration batch (0 = skip)")
+    ap.add_argument("--host-io", action="store_true",
+                    help="PCIe-inclusive variant: frames come from host buffers (dslam_view_update) and the raycast "
+                         "depth image is downloaded every frame, as InfiniTamDriver does; never the headline value")
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise torch.distributed (RCCL) and run the all-gather path even with one rank (plumbing check)")
     ap.add_argument("--sync", action="store_true", help="synchronous calls (reference driver behaviour) instead of pipelined")
@@ -136,10 +139,13 @@ def main():
     depth_stride = wl.W * wl.H * 2
 
     def step(i):
-        eng.view_update_device(view, rgba_d.data_ptr() + i * rgba_stride, depth_d.data_ptr() + i * depth_stride,
-                               timestamp=float(i))
+        if args.host_io:
+            eng.view_update(view, rgba_h[i], depth_h[i], timestamp=float(i))
+        else:
+            eng.view_update_device(view, rgba_d.data_ptr() + i * rgba_stride, depth_d.data_ptr() + i * depth_stride,
+                                   timestamp=float(i))
         eng.process_frame(scene, view, rs, Ms[i], wl.intr)
-        eng.get_image(scene, rs, Ms[i], wl.intr, pkg.IMAGE_DEPTH, download=False)
+        eng.get_image(scene, rs, Ms[i], wl.intr, pkg.IMAGE_DEPTH, download=args.host_io)
 
     for i in range(Wm):
         step(i)
@@ -231,7 +237,8 @@ def main():
                                    f"(BASELINE configs[1]), fusion+raycast only, poses precomputed, voxel "
                                    f"{wl.scene_kwargs['voxel_size']} m, mu {wl.scene_kwargs['mu']} m, frustum "
                                    f"{wl.scene_kwargs['frustum_min']}-{wl.scene_kwargs['frustum_max']} m",
-                       "calls": "pipelined (async engine stream)" if not args.sync else "synchronous per call",
+                       "calls": ("host buffers in, depth image out over PCIe every frame" if args.host_io else
+                                 "pipelined (async engine stream)" if not args.sync else "synchronous per call"),
                        "parallelism": "replicas" if world > 1 else "single GPU",
                        "voxel_block_pool": nlb,
                        "visible_blocks_per_frame": blocks / max(1, launches),
