@@ -1,0 +1,135 @@
+"""Edge cases and full-size, oracle-free properties of the HIP engine (called through the C ABI)."""
+import numpy as np
+import pytest
+
+import util
+
+pytestmark = pytest.mark.gpu
+
+
+def _fuse(api, pkg, wl, p, n, M_rgb_of=None, intr_rgb=None, view_size=None):
+    s = api.create_scene(p)
+    rs = api.create_render_state(s, wl.W, wl.H)
+    v = api.create_view(wl.W, wl.H)
+    for i in range(n):
+        rgba, mm, M = wl.frame(i)
+        api.view_update(v, rgba, mm, timestamp=float(i))
+        api.process_frame(s, v, rs, M, wl.intr, M_rgb=None if M_rgb_of is None else M_rgb_of(M), intr_rgb=intr_rgb)
+    return s, rs, v
+
+
+def test_separate_rgb_camera_variant(pkg, synth, gpu, oracle):
+    """trafo_rgb_to_depth != identity and different RGB intrinsics: exercises the two-matrix kernel variant
+    (the reference sets identity, InfiniTamDriver.cpp:74-75, but the ITMLib interface allows any calib)."""
+    wl = synth.s_tiny()
+    p = util.small_params(pkg, wl)
+    T = synth.pose_matrix(synth.look_rotation(0.01, 0.005), [0.02, -0.01, 0.0]).astype(np.float32)
+    intr_rgb = np.asarray(wl.intr, np.float32) * np.float32(1.02)
+    snaps = {}
+    for name, api in (("gpu", gpu), ("oracle", oracle)):
+        s, rs, v = _fuse(api, pkg, wl, p, 4, M_rgb_of=lambda M: (T @ M).astype(np.float32), intr_rgb=intr_rgb)
+        snaps[name] = util.snapshot(api, s, rs)
+    util.assert_same_state(snaps["gpu"], snaps["oracle"], "separate RGB camera")
+    assert (snaps["gpu"]["voxels"]["w_color"] > 0).sum() > 1000
+
+
+def test_stop_integrating_at_max_w(pkg, synth, gpu, oracle):
+    wl = synth.s_tiny()
+    p = util.small_params(pkg, wl, max_w=2, stop_integrating_at_max_w=1)
+    snaps = {}
+    for name, api in (("gpu", gpu), ("oracle", oracle)):
+        s, rs, v = _fuse(api, pkg, wl, p, 5)
+        snaps[name] = util.snapshot(api, s, rs)
+    util.assert_same_state(snaps["gpu"], snaps["oracle"], "stopIntegratingAtMaxW")
+    assert snaps["gpu"]["voxels"]["w_depth"].max() == 2
+
+
+def test_empty_and_invalid_depth(pkg, synth, gpu, oracle):
+    wl = synth.s_tiny()
+    p = util.small_params(pkg, wl)
+    rgba, mm, M = wl.frame(0)
+    for depth in (np.zeros_like(mm), np.full_like(mm, -5), np.full_like(mm, 32500)):  # none, negative, > 32000 mm
+        snaps = {}
+        for name, api in (("gpu", gpu), ("oracle", oracle)):
+            s = api.create_scene(p)
+            rs = api.create_render_state(s, wl.W, wl.H)
+            v = api.create_view(wl.W, wl.H)
+            api.view_update(v, rgba, depth)
+            api.process_frame(s, v, rs, M, wl.intr)
+            snaps[name] = util.snapshot(api, s, rs)
+            snaps[name]["img"] = api.get_image(s, rs, M, wl.intr, pkg.IMAGE_DEPTH)
+        util.assert_same_state(snaps["gpu"], snaps["oracle"], "empty depth")
+        assert snaps["gpu"]["stats"]["no_visible_entries"] == 0 and (snaps["gpu"]["img"] == 0).all()
+
+
+def test_shards_partition_the_integration(pkg, synth, gpu):
+    """integrate(shard 0) then integrate(shard 1) over the same visible list == unsharded integrate."""
+    wl = synth.s_tiny()
+    p = util.small_params(pkg, wl)
+    rgba, mm, M = wl.frame(0)
+    res = []
+    for shards in (1, 2, 3):
+        s = gpu.create_scene(p)
+        rs = gpu.create_render_state(s, wl.W, wl.H)
+        v = gpu.create_view(wl.W, wl.H)
+        gpu.view_update(v, rgba, mm)
+        gpu.allocate_scene_from_depth(s, v, rs, M, wl.intr)
+        for k in range(shards):
+            gpu.set_shard(s, k, shards, 8)
+            gpu.integrate_into_scene(s, v, rs, M, wl.intr)
+        gpu.set_shard(s, 0, 1, 8)
+        res.append(gpu.download_voxel_blocks(s).view(np.uint64))
+    assert np.array_equal(res[0], res[1]) and np.array_equal(res[0], res[2])
+    assert (res[0] != 0x7FFF).sum() > 10000
+
+
+def test_full_size_properties_default_pools(pkg, synth, gpu):
+    """BASELINE frame size (640x480) and the upstream default pools (0x40000 blocks, 0x100000 + 0x20000 entries):
+    properties that need no oracle -- structural invariants, allocation idempotence, integrate o de-integrate =
+    identity, run-to-run determinism."""
+    wl = synth.s_street()
+    p = pkg.SceneParams(**wl.scene_kwargs)
+    runs = []
+    for rep in range(2):
+        s = gpu.create_scene(p)
+        rs = gpu.create_render_state(s, wl.W, wl.H)
+        v = gpu.create_view(wl.W, wl.H)
+        for i in range(3):
+            rgba, mm, M = wl.frame(i)
+            gpu.view_update(v, rgba, mm, timestamp=float(i))
+            gpu.process_frame(s, v, rs, M, wl.intr)
+        snap = util.snapshot(gpu, s, rs)
+        snap["depth"] = gpu.get_image(s, rs, M, wl.intr, pkg.IMAGE_DEPTH)
+        runs.append(snap)
+        if rep == 0:
+            util.check_invariants(snap, s.params)
+            assert snap["stats"]["no_visible_entries"] > 5000
+            # allocation idempotence: same frame again until collisions are resolved, then nothing new
+            prev = None
+            for it in range(8):
+                gpu.allocate_scene_from_depth(s, v, rs, M, wl.intr)
+                lf = gpu.stats(s, rs)["last_free_block_id"]
+                if lf == prev:
+                    break
+                prev = lf
+            assert it < 7
+            ids = gpu.download_visible_ids(rs)
+            assert (np.diff(ids) > 0).all()
+        for o in (s, rs, v):
+            o.close()
+    util.assert_same_state(runs[0], runs[1], "determinism at full size")
+    assert np.array_equal(runs[0]["depth"], runs[1]["depth"])
+    hit = runs[0]["depth"] > 0
+    true = wl.frame(2)[1].astype(np.float32) / 1000.0
+    ok = hit & (true > 0)
+    assert ok.mean() > 0.5 and np.median(np.abs(runs[0]["depth"] - true)[ok]) < 0.5 * wl.scene_kwargs["voxel_size"]
+    # integrate o de-integrate = identity on a fresh map (weights never clamp at 1 observation)
+    s = gpu.create_scene(p)
+    rs = gpu.create_render_state(s, wl.W, wl.H)
+    v = gpu.create_view(wl.W, wl.H)
+    rgba, mm, M = wl.frame(0)
+    gpu.view_update(v, rgba, mm)
+    gpu.process_frame(s, v, rs, M, wl.intr)
+    gpu.deprocess_frame(s, v, rs, M, wl.intr)
+    vox = gpu.download_voxel_blocks(s, 0x40000 - 9000, 9000).view(np.uint64)
+    assert (vox == 0x7FFF).all()
