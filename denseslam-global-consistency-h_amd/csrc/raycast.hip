@@ -554,7 +554,10 @@ __device__ __forceinline__ bool cast_ray(Vec4 &out, int x, int y, const RenderPa
   return pt_found;
 }
 
-template <int WAVES>
+// SHADE = false: raycast only / depth image -- the variant the fusion loop and the tracker use; it carries no
+// shading code, which keeps it at <= 64 VGPRs = 8 waves per SIMD (the march is latency-bound, occupancy is what
+// hides its load round trips).  SHADE = true adds the normal / colour modes.
+template <int WAVES, bool SHADE, bool DIAG = false>
 __global__ __launch_bounds__(WAVES * 64) void k_render(RenderParams p) {
   // one wavefront = one workgroup = an 8x8 pixel tile = exactly one cell of the 1/8-resolution range image.
   // Single-wave workgroups let the dispatcher backfill a SIMD the moment a short tile finishes (ray lengths vary
@@ -567,9 +570,9 @@ __global__ __launch_bounds__(WAVES * 64) void k_render(RenderParams p) {
   const int loc2 = (int)floorf((float)x / 8.0f) + (int)floorf((float)y / 8.0f) * p.W;
   Vec4 pr;
   int iters = 0;
-  const unsigned long long t_start = p.dbg_waves ? __builtin_amdgcn_s_memtime() : 0ull;
+  const unsigned long long t_start = DIAG ? __builtin_amdgcn_s_memtime() : 0ull;
   cast_ray(pr, x, y, p, p.range[loc2], iters);
-  if (p.dbg_waves) {  // diagnostic build path: never taken in normal runs
+  if (DIAG) {  // diagnostic instantiation (DSLAM_DBG_WAVETIME): per-wave cycles and march length
     const unsigned long long dt = __builtin_amdgcn_s_memtime() - t_start;
     int mx = iters;
     for (int d = 32; d > 0; d >>= 1) { const int o = __shfl_xor(mx, d, 64); mx = mx > o ? mx : o; }
@@ -593,6 +596,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_render(RenderParams p) {
     p.out_float[loc] = d;
     return;
   }
+  if (!SHADE) return;
   IndexCache c = {0x7fffffff, 0x7fffffff, 0x7fffffff, -1};
   Vec3 n = {0, 0, 0};
   float angle = 0.0f;
@@ -656,10 +660,15 @@ int launch_render(dslam_engine *e, const dslam_scene *s, dslam_render_state *r, 
     memset(dbg_host, 0, (size_t)n_waves * 16);
     rp.dbg_waves = dbg_host;
   }
+  const dim3 grid1((r->w + 7) / 8, (r->h + 7) / 8);
   if (rp.dbg_flags & 8)
-    hipLaunchKernelGGL(k_render<4>, dim3((r->w + 15) / 16, (r->h + 15) / 16), dim3(256), 0, e->stream, rp);
+    hipLaunchKernelGGL((k_render<4, true>), dim3((r->w + 15) / 16, (r->h + 15) / 16), dim3(256), 0, e->stream, rp);
+  else if (rp.dbg_waves)
+    hipLaunchKernelGGL((k_render<1, false, true>), grid1, dim3(64), 0, e->stream, rp);
+  else if (type == DSLAM_IMAGE_DEPTH || type < 0)
+    hipLaunchKernelGGL((k_render<1, false>), grid1, dim3(64), 0, e->stream, rp);
   else
-    hipLaunchKernelGGL(k_render<1>, dim3((r->w + 7) / 8, (r->h + 7) / 8), dim3(64), 0, e->stream, rp);
+    hipLaunchKernelGGL((k_render<1, true>), grid1, dim3(64), 0, e->stream, rp);
   DSLAM_HIP(hipGetLastError());
   if (dbg_host) {
     DSLAM_HIP(hipStreamSynchronize(e->stream));
@@ -727,7 +736,7 @@ int launch_icp_maps(dslam_engine *e, const dslam_scene *s, dslam_render_state *r
   int rc = fill_render_params(rp, s, r, M, intr, -1);
   if (rc) return rc;
   const dim3 grid((r->w + 15) / 16, (r->h + 15) / 16);
-  hipLaunchKernelGGL(k_render<1>, dim3((r->w + 7) / 8, (r->h + 7) / 8), dim3(64), 0, e->stream, rp);
+  hipLaunchKernelGGL((k_render<1, false>), dim3((r->w + 7) / 8, (r->h + 7) / 8), dim3(64), 0, e->stream, rp);
   hipLaunchKernelGGL(k_icp_maps, grid, dim3(256), 0, e->stream, r->raycast, r->w, r->h, s->p.voxel_size, -rp.invM.m[8],
                      -rp.invM.m[9], -rp.invM.m[10], r->icp_points, r->icp_normals);
   DSLAM_HIP(hipGetLastError());
