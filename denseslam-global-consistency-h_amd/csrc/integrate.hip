@@ -71,7 +71,6 @@ __device__ __forceinline__ void bilinear_rgb(const uchar4 *__restrict__ rgba, fl
   const float dx = px - (float)ix, dy = py - (float)iy;
   const uchar4 a = rgba[ix + iy * W], b = rgba[(ix + 1) + iy * W], c = rgba[ix + (iy + 1) * W],
                d = rgba[(ix + 1) + (iy + 1) * W];
-  const float w00 = (1.0f - dx) * (1.0f - dy), w10 = dx * (1.0f - dy), w01 = (1.0f - dx) * dy, w11 = dx * dy;
   // ((a*(1-dx))*(1-dy)) in the reference's evaluation order: the products are NOT regrouped
   out[0] = ((float)a.x * (1.0f - dx) * (1.0f - dy) + (float)b.x * dx * (1.0f - dy) + (float)c.x * (1.0f - dx) * dy +
             (float)d.x * dx * dy);
@@ -79,7 +78,6 @@ __device__ __forceinline__ void bilinear_rgb(const uchar4 *__restrict__ rgba, fl
             (float)d.y * dx * dy);
   out[2] = ((float)a.z * (1.0f - dx) * (1.0f - dy) + (float)b.z * dx * (1.0f - dy) + (float)c.z * (1.0f - dx) * dy +
             (float)d.z * dx * dy);
-  (void)w00; (void)w10; (void)w01; (void)w11;
 }
 
 // ComputeUpdatedVoxelInfo<hasColor>::compute on a packed voxel (lo, hi) whose camera-frame position pc = M_d * pm

@@ -464,7 +464,7 @@ struct RenderParams {
   float *out_float;
   int type;  // dslam_image_type, or -1: raycast only
   unsigned long long *dbg_waves;  // diagnostics only (env DSLAM_DBG_WAVETIME=<file>): per wave {cycles, max iterations}
-  int dbg_max_iter, dbg_flags;  // diagnostics only (env DSLAM_DBG_MAX_ITER / DSLAM_DBG_FLAGS); defaults never trigger
+  int dbg_flags;  // diagnostics only (env DSLAM_DBG_FLAGS: 4 = probe the bucket bitmap first, 8 = 16x16 workgroups)
 };
 
 __device__ __forceinline__ bool cast_ray(Vec4 &out, int x, int y, const RenderParams &p, const float2 minmax,
@@ -652,9 +652,8 @@ static int fill_render_params(RenderParams &rp, const dslam_scene *s, dslam_rend
   rp.W = r->w; rp.H = r->h;
   rp.range = r->range; rp.raycast = r->raycast; rp.out_rgba = r->image_rgba; rp.out_float = r->image_float;
   rp.type = type;
-  static const int dbg_iter = getenv("DSLAM_DBG_MAX_ITER") ? atoi(getenv("DSLAM_DBG_MAX_ITER")) : 0x7fffffff;
   static const int dbg_flags = getenv("DSLAM_DBG_FLAGS") ? atoi(getenv("DSLAM_DBG_FLAGS")) : 0;
-  rp.dbg_max_iter = dbg_iter; rp.dbg_flags = dbg_flags; rp.dbg_waves = nullptr;
+  rp.dbg_flags = dbg_flags; rp.dbg_waves = nullptr;
   // measured on MI355X: the bucket-occupancy bitmap does not pay in the ray march (125 vs 132 us: an extra load on
   // every hit outweighs the cheaper miss), so it is off unless DSLAM_DBG_FLAGS bit 2 asks for it
   if (!(dbg_flags & 4)) rp.vol.bucket_bits = nullptr;
