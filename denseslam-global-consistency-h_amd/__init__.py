@@ -29,8 +29,27 @@ def build(verbose=False):
     return LIB_PATH
 
 
+def _share_torch_hip_runtime():
+    """PyTorch-ROCm wheels bundle their own libamdhip64.so.7 + libhsa-runtime64; two HSA runtimes in one process
+    cannot both own the GPU ("No HIP GPUs are available" from whichever comes second).  Python callers of this
+    package use torch for device buffers and RCCL, so bind the engine to the runtime torch will use: load torch's
+    bundled HIP runtime first (same SONAME, so libdslam_fusion.so resolves to it) -- without importing torch."""
+    import ctypes
+    import importlib.util
+    import sys
+    if "torch" in sys.modules:
+        return  # its runtime is already the loaded libamdhip64.so.7
+    spec = importlib.util.find_spec("torch")
+    if spec is None or not spec.submodule_search_locations:
+        return
+    bundled = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+    if os.path.exists(bundled):
+        ctypes.CDLL(bundled, mode=ctypes.RTLD_GLOBAL)
+
+
 def open_engine(device=0):
     """Create a HIP engine on `device`.  Raises DslamError when the library or the GPU is missing."""
+    _share_torch_hip_runtime()
     return CApi(LIB_PATH, "dslam_", has_engine_device=True, device=device)
 
 

@@ -219,6 +219,45 @@ class CApi:
         self._call("view_update_device", self._engine, view.ptr, C.c_void_p(rgba_dev_ptr), C.c_void_p(depth_dev_ptr),
                    C.c_float(affine_a), C.c_float(affine_b), C.c_double(timestamp), C.c_int(int(bilateral)))
 
+    def view_update_bgr(self, view, bgr, depth_mm, affine_a=1.0 / 1000.0, affine_b=0.0, timestamp=0.0, bilateral=False):
+        """CvToItm + UpdateView: packed OpenCV BGR (H, W, 3) in, converted to RGBA on the device."""
+        bgr = np.ascontiguousarray(bgr, dtype=np.uint8)
+        depth_mm = np.ascontiguousarray(depth_mm, dtype=np.int16)
+        assert bgr.size == view.width * view.height * 3 and depth_mm.size == view.width_d * view.height_d
+        self._call("view_update_bgr", self._engine, view.ptr, _vptr(bgr), _vptr(depth_mm), C.c_float(affine_a),
+                   C.c_float(affine_b), C.c_double(timestamp), C.c_int(int(bilateral)))
+
+    def view_update_bgr_device(self, view, bgr_dev_ptr, depth_dev_ptr, affine_a=1.0 / 1000.0, affine_b=0.0,
+                               timestamp=0.0, bilateral=False):
+        self._call("view_update_bgr_device", self._engine, view.ptr, C.c_void_p(bgr_dev_ptr), C.c_void_p(depth_dev_ptr),
+                   C.c_float(affine_a), C.c_float(affine_b), C.c_double(timestamp), C.c_int(int(bilateral)))
+
+    def download_view_rgba(self, view):
+        out = np.empty((view.height, view.width, 4), dtype=np.uint8)
+        self._call("download_view_rgba", self._engine, view.ptr, _vptr(out))
+        return out
+
+    def depth_post_processing(self, curr_depth_mm, prev_depth_mm, Tpc, intr, filter_threshold, filter_area):
+        """DenseSlam::depthPostProcessing's pixel loop on host images; returns (filtered depth, count)."""
+        curr = np.array(curr_depth_mm, dtype=np.int16, order="C")
+        prev = np.ascontiguousarray(prev_depth_mm, dtype=np.int16)
+        assert curr.ndim == 2 and curr.shape == prev.shape
+        m, k = self._mi(Tpc, intr)
+        count = C.c_int(0)
+        self._call("depth_post_processing", self._engine, _vptr(curr), _vptr(prev), C.c_int(curr.shape[1]),
+                   C.c_int(curr.shape[0]), _fptr(m), _fptr(k), C.c_float(filter_threshold), C.c_float(filter_area),
+                   C.byref(count))
+        return curr, count.value
+
+    def depth_post_processing_device(self, curr_dev_ptr, prev_dev_ptr, width, height, Tpc, intr, filter_threshold,
+                                     filter_area, want_count=True):
+        m, k = self._mi(Tpc, intr)
+        count = C.c_int(0)
+        self._call("depth_post_processing_device", self._engine, C.c_void_p(curr_dev_ptr), C.c_void_p(prev_dev_ptr),
+                   C.c_int(width), C.c_int(height), _fptr(m), _fptr(k), C.c_float(filter_threshold),
+                   C.c_float(filter_area), C.byref(count) if want_count else None)
+        return count.value
+
     # -- fusion ----------------------------------------------------------------------------------------
     @staticmethod
     def _mi(M, intr):

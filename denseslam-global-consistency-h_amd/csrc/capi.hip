@@ -134,6 +134,7 @@ int dslam_engine_create(int device_index, dslam_engine **out) {
   e->pinned_bytes = 64 * 1024;
   DSLAM_HIP(hipHostMalloc(&e->pinned, e->pinned_bytes, hipHostMallocDefault));
   memset(e->pinned, 0, e->pinned_bytes);
+  DSLAM_HIP(hipMalloc(&e->misc_counter, 16 * sizeof(int)));
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, device_index) == hipSuccess) e->sm_count = prop.multiProcessorCount;
   *out = e;
@@ -150,6 +151,7 @@ int dslam_engine_destroy(dslam_engine *e) {
   if (e->staging_host) (void)hipHostFree(e->staging_host);
   if (e->pinned) (void)hipHostFree(e->pinned);
   if (e->timer_counts_dev) (void)hipFree(e->timer_counts_dev);
+  free_dev(e->misc_counter);
   for (auto ev : e->ev_pool) (void)hipEventDestroy(ev);
   (void)hipStreamDestroy(e->stream);
   (void)hipStreamDestroy(e->copy_stream);
@@ -322,39 +324,125 @@ int dslam_view_create(dslam_engine *e, int w_rgb, int h_rgb, int w_d, int h_d, d
 int dslam_view_destroy(dslam_view *v) {
   if (!v) return DSLAM_OK;
   (void)hipStreamSynchronize(v->engine->stream);
-  free_dev(v->rgba); free_dev(v->depth); free_dev(v->raw_depth);
+  free_dev(v->rgba); free_dev(v->depth); free_dev(v->raw_depth); free_dev(v->filter_tmp);
   delete v;
+  return DSLAM_OK;
+}
+
+// common tail of the UpdateView entry points: remember the sources; with useBilateralFilter the float depth image
+// is produced now (conversion + five filter passes), otherwise lazily by the next consumer
+static int finish_view_update(dslam_engine *e, dslam_view *v, const void *rgba_dev, const void *depth_dev, float a,
+                              float b, double timestamp, int use_bilateral) {
+  int rc = launch_view_convert(e, v, rgba_dev, depth_dev, a, b);
+  if (rc) return rc;
+  if (use_bilateral) {
+    DSLAM_REQUIRE(v->w_d >= 5 && v->h_d >= 5, "bilateral filter needs an image of at least 5x5");
+    if ((rc = launch_bilateral(e, v))) return rc;
+  }
+  v->timestamp = timestamp;
+  return finish_call(e);
+}
+
+static int upload_view_host(dslam_engine *e, dslam_view *v, const uint8_t *colour_host, int colour_channels,
+                            const int16_t *depth_host) {
+  const size_t c_bytes = (size_t)v->w_rgb * v->h_rgb * colour_channels, d_bytes = (size_t)v->w_d * v->h_d * 2;
+  int rc = ensure_staging(e, (size_t)v->w_rgb * v->h_rgb * 4 + d_bytes);
+  if (rc) return rc;
+  // the caller may reuse its buffers right after the call (CvToItm rewrites them every frame), so stage through
+  // pinned memory; in async mode the previous upload must have drained before the staging buffer is rewritten
+  DSLAM_HIP(hipStreamSynchronize(e->stream));
+  memcpy(e->staging_host, colour_host, c_bytes);
+  memcpy((char *)e->staging_host + c_bytes, depth_host, d_bytes);
+  void *colour_dst = colour_channels == 4 ? (void *)v->rgba : e->staging_dev;
+  DSLAM_HIP(hipMemcpyAsync(colour_dst, e->staging_host, c_bytes, hipMemcpyHostToDevice, e->stream));
+  DSLAM_HIP(hipMemcpyAsync(v->raw_depth, (char *)e->staging_host + c_bytes, d_bytes, hipMemcpyHostToDevice, e->stream));
+  if (colour_channels == 3) return launch_bgr_to_rgba(e, e->staging_dev, v->rgba, v->w_rgb * v->h_rgb);
   return DSLAM_OK;
 }
 
 int dslam_view_update(dslam_engine *e, dslam_view *v, const uint8_t *rgba_host, const int16_t *depth_host, float a,
                       float b, double timestamp, int use_bilateral) {
   DSLAM_REQUIRE(e && v && rgba_host && depth_host, "null argument");
-  if (use_bilateral) { set_last_error("bilateral depth filter is not implemented (ITMLibSettings default is off)"); return DSLAM_ERR_UNSUPPORTED; }
-  const size_t rgb_bytes = (size_t)v->w_rgb * v->h_rgb * 4, d_bytes = (size_t)v->w_d * v->h_d * 2;
-  int rc = ensure_staging(e, rgb_bytes + d_bytes);
+  int rc = upload_view_host(e, v, rgba_host, 4, depth_host);
   if (rc) return rc;
-  // the caller may reuse its buffers right after the call (CvToItm rewrites them every frame), so stage through
-  // pinned memory; in async mode the previous upload must have drained before the staging buffer is rewritten
-  DSLAM_HIP(hipStreamSynchronize(e->stream));
-  memcpy(e->staging_host, rgba_host, rgb_bytes);
-  memcpy((char *)e->staging_host + rgb_bytes, depth_host, d_bytes);
-  DSLAM_HIP(hipMemcpyAsync(v->rgba, e->staging_host, rgb_bytes, hipMemcpyHostToDevice, e->stream));
-  DSLAM_HIP(hipMemcpyAsync(v->raw_depth, (char *)e->staging_host + rgb_bytes, d_bytes, hipMemcpyHostToDevice, e->stream));
-  rc = launch_view_convert(e, v, v->rgba, v->raw_depth, a, b);
-  if (rc) return rc;
-  v->timestamp = timestamp;
-  return finish_call(e);
+  return finish_view_update(e, v, v->rgba, v->raw_depth, a, b, timestamp, use_bilateral);
 }
 
 int dslam_view_update_device(dslam_engine *e, dslam_view *v, const void *rgba_dev, const void *depth_dev, float a,
                              float b, double timestamp, int use_bilateral) {
   DSLAM_REQUIRE(e && v && rgba_dev && depth_dev, "null argument");
-  if (use_bilateral) { set_last_error("bilateral depth filter is not implemented"); return DSLAM_ERR_UNSUPPORTED; }
-  int rc = launch_view_convert(e, v, rgba_dev, depth_dev, a, b);
+  return finish_view_update(e, v, rgba_dev, depth_dev, a, b, timestamp, use_bilateral);
+}
+
+int dslam_view_update_bgr(dslam_engine *e, dslam_view *v, const uint8_t *bgr_host, const int16_t *depth_host, float a,
+                          float b, double timestamp, int use_bilateral) {
+  DSLAM_REQUIRE(e && v && bgr_host && depth_host, "null argument");
+  int rc = upload_view_host(e, v, bgr_host, 3, depth_host);
   if (rc) return rc;
-  v->timestamp = timestamp;
+  return finish_view_update(e, v, v->rgba, v->raw_depth, a, b, timestamp, use_bilateral);
+}
+
+int dslam_view_update_bgr_device(dslam_engine *e, dslam_view *v, const void *bgr_dev, const void *depth_dev, float a,
+                                 float b, double timestamp, int use_bilateral) {
+  DSLAM_REQUIRE(e && v && bgr_dev && depth_dev, "null argument");
+  DSLAM_REQUIRE(((uintptr_t)bgr_dev & 3) == 0, "bgr image must be 4-byte aligned");
+  int rc = launch_bgr_to_rgba(e, bgr_dev, v->rgba, v->w_rgb * v->h_rgb);
+  if (rc) return rc;
+  return finish_view_update(e, v, v->rgba, depth_dev, a, b, timestamp, use_bilateral);
+}
+
+int dslam_download_view_rgba(dslam_engine *e, const dslam_view *v, uint8_t *out) {
+  DSLAM_REQUIRE(e && v && out, "null argument");
+  DSLAM_HIP(hipMemcpyAsync(out, v->rgba_src, (size_t)v->w_rgb * v->h_rgb * 4, hipMemcpyDeviceToHost, e->stream));
+  DSLAM_HIP(hipStreamSynchronize(e->stream));
+  return DSLAM_OK;
+}
+
+// ---- depthPostProcessing -------------------------------------------------------------------------------------
+static int depth_post_args(dslam_engine *e, const void *curr, const void *prev, int w, int h, const float *Tpc,
+                           const float *intr) {
+  DSLAM_REQUIRE(e && curr && prev && Tpc && intr, "null argument");
+  DSLAM_REQUIRE(w > 0 && h > 0, "bad image size");
+  return DSLAM_OK;
+}
+
+int dslam_depth_post_processing_device(dslam_engine *e, void *curr_dev, const void *prev_dev, int w, int h,
+                                       const float Tpc[16], const float intr[4], float threshold, float area,
+                                       int *count_out) {
+  int rc = depth_post_args(e, curr_dev, prev_dev, w, h, Tpc, intr);
+  if (rc) return rc;
+  int *count_dev = e->misc_counter;
+  if ((rc = launch_depth_post(e, (short *)curr_dev, (const unsigned short *)prev_dev, w, h, Tpc, intr, threshold, area, count_dev))) return rc;
+  if (count_out) {
+    DSLAM_HIP(hipMemcpyAsync(e->pinned, count_dev, sizeof(int), hipMemcpyDeviceToHost, e->stream));
+    DSLAM_HIP(hipStreamSynchronize(e->stream));
+    *count_out = *(int *)e->pinned;
+    return DSLAM_OK;
+  }
   return finish_call(e);
+}
+
+int dslam_depth_post_processing(dslam_engine *e, int16_t *curr_host, const int16_t *prev_host, int w, int h,
+                                const float Tpc[16], const float intr[4], float threshold, float area,
+                                int *count_out) {
+  int rc = depth_post_args(e, curr_host, prev_host, w, h, Tpc, intr);
+  if (rc) return rc;
+  const size_t d_bytes = (size_t)w * h * 2;
+  if ((rc = ensure_staging(e, 2 * d_bytes))) return rc;
+  DSLAM_HIP(hipStreamSynchronize(e->stream));
+  memcpy(e->staging_host, curr_host, d_bytes);
+  memcpy((char *)e->staging_host + d_bytes, prev_host, d_bytes);
+  DSLAM_HIP(hipMemcpyAsync(e->staging_dev, e->staging_host, 2 * d_bytes, hipMemcpyHostToDevice, e->stream));
+  int *count_dev = e->misc_counter;
+  if ((rc = launch_depth_post(e, (short *)e->staging_dev, (const unsigned short *)((char *)e->staging_dev + d_bytes), w, h, Tpc,
+                              intr, threshold, area, count_dev)))
+    return rc;
+  DSLAM_HIP(hipMemcpyAsync(e->staging_host, e->staging_dev, d_bytes, hipMemcpyDeviceToHost, e->stream));
+  DSLAM_HIP(hipMemcpyAsync(e->pinned, count_dev, sizeof(int), hipMemcpyDeviceToHost, e->stream));
+  DSLAM_HIP(hipStreamSynchronize(e->stream));
+  memcpy(curr_host, e->staging_host, d_bytes);
+  if (count_out) *count_out = *(int *)e->pinned;
+  return DSLAM_OK;
 }
 
 // ---- fusion --------------------------------------------------------------------------------------------------

@@ -66,6 +66,7 @@ struct dslam_engine {
   long long timer_blocks = 0;
   int *timer_counts_dev = nullptr;    // visible-block count of each timed launch (written by the kernel)
   int sm_count = 256;
+  int *misc_counter = nullptr;        // device: small result counters of one-off kernels (depthPostProcessing)
 };
 
 struct dslam_scene {
@@ -121,6 +122,7 @@ struct dslam_view {
   uchar4 *rgba = nullptr;       // own buffers (host uploads land here)
   float *depth = nullptr;
   short *raw_depth = nullptr;
+  float *filter_tmp = nullptr;  // ITMViewBuilder::floatImage, allocated when the bilateral filter is first used
   // what the kernels read: own buffers, or the caller's resident frame (dslam_view_update_device: no copy)
   const uchar4 *rgba_src = nullptr;
   const short *raw_src = nullptr;
@@ -134,6 +136,10 @@ namespace dslam {
 int launch_scene_reset(dslam_engine *e, dslam_scene *s);
 int launch_rebuild_bucket_bits(dslam_engine *e, dslam_scene *s);
 int launch_view_convert(dslam_engine *e, dslam_view *v, const void *rgba_dev, const void *depth_dev, float a, float b);
+int launch_bgr_to_rgba(dslam_engine *e, const void *bgr_dev, uchar4 *rgba_dev, int npix);
+int launch_bilateral(dslam_engine *e, dslam_view *v);
+int launch_depth_post(dslam_engine *e, short *curr_dev, const unsigned short *prev_dev, int cols, int rows,
+                      const float *Tpc, const float *intr, float threshold, float area, int *count_dev);
 int launch_allocate(dslam_engine *e, dslam_scene *s, const dslam_view *v, dslam_render_state *r, const float *M_d,
                     const float *intr, int only_update_visible_list);
 // push_ring >= 0: also queue the frame's visible list on that ring (fused into the integrate kernel)

@@ -155,12 +155,39 @@ int dslam_view_destroy(dslam_view *v);
 /* viewBuilder->UpdateView(&view, rgb, rawDepth, timestamp, useBilateralFilter)
  * (InfiniTamDriver.cpp:280-288).  rgba: Vector4u per pixel as written by CvToItm (:84-103);
  * depth_mm: int16 millimetres (:106-110); depth_m = d<=0 ? -1 : d*affine_a + affine_b with
- * (a,b) = (1/1000, 0) from CreateItmCalib (:58,79). */
+ * (a,b) = (1/1000, 0) from CreateItmCalib (:58,79).
+ * use_bilateral_filter: ITMViewBuilder's five passes of the 5x5 bilateral depth filter (upstream InfiniTAM v2
+ * filterDepth); the filtered image keeps upstream's 2-pixel border of 0 (= no measurement). */
 int dslam_view_update(dslam_engine *e, dslam_view *v, const uint8_t *rgba_host, const int16_t *depth_mm_host,
                       float affine_a, float affine_b, double timestamp, int use_bilateral_filter);
 /* same, inputs already resident in HBM (frame database kept on device). */
 int dslam_view_update_device(dslam_engine *e, dslam_view *v, const void *rgba_dev, const void *depth_mm_dev,
                              float affine_a, float affine_b, double timestamp, int use_bilateral_filter);
+
+/* CvToItm(const cv::Mat3b&, ITMUChar4Image*) fused into UpdateView (InfiniTamDriver.cpp:84-103, 280-288): the
+ * colour image arrives as OpenCV packed BGR (3 bytes per pixel, rows contiguous) and is converted to RGBA with
+ * a = 255 on the device.  The _device variant needs a 4-byte aligned image. */
+int dslam_view_update_bgr(dslam_engine *e, dslam_view *v, const uint8_t *bgr_host, const int16_t *depth_mm_host,
+                          float affine_a, float affine_b, double timestamp, int use_bilateral_filter);
+int dslam_view_update_bgr_device(dslam_engine *e, dslam_view *v, const void *bgr_dev, const void *depth_mm_dev,
+                                 float affine_a, float affine_b, double timestamp, int use_bilateral_filter);
+/* test / debug read-back of the view's RGBA image (what IntegrateIntoScene will read). */
+int dslam_download_view_rgba(dslam_engine *e, const dslam_view *v, uint8_t *out_rgba);
+
+/* DenseSlam::depthPostProcessing's pixel loop (DenseSlam.cpp:488-529): blanks (sets to 0) every pixel of the
+ * current keyframe's depth whose reprojection into the previous keyframe disagrees with that keyframe's depth by
+ * more than `filter_threshold` (relative) and which lies below row `filter_area * rows`
+ * (PostPocessParams, VoxelDecayParams.h:38-46).  Tpc = prev_pose.inv() * curr_pose (DenseSlam.cpp:507), column-major
+ * like every matrix of this ABI; intrinsics = (fx, fy, cx, cy) of projection_left_rgb_ (:436-439).  The reference
+ * pairs `row` with cx/fx and `col` with cy/fy (:500-513); that pairing is reproduced.  curr is updated in place;
+ * *count_out (optional) receives the reference's `count` (pixels compared).  Host variant: cv::Mat1s buffers;
+ * device variant: frames resident in HBM (frame database on device). */
+int dslam_depth_post_processing(dslam_engine *e, int16_t *curr_depth_mm_host, const int16_t *prev_depth_mm_host,
+                                int width, int height, const float Tpc[16], const float intrinsics[4],
+                                float filter_threshold, float filter_area, int *count_out);
+int dslam_depth_post_processing_device(dslam_engine *e, void *curr_depth_mm_dev, const void *prev_depth_mm_dev,
+                                       int width, int height, const float Tpc[16], const float intrinsics[4],
+                                       float filter_threshold, float filter_area, int *count_out);
 
 /* ---- fusion ------------------------------------------------------------------------------------ */
 /* denseMapper->SetFusionWeightParams(...)  (InfiniTamDriver.h:189,196) */

@@ -176,6 +176,7 @@ struct oracle_view {
   int w_rgb, h_rgb, w_d, h_d;
   std::vector<uint8_t> rgba;
   std::vector<float> depth;
+  std::vector<float> float_image;  // ITMViewBuilder::floatImage (bilateral filter scratch)
   double timestamp;
 };
 
@@ -557,17 +558,146 @@ extern "C" int oracle_view_create(oracle_engine *, int w_rgb, int h_rgb, int w_d
 }
 extern "C" int oracle_view_destroy(oracle_view *v) { delete v; return 0; }
 
-// viewBuilder->UpdateView (InfiniTamDriver.cpp:280-288; SURVEY A.3): convertDepthAffineToFloat
-extern "C" int oracle_view_update(oracle_engine *, oracle_view *v, const uint8_t *rgba, const int16_t *depth_mm, float a,
-                       float b, double timestamp, int use_bilateral) {
-  if (use_bilateral) return DSLAM_ERR_UNSUPPORTED;
-  memcpy(v->rgba.data(), rgba, v->rgba.size());
-  size_t n = (size_t)v->w_d * v->h_d;
+// exp(x) for x <= 0 as a fixed operation sequence (Cody-Waite reduction, degree-6 polynomial in explicit FMAs, exact
+// power-of-two scaling), within 1 ulp of libm's expf (tests/test_oracle_kat.py).  The HIP filter kernel runs the
+// same sequence, which makes the bilateral filter -- the only transcendental on the path -- bit-identical on host
+// and device.  x < -86 returns 0: next to the centre tap's weight of exactly 1 such a weight never reaches the sums.
+static float det_exp(float x) {
+  if (x < -86.0f) return 0.0f;
+  const float n = rintf(x * 1.44269504f);
+  float r = fmaf(-n, 0.693359375f, x);
+  r = fmaf(-n, -2.12194440e-4f, r);
+  float p = 1.9875691500e-4f;
+  p = fmaf(p, r, 1.3981999507e-3f);
+  p = fmaf(p, r, 8.3334519073e-3f);
+  p = fmaf(p, r, 4.1665795894e-2f);
+  p = fmaf(p, r, 1.6666665459e-1f);
+  p = fmaf(p, r, 5.0000001201e-1f);
+  const float y = fmaf(p, r * r, r) + 1.0f;
+  const int32_t bits = ((int32_t)n + 127) << 23;
+  float scale;
+  memcpy(&scale, &bits, 4);
+  return y * scale;
+}
+extern "C" float oracle_det_exp(float x) { return det_exp(x); }
+
+// filterDepth (upstream InfiniTAM v2 ITMViewBuilder_Shared.h; [UPSTREAM-RECALL]) over the interior; border pixels
+// of `out` are left alone, as upstream's loop bounds do
+static void filter_depth_pass(const float *in, float *out, int W, int H) {
+  const float MEAN_SIGMA_L = 1.2232f;
+#pragma omp parallel for schedule(static)
+  for (int y = 2; y < H - 2; y++)
+    for (int x = 2; x < W - 2; x++) {
+      const float z = in[x + y * W];
+      if (z < 0.0f) { out[x + y * W] = -1.0f; continue; }
+      const float sigma_z = 1.0f / (0.0012f + 0.0019f * (z - 0.4f) * (z - 0.4f) + 0.0001f / sqrtf(z) * 0.25f);
+      float final_depth = 0.0f, w_sum = 0.0f;
+      for (int i = -2; i <= 2; i++)
+        for (int j = -2; j <= 2; j++) {
+          const float tmpz = in[(x + j) + (y + i) * W];
+          if (tmpz < 0.0f) continue;
+          float dz = tmpz - z;
+          dz *= dz;
+          const float w = det_exp(-0.5f * ((float)(abs(i) + abs(j)) * MEAN_SIGMA_L * MEAN_SIGMA_L + dz * sigma_z * sigma_z));
+          w_sum += w;
+          final_depth += w * tmpz;
+        }
+      out[x + y * W] = final_depth / w_sum;
+    }
+}
+
+static int view_finish(oracle_view *v, const int16_t *depth_mm, float a, float b, double timestamp, int use_bilateral) {
+  const size_t n = (size_t)v->w_d * v->h_d;
   for (size_t i = 0; i < n; i++) {
     int d = depth_mm[i];
     v->depth[i] = (d <= 0 || d > 32000) ? -1.0f : (float)d * a + b;
   }
+  if (use_bilateral) {
+    // ITMViewBuilder::UpdateView: DepthFiltering(floatImage <- depth), (depth <- floatImage), ... five passes, then
+    // depth = floatImage.  floatImage is zero-initialised and its border is never written
+    if (v->w_d < 5 || v->h_d < 5) return DSLAM_ERR_INVALID;
+    if (v->float_image.size() != n) v->float_image.assign(n, 0.0f);
+    float *A = v->depth.data(), *B = v->float_image.data();
+    filter_depth_pass(A, B, v->w_d, v->h_d);
+    filter_depth_pass(B, A, v->w_d, v->h_d);
+    filter_depth_pass(A, B, v->w_d, v->h_d);
+    filter_depth_pass(B, A, v->w_d, v->h_d);
+    filter_depth_pass(A, B, v->w_d, v->h_d);
+    v->depth = v->float_image;
+  }
   v->timestamp = timestamp;
+  return 0;
+}
+
+// viewBuilder->UpdateView (InfiniTamDriver.cpp:280-288; SURVEY A.3): convertDepthAffineToFloat
+extern "C" int oracle_view_update(oracle_engine *, oracle_view *v, const uint8_t *rgba, const int16_t *depth_mm, float a,
+                       float b, double timestamp, int use_bilateral) {
+  memcpy(v->rgba.data(), rgba, v->rgba.size());
+  return view_finish(v, depth_mm, a, b, timestamp, use_bilateral);
+}
+
+// CvToItm(cv::Mat3b) + UpdateView (InfiniTamDriver.cpp:84-103, 280-288)
+extern "C" int oracle_view_update_bgr(oracle_engine *, oracle_view *v, const uint8_t *bgr, const int16_t *depth_mm, float a,
+                           float b, double timestamp, int use_bilateral) {
+  const size_t n = (size_t)v->w_rgb * v->h_rgb;
+  for (size_t i = 0; i < n; i++) {
+    v->rgba[4 * i + 2] = bgr[3 * i];      // .b = col[0]
+    v->rgba[4 * i + 1] = bgr[3 * i + 1];  // .g = col[1]
+    v->rgba[4 * i + 0] = bgr[3 * i + 2];  // .r = col[2]
+    v->rgba[4 * i + 3] = 255u;
+  }
+  return view_finish(v, depth_mm, a, b, timestamp, use_bilateral);
+}
+
+extern "C" int oracle_download_view_rgba(oracle_engine *, const oracle_view *v, uint8_t *out) {
+  memcpy(out, v->rgba.data(), v->rgba.size());
+  return 0;
+}
+
+// DenseSlam::depthPostProcessing, the pixel loop (DenseSlam.cpp:488-529).  Arithmetic types follow the C++ of the
+// reference: floats from cv::Mat CV_32F elements, doubles where a double literal enters the expression; cv::Mat
+// products of CV_32F operands accumulate in double and round once (OpenCV's GEMMSingleMul<float,double>) [recalled:
+// OpenCV is not in this image].  `row` goes with cx/fx and `col` with cy/fy, as written there.  The double -> int
+// conversions saturate (undefined in C when out of range; such projections fail the bounds test either way).
+static int d2i_sat(double v) {
+  if (!(v == v)) return INT_MIN;
+  if (v >= 2147483647.0) return INT_MAX;
+  if (v <= -2147483648.0) return INT_MIN;
+  return (int)v;
+}
+extern "C" int oracle_depth_post_processing(oracle_engine *, int16_t *curr, const int16_t *prev_s, int cols, int rows,
+                                 const float *Tpc, const float *intr, float threshold, float area, int *count_out) {
+  const uint16_t *prev = (const uint16_t *)prev_s;  // prev_depth.at<uint16_t>(row_u, col_v)  (:515)
+  const float fx = intr[0], fy = intr[1], cx = intr[2], cy = intr[3];
+  const float inv_fx = (float)(1.0 / fx), inv_fy = (float)(1.0 / fy);  // (:440-441)
+  float R[9], t[3];
+  for (int r = 0; r < 3; r++) {
+    for (int c = 0; c < 3; c++) R[3 * r + c] = Tpc[c * 4 + r];
+    t[r] = Tpc[12 + r];
+  }
+  int count = 0;
+  for (int row = 0; row < rows; row++)
+    for (int col = 0; col < cols; col++) {
+      const float z = (float)(((float)curr[row * cols + col]) / 1000.0);
+      if (z < 0.005) continue;
+      const float X = z * (row - cx) * inv_fx;
+      const float Y = z * (col - cy) * inv_fy;
+      float P[3];
+      for (int k = 0; k < 3; k++) {
+        const double acc = (double)R[3 * k] * X + (double)R[3 * k + 1] * Y + (double)R[3 * k + 2] * z;
+        P[k] = (float)acc + t[k];
+      }
+      const int row_u = d2i_sat(fx * P[0] * (1.0 / P[2]) + cx + 0.5);
+      const int col_v = d2i_sat(fy * P[1] * (1.0 / P[2]) + cy + 0.5);
+      if (row_u < 0.1 || col_v < 0.1 || (row_u + 1) > rows || (col_v + 1) > cols) continue;
+      const float prev_z = (float)((float)prev[row_u * cols + col_v] / 1000.0);
+      if (prev_z < 0.005) continue;
+      const float curr_z = P[2];
+      const float diff = fabsf(prev_z - curr_z);
+      if ((diff / curr_z) > threshold && row > area * rows) curr[row * cols + col] = 0;
+      count++;
+    }
+  if (count_out) *count_out = count;
   return 0;
 }
 
