@@ -102,6 +102,10 @@ class View(_Handle):
     pass
 
 
+class FrameStore(_Handle):
+    pass
+
+
 class CApi:
     """One bound library.  Also plays the role of the engine handle (one engine per CApi instance)."""
 
@@ -231,6 +235,42 @@ class CApi:
                                timestamp=0.0, bilateral=False):
         self._call("view_update_bgr_device", self._engine, view.ptr, C.c_void_p(bgr_dev_ptr), C.c_void_p(depth_dev_ptr),
                    C.c_float(affine_a), C.c_float(affine_b), C.c_double(timestamp), C.c_int(int(bilateral)))
+
+    # -- keyframe store ----------------------------------------------------------------------------------
+    def create_frame_store(self, width, height, capacity, width_d=None, height_d=None):
+        h = C.c_void_p()
+        width_d = width if width_d is None else width_d
+        height_d = height if height_d is None else height_d
+        self._call("frame_store_create", self._engine, C.c_int(width), C.c_int(height), C.c_int(width_d),
+                   C.c_int(height_d), C.c_int(capacity), C.byref(h))
+        fs = FrameStore(self, h, self._fn("frame_store_destroy"))
+        fs.width, fs.height, fs.width_d, fs.height_d, fs.capacity = width, height, width_d, height_d, capacity
+        return fs
+
+    def frame_store_put(self, fs, slot, rgba, depth_mm):
+        rgba = np.ascontiguousarray(rgba, dtype=np.uint8)
+        depth_mm = np.ascontiguousarray(depth_mm, dtype=np.int16)
+        assert rgba.size == fs.width * fs.height * 4 and depth_mm.size == fs.width_d * fs.height_d
+        self._call("frame_store_put", self._engine, fs.ptr, C.c_int(slot), _vptr(rgba), _vptr(depth_mm))
+
+    def frame_store_put_bgr(self, fs, slot, bgr, depth_mm):
+        bgr = np.ascontiguousarray(bgr, dtype=np.uint8)
+        depth_mm = np.ascontiguousarray(depth_mm, dtype=np.int16)
+        assert bgr.size == fs.width * fs.height * 3 and depth_mm.size == fs.width_d * fs.height_d
+        self._call("frame_store_put_bgr", self._engine, fs.ptr, C.c_int(slot), _vptr(bgr), _vptr(depth_mm))
+
+    def frame_store_put_view(self, fs, slot, view):
+        self._call("frame_store_put_view", self._engine, fs.ptr, C.c_int(slot), view.ptr)
+
+    def frame_store_get(self, fs, slot):
+        rgba = np.empty((fs.height, fs.width, 4), dtype=np.uint8)
+        depth = np.empty((fs.height_d, fs.width_d), dtype=np.int16)
+        self._call("frame_store_get", self._engine, fs.ptr, C.c_int(slot), _vptr(rgba), _vptr(depth))
+        return rgba, depth
+
+    def view_update_from_store(self, view, fs, slot, affine_a=1.0 / 1000.0, affine_b=0.0, timestamp=0.0, bilateral=False):
+        self._call("view_update_from_store", self._engine, view.ptr, fs.ptr, C.c_int(slot), C.c_float(affine_a),
+                   C.c_float(affine_b), C.c_double(timestamp), C.c_int(int(bilateral)))
 
     def download_view_rgba(self, view):
         out = np.empty((view.height, view.width, 4), dtype=np.uint8)

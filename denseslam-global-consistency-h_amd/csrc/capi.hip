@@ -398,6 +398,98 @@ int dslam_download_view_rgba(dslam_engine *e, const dslam_view *v, uint8_t *out)
   return DSLAM_OK;
 }
 
+// ---- keyframe store (fusion-frame database payload resident in HBM) -------------------------------------------
+int dslam_frame_store_create(dslam_engine *e, int w_rgb, int h_rgb, int w_d, int h_d, int capacity, dslam_frame_store **out) {
+  DSLAM_REQUIRE(e && out && w_rgb > 0 && h_rgb > 0 && w_d > 0 && h_d > 0 && capacity > 0, "bad argument");
+  dslam_frame_store *fs = new dslam_frame_store();
+  fs->engine = e; fs->w_rgb = w_rgb; fs->h_rgb = h_rgb; fs->w_d = w_d; fs->h_d = h_d; fs->capacity = capacity;
+  // slots are padded to 256 bytes so every image starts on an aligned address whatever the image size
+  fs->rgba_bytes = ((size_t)w_rgb * h_rgb * 4 + 255) & ~(size_t)255;
+  fs->depth_bytes = ((size_t)w_d * h_d * 2 + 255) & ~(size_t)255;
+  hipError_t err = hipMalloc(&fs->rgba, fs->rgba_bytes * capacity);
+  if (err == hipSuccess) err = hipMalloc(&fs->depth, fs->depth_bytes * capacity);
+  if (err != hipSuccess) {
+    free_dev(fs->rgba); free_dev(fs->depth);
+    delete fs;
+    set_last_error("frame store: out of device memory");
+    return DSLAM_ERR_HIP;
+  }
+  *out = fs;
+  return DSLAM_OK;
+}
+
+int dslam_frame_store_destroy(dslam_frame_store *fs) {
+  if (!fs) return DSLAM_OK;
+  (void)hipStreamSynchronize(fs->engine->stream);
+  free_dev(fs->rgba); free_dev(fs->depth);
+  delete fs;
+  return DSLAM_OK;
+}
+
+static int store_slot_ok(const dslam_engine *e, const dslam_frame_store *fs, int slot) {
+  DSLAM_REQUIRE(e && fs && fs->engine == e, "frame store belongs to a different engine");
+  DSLAM_REQUIRE(slot >= 0 && slot < fs->capacity, "frame store slot out of range");
+  return DSLAM_OK;
+}
+
+static int store_put_host(dslam_engine *e, dslam_frame_store *fs, int slot, const uint8_t *colour, int channels, const int16_t *depth) {
+  int rc = store_slot_ok(e, fs, slot);
+  if (rc) return rc;
+  DSLAM_REQUIRE(colour && depth, "null argument");
+  const size_t c_bytes = (size_t)fs->w_rgb * fs->h_rgb * channels, d_bytes = (size_t)fs->w_d * fs->h_d * 2;
+  if ((rc = ensure_staging(e, (size_t)fs->w_rgb * fs->h_rgb * 4 + d_bytes))) return rc;
+  DSLAM_HIP(hipStreamSynchronize(e->stream));
+  memcpy(e->staging_host, colour, c_bytes);
+  memcpy((char *)e->staging_host + c_bytes, depth, d_bytes);
+  unsigned char *rgba_dst = fs->rgba + fs->rgba_bytes * slot;
+  DSLAM_HIP(hipMemcpyAsync(channels == 4 ? (void *)rgba_dst : e->staging_dev, e->staging_host, c_bytes, hipMemcpyHostToDevice, e->stream));
+  DSLAM_HIP(hipMemcpyAsync(fs->depth + fs->depth_bytes * slot, (char *)e->staging_host + c_bytes, d_bytes, hipMemcpyHostToDevice, e->stream));
+  if (channels == 3 && (rc = launch_bgr_to_rgba(e, e->staging_dev, (uchar4 *)rgba_dst, fs->w_rgb * fs->h_rgb))) return rc;
+  return finish_call(e);
+}
+
+int dslam_frame_store_put(dslam_engine *e, dslam_frame_store *fs, int slot, const uint8_t *rgba_host, const int16_t *depth_host) {
+  return store_put_host(e, fs, slot, rgba_host, 4, depth_host);
+}
+int dslam_frame_store_put_bgr(dslam_engine *e, dslam_frame_store *fs, int slot, const uint8_t *bgr_host, const int16_t *depth_host) {
+  return store_put_host(e, fs, slot, bgr_host, 3, depth_host);
+}
+
+int dslam_frame_store_put_view(dslam_engine *e, dslam_frame_store *fs, int slot, const dslam_view *v) {
+  int rc = store_slot_ok(e, fs, slot);
+  if (rc) return rc;
+  DSLAM_REQUIRE(v && v->engine == e, "null argument");
+  DSLAM_REQUIRE(v->w_rgb == fs->w_rgb && v->h_rgb == fs->h_rgb && v->w_d == fs->w_d && v->h_d == fs->h_d, "view and frame store sizes differ");
+  DSLAM_HIP(hipMemcpyAsync(fs->rgba + fs->rgba_bytes * slot, v->rgba_src, (size_t)fs->w_rgb * fs->h_rgb * 4, hipMemcpyDeviceToDevice, e->stream));
+  DSLAM_HIP(hipMemcpyAsync(fs->depth + fs->depth_bytes * slot, v->raw_src, (size_t)fs->w_d * fs->h_d * 2, hipMemcpyDeviceToDevice, e->stream));
+  return finish_call(e);
+}
+
+int dslam_frame_store_get(dslam_engine *e, const dslam_frame_store *fs, int slot, uint8_t *rgba_out, int16_t *depth_out) {
+  int rc = store_slot_ok(e, fs, slot);
+  if (rc) return rc;
+  if (rgba_out) DSLAM_HIP(hipMemcpyAsync(rgba_out, fs->rgba + fs->rgba_bytes * slot, (size_t)fs->w_rgb * fs->h_rgb * 4, hipMemcpyDeviceToHost, e->stream));
+  if (depth_out) DSLAM_HIP(hipMemcpyAsync(depth_out, fs->depth + fs->depth_bytes * slot, (size_t)fs->w_d * fs->h_d * 2, hipMemcpyDeviceToHost, e->stream));
+  DSLAM_HIP(hipStreamSynchronize(e->stream));
+  return DSLAM_OK;
+}
+
+int dslam_frame_store_device_ptrs(const dslam_frame_store *fs, int slot, void **rgba_dev, void **depth_dev) {
+  DSLAM_REQUIRE(fs && slot >= 0 && slot < fs->capacity, "frame store slot out of range");
+  if (rgba_dev) *rgba_dev = fs->rgba + fs->rgba_bytes * slot;
+  if (depth_dev) *depth_dev = fs->depth + fs->depth_bytes * slot;
+  return DSLAM_OK;
+}
+
+int dslam_view_update_from_store(dslam_engine *e, dslam_view *v, const dslam_frame_store *fs, int slot, float a, float b,
+                                 double timestamp, int use_bilateral) {
+  int rc = store_slot_ok(e, fs, slot);
+  if (rc) return rc;
+  DSLAM_REQUIRE(v && v->engine == e, "null argument");
+  DSLAM_REQUIRE(v->w_rgb == fs->w_rgb && v->h_rgb == fs->h_rgb && v->w_d == fs->w_d && v->h_d == fs->h_d, "view and frame store sizes differ");
+  return finish_view_update(e, v, fs->rgba + fs->rgba_bytes * slot, fs->depth + fs->depth_bytes * slot, a, b, timestamp, use_bilateral);
+}
+
 // ---- depthPostProcessing -------------------------------------------------------------------------------------
 static int depth_post_args(dslam_engine *e, const void *curr, const void *prev, int w, int h, const float *Tpc,
                            const float *intr) {

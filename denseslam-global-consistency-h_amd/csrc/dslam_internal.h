@@ -131,6 +131,16 @@ struct dslam_view {
   double timestamp = 0;
 };
 
+// mfusionFrameDataBase's image payload (fusionFrameInfo::rgbinfo / depthinfo, DenseSlam.h:431-433) kept in HBM:
+// `capacity` slots of one RGBA image + one int16 depth image each, in two contiguous arrays
+struct dslam_frame_store {
+  dslam_engine *engine = nullptr;
+  int w_rgb = 0, h_rgb = 0, w_d = 0, h_d = 0, capacity = 0;
+  size_t rgba_bytes = 0, depth_bytes = 0;  // per slot
+  unsigned char *rgba = nullptr;
+  unsigned char *depth = nullptr;
+};
+
 namespace dslam {
 // kernels' host launchers (one translation unit per subsystem)
 int launch_scene_reset(dslam_engine *e, dslam_scene *s);

@@ -115,3 +115,116 @@ def make_numpy_all_gather(api, scene, dist, chunk_blocks):
         merged = np.ascontiguousarray(recv.numpy().transpose(1, 0, 2))
         api.upload_voxel_blocks(scene, lo, merged.view(vox.dtype).reshape(n, 512))
     return run
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# DenseSlam::OnlineCorrection's scheduler (reference DenseSlam.cpp:298-432) over a device-resident keyframe store.
+# The C++ counterpart a maintainer links against is itmlib/DenseSLAM/OnlineCorrection.h; this is the same logic for
+# the Python harnesses (bench --reint, the gloo test), engine-agnostic like the rest of this module.
+# ---------------------------------------------------------------------------------------------------------------------
+def se3_log(T):
+    """(translation part u, rotation vector w) of the se(3) logarithm of a 4x4 rigid transform (float64)."""
+    T = np.asarray(T, np.float64)
+    R, t = T[:3, :3], T[:3, 3]
+    c = min(1.0, max(-1.0, (np.trace(R) - 1.0) * 0.5))
+    angle = np.arccos(c)
+    w = 0.5 * np.array([R[2, 1] - R[1, 2], R[0, 2] - R[2, 0], R[1, 0] - R[0, 1]])
+    s = np.linalg.norm(w)
+    if s > 1e-12:
+        w = w * (angle / s)
+    u = t.copy()
+    if angle > 1e-9:
+        K = np.array([[0, -w[2], w[1]], [w[2], 0, -w[0]], [-w[1], w[0], 0]])
+        half_cot = 0.5 * angle * np.sin(angle) / (1.0 - np.cos(angle))
+        u = t - 0.5 * (K @ t) + ((1.0 - half_cot) / angle ** 2) * (K @ K @ t)
+    return u, w
+
+
+def pose_error(pre_Twc, cur_Twc):
+    """sqrt(trace(E W E^T)), W = diag(.5,.5,.5,1), E = hat(log(pre^-1 cur)) (DenseSlam.cpp:322-357)
+    = sqrt(|rotation vector|^2 + |translation part|^2)."""
+    u, w = se3_log(np.linalg.inv(np.asarray(pre_Twc, np.float64)) @ np.asarray(cur_Twc, np.float64))
+    return float(np.sqrt(w @ w + u @ u))
+
+
+class FusionFrameDatabase:
+    """mfusionFrameDataBase (DenseSlam.h:431-433) with the images in a keyframe store on the engine's device."""
+
+    def __init__(self, api, width, height, capacity, pose_to_M=None):
+        self.api = api
+        self.store = api.create_frame_store(width, height, capacity)
+        self.entries = {}  # timestamp -> [Twc, slot, flag]
+        self.free = list(range(capacity - 1, -1, -1))
+        self.pose_to_M = pose_to_M or (lambda Twc: np.linalg.inv(np.asarray(Twc, np.float64)).astype(np.float32))
+
+    def __len__(self):
+        return len(self.entries)
+
+    def _slot_for(self, ts):
+        if ts in self.entries:
+            return self.entries[ts][1]
+        if not self.free:
+            raise RuntimeError("keyframe store full")
+        return self.free.pop()
+
+    def insert_from_view(self, ts, Twc, view):
+        slot = self._slot_for(ts)
+        self.api.frame_store_put_view(self.store, slot, view)
+        self.entries[ts] = [np.array(Twc, np.float32), slot, 0]
+        return slot
+
+    def insert(self, ts, Twc, rgba, depth_mm):
+        slot = self._slot_for(ts)
+        self.api.frame_store_put(self.store, slot, rgba, depth_mm)
+        self.entries[ts] = [np.array(Twc, np.float32), slot, 0]
+        return slot
+
+    def _erase(self, ts):
+        self.free.append(self.entries.pop(ts)[1])
+
+    def slide_window_pose(self, max_age):
+        """DenseSlam::SlideWindowPose (DenseSlam.cpp:284-296): drop the oldest entries until max_age remain."""
+        for ts in sorted(self.entries)[:max(0, len(self.entries) - max_age)]:
+            self._erase(ts)
+
+    def plan(self, keyframes, correction_num, start_to_correction_num, identity_eps=0.0):
+        """The selection half of OnlineCorrection: returns ([(ts, new Twc)] in re-fusion order, [culled ts]).
+        keyframes: iterable of (timestamp, Twc, is_bad).  Marks flags like the reference does."""
+        errors = {}
+        for ts, Twc, bad in keyframes:
+            if bad or ts not in self.entries:
+                continue
+            ent = self.entries[ts]
+            ent[2] = 1
+            err = pose_error(ent[0], Twc)
+            if err <= identity_eps:
+                continue  # is_identity_matrix(poseDiff)
+            errors[np.float32(err)] = (ts, np.array(Twc, np.float32))  # equal keys overwrite (std::map)
+        order = []
+        if len(errors) > start_to_correction_num - 1:
+            for err in sorted(errors, reverse=True):
+                if errors[err][0] in self.entries:
+                    order.append(errors[err])
+                if len(order) > correction_num - 1:
+                    break
+        culled = [ts for ts in sorted(self.entries) if self.entries[ts][2] == 0]
+        return order, culled
+
+    def online_correction(self, scene, view, rs, intr, keyframes, correction_num, start_to_correction_num,
+                          identity_eps=0.0):
+        """DenseSlam::OnlineCorrection: de-integrate each selected keyframe at its old pose, re-integrate it at the
+        optimised one with isDefusion, then take culled keyframes out of the map.  No image leaves the device."""
+        api = self.api
+        order, culled = self.plan(keyframes, correction_num, start_to_correction_num, identity_eps)
+        for ts, new_Twc in order:
+            ent = self.entries[ts]
+            api.view_update_from_store(view, self.store, ent[1], timestamp=float(ts))
+            api.deprocess_frame(scene, view, rs, self.pose_to_M(ent[0]), intr)
+            ent[0] = new_Twc
+            api.process_frame(scene, view, rs, self.pose_to_M(ent[0]), intr, is_defusion=True)
+        for ts in culled:
+            ent = self.entries[ts]
+            api.view_update_from_store(view, self.store, ent[1], timestamp=0.0)
+            api.deprocess_frame(scene, view, rs, self.pose_to_M(ent[0]), intr)
+            self._erase(ts)
+        return [ts for ts, _ in order], culled

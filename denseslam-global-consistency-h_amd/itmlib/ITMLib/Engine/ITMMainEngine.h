@@ -126,6 +126,16 @@ class ITMViewBuilder {
     memcpy(v->rgb->GetData(MEMORYDEVICE_CPU), rgb->GetData(MEMORYDEVICE_CPU), (size_t)rgb->noDims.x * rgb->noDims.y * 4);
     dslam_check(dslam_download_view_depth(eng_, v->handle, v->depth->GetData(MEMORYDEVICE_CPU)), "dslam_download_view_depth");
   }
+  /// UpdateView for a keyframe that already sits in the device-resident keyframe store (the UpdateView calls of
+  /// DenseSlam::OnlineCorrection, DenseSlam.cpp:392,421): no upload, and the host mirrors view->rgb / view->depth
+  /// are left alone -- nothing on that path reads them.
+  void UpdateViewFromStore(ITMView **view, const dslam_frame_store *store, int slot, double timestamp, bool useBilateralFilter) {
+    if (*view == nullptr) throw std::runtime_error("UpdateViewFromStore: the view must have been created by UpdateView first");
+    const Vector2f ab = calib_->disparityCalib.params;
+    dslam_check(dslam_view_update_from_store(eng_, (*view)->handle, store, slot, ab.x, ab.y, timestamp, useBilateralFilter),
+                "dslam_view_update_from_store");
+    (*view)->timestamp = timestamp;
+  }
 };
 
 /// ITMTrackingController: Prepare = raycast into ICP maps (InfiniTamDriver.h:212-215); Track (ICP) is out of scope

@@ -19,18 +19,37 @@ class ITMPose {
   void paramsFromM() {
     const float R[3][3] = {{M.at(0, 0), M.at(1, 0), M.at(2, 0)}, {M.at(0, 1), M.at(1, 1), M.at(2, 1)}, {M.at(0, 2), M.at(1, 2), M.at(2, 2)}};
     const float t[3] = {M.at(3, 0), M.at(3, 1), M.at(3, 2)};
-    float c = (R[0][0] + R[1][1] + R[2][2] - 1.0f) * 0.5f;
-    c = c > 1.0f ? 1.0f : (c < -1.0f ? -1.0f : c);
-    const float angle = acosf(c);
+    // rotation vector as upstream's SetParamsFromModelView structures it [UPSTREAM-RECALL]: asin of the
+    // antisymmetric part for small angles (acos loses all precision near 1), acos in the middle range, and the
+    // symmetric part for the axis near pi
+    const float c = (R[0][0] + R[1][1] + R[2][2] - 1.0f) * 0.5f;
     float w[3] = {(R[2][1] - R[1][2]) * 0.5f, (R[0][2] - R[2][0]) * 0.5f, (R[1][0] - R[0][1]) * 0.5f};
     const float s = sqrtf(w[0] * w[0] + w[1] * w[1] + w[2] * w[2]);
-    if (s > 1e-8f) { const float k = angle / s; w[0] *= k; w[1] *= k; w[2] *= k; }
+    float angle = 0.0f;
+    if (c > 0.70710678f) {
+      if (s > 0.0f) { angle = asinf(s > 1.0f ? 1.0f : s); const float k = angle / s; w[0] *= k; w[1] *= k; w[2] *= k; }
+    } else if (c > -0.70710678f) {
+      angle = acosf(c);
+      const float k = angle / s; w[0] *= k; w[1] *= k; w[2] *= k;
+    } else {
+      angle = 3.14159265358979f - asinf(s > 1.0f ? 1.0f : s);
+      const float d[3] = {R[0][0] - c, R[1][1] - c, R[2][2] - c};
+      float r2[3];
+      if (fabsf(d[0]) > fabsf(d[1]) && fabsf(d[0]) > fabsf(d[2])) { r2[0] = d[0]; r2[1] = (R[1][0] + R[0][1]) * 0.5f; r2[2] = (R[0][2] + R[2][0]) * 0.5f; }
+      else if (fabsf(d[1]) > fabsf(d[2])) { r2[0] = (R[1][0] + R[0][1]) * 0.5f; r2[1] = d[1]; r2[2] = (R[2][1] + R[1][2]) * 0.5f; }
+      else { r2[0] = (R[0][2] + R[2][0]) * 0.5f; r2[1] = (R[2][1] + R[1][2]) * 0.5f; r2[2] = d[2]; }
+      if (r2[0] * w[0] + r2[1] * w[1] + r2[2] * w[2] < 0.0f) { r2[0] = -r2[0]; r2[1] = -r2[1]; r2[2] = -r2[2]; }
+      const float n = sqrtf(r2[0] * r2[0] + r2[1] * r2[1] + r2[2] * r2[2]);
+      for (int i = 0; i < 3; i++) w[i] = n > 0.0f ? angle * r2[i] / n : 0.0f;
+    }
     // t = V u  ->  u = V^-1 t with V = I + B [w]x + C [w]x^2
     float u[3] = {t[0], t[1], t[2]};
     if (angle > 1e-6f) {
       const float a2 = angle * angle;
-      const float halfcot = 0.5f * angle * (sinf(angle) / (1.0f - cosf(angle)));
-      const float D = (1.0f - halfcot) / a2;
+      // D = (1 - (a/2) cot(a/2)) / a^2: by its series below 0.1 rad, where the closed form cancels catastrophically
+      float D;
+      if (angle < 0.1f) D = 1.0f / 12.0f + a2 * (1.0f / 720.0f + a2 * (1.0f / 30240.0f));
+      else { const float h = 0.5f * angle; D = (1.0f - h * cosf(h) / sinf(h)) / a2; }
       const float wxt[3] = {w[1] * t[2] - w[2] * t[1], w[2] * t[0] - w[0] * t[2], w[0] * t[1] - w[1] * t[0]};
       const float wxwxt[3] = {w[1] * wxt[2] - w[2] * wxt[1], w[2] * wxt[0] - w[0] * wxt[2], w[0] * wxt[1] - w[1] * wxt[0]};
       for (int i = 0; i < 3; i++) u[i] = t[i] - 0.5f * wxt[i] + D * wxwxt[i];

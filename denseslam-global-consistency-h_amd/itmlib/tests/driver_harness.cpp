@@ -3,15 +3,21 @@
 // (InfiniTamDriver.h:90-116) and issues the same member calls with the same expressions (cited per method), minus
 // OpenCV / Eigen / Pangolin, which are not in this image.
 //
-//   driver_harness <frames.bin> <out.bin> <decay:0|1> <slide_max_age|-1>
+//   driver_harness <frames.bin> <out.bin> <decay:0|1> <slide_max_age|-1> [keyframes.bin]
+// keyframes.bin (optional, switches DenseSlam::OnlineCorrection on; frames.bin poses are then used as Twc = M_d^-1):
+//             int32 CorrectionNum, StartToCorrectionNum, then per frame: int32 n, n x { double timestamp,
+//             float Twc[16] (column-major), int32 isBad } = ORB-SLAM2's keyframes at that moment
 // frames.bin: int32 W, H, N, then per frame: uint8 rgba[W*H*4], int16 depth_mm[W*H], float M_d[16] (column-major),
 //             then float intr[4], then scene params: float voxel, mu, fmin, fmax, int32 maxW, nLocal, nBuckets, nExcess
 // out.bin:    int32 lastFreeBlockId, noVisibleEntries, usedBytesLo, decayedBlocks; uint64 fnv(hash table), fnv(voxels);
-//             float depth[W*H]; uint8 colour[W*H*4]
+//             float depth[W*H]; uint8 colour[W*H*4];
+//             with keyframes.bin, per frame: int32 nCorrected, double ts[nCorrected] (in re-fusion order),
+//             int32 nCulled, int32 databaseSize
 #include <cstdint>
 #include <cstdio>
 #include <vector>
 
+#include "DenseSLAM/OnlineCorrection.h"
 #include "ITMLib/Engine/ITMMainEngine.h"
 
 using namespace ITMLib::Engine;
@@ -19,12 +25,15 @@ using namespace ITMLib::Objects;
 
 struct VoxelDecayParams { bool enabled; int min_decay_age, max_decay_weight; };
 struct SlideWindowParams { bool enabled; int max_age; };
+using SparsetoDense::OnlineCorrectionParams;
 
 class DriverHarness : public ITMMainEngine {
  public:
-  DriverHarness(const ITMLibSettings *settings, const ITMRGBDCalib *calib, const Vector2i &sz, VoxelDecayParams d, SlideWindowParams s)
+  DriverHarness(const ITMLibSettings *settings, const ITMRGBDCalib *calib, const Vector2i &sz, VoxelDecayParams d, SlideWindowParams s,
+                OnlineCorrectionParams oc = OnlineCorrectionParams(false, 0, 0))
       : ITMMainEngine(settings, calib, sz, sz), rgb_itm_(new ITMUChar4Image(sz, true, true)),
-        raw_depth_itm_(new ITMShortImage(sz, true, true)), voxel_decay_params_(d), slide_window_params_(s) {}
+        raw_depth_itm_(new ITMShortImage(sz, true, true)), voxel_decay_params_(d), slide_window_params_(s),
+        online_correction_params_(oc) {}
   ~DriverHarness() { delete rgb_itm_; delete raw_depth_itm_; }
 
   // InfiniTamDriver::UpdateView (InfiniTamDriver.cpp:280-288)
@@ -32,6 +41,22 @@ class DriverHarness : public ITMMainEngine {
     memcpy(rgb_itm_->GetData(MEMORYDEVICE_CPU), rgba, rgb_itm_->dataSize * 4);
     memcpy(raw_depth_itm_->GetData(MEMORYDEVICE_CPU), depth, raw_depth_itm_->dataSize * 2);
     this->viewBuilder->UpdateView(&view, rgb_itm_, raw_depth_itm_, timestamp, settings->useBilateralFilter);
+  }
+  // the same call for a keyframe kept in the device-resident store (DenseSlam.cpp:392,421 without the upload)
+  void UpdateViewFromStore(const dslam_frame_store *store, int slot, double timestamp) {
+    this->viewBuilder->UpdateViewFromStore(&view, store, slot, timestamp, settings->useBilateralFilter);
+  }
+  // InfiniTamDriver::SetPoseLocalMap (InfiniTamDriver.h:173-178); last_egomotion_ feeds only the GUI
+  void SetPoseLocalMap(const ITMLocalMap *m, const Matrix4f &new_pose) {
+    const Matrix4f Tcurrmap_w = m->estimatedGlobalPose.GetM();
+    m->trackingState->pose_d->SetInvM(Tcurrmap_w * new_pose);
+  }
+  // InfiniTamDriver::SlideWindowDefusionPart (InfiniTamDriver.h:302-310)
+  void SlideWindowDefusionPart(const ITMLocalMap *m) {
+    if (slide_window_params_.enabled) {
+      int maxSize = (slide_window_params_.max_age - online_correction_params_.StartToCorrectionNum) * online_correction_params_.CorrectionNum;
+      denseMapper->SlideWindowDefusionPart(m->scene, m->renderState, slide_window_params_.max_age, maxSize);
+    }
   }
   ITMVoxelMapGraphManager *GetMapManager() const { return this->mapManager; }  // InfiniTamDriver.h:136
   // InfiniTamDriver::IntegrateLocalMap (InfiniTamDriver.h:187-192)
@@ -85,6 +110,7 @@ class DriverHarness : public ITMMainEngine {
   WeightParams fusion_weight_params_;
   VoxelDecayParams voxel_decay_params_;
   SlideWindowParams slide_window_params_;
+  OnlineCorrectionParams online_correction_params_;
 };
 
 static uint64_t fnv1a(const void *p, size_t n, uint64_t h = 1469598103934665603ull) {
@@ -113,6 +139,30 @@ int main(int argc, char **argv) {
   if (fread(intr, 4, 4, f) != 4 || fread(sp, 4, 4, f) != 4 || fread(ip, 4, 4, f) != 4) return 2;
   fclose(f);
 
+  // optional ORB-SLAM2 keyframe snapshots, one set per fused frame
+  OnlineCorrectionParams oc(false, 0, 0);
+  std::vector<std::vector<SparsetoDense::MapKeyFrame>> keyframes(N);
+  if (argc >= 6) {
+    FILE *k = fopen(argv[5], "rb");
+    if (!k) { perror("keyframes"); return 2; }
+    int32_t cn[2];
+    if (fread(cn, 4, 2, k) != 2) return 2;
+    oc = OnlineCorrectionParams(true, cn[0], cn[1]);
+    for (int i = 0; i < N; i++) {
+      int32_t n;
+      if (fread(&n, 4, 1, k) != 1) return 2;
+      keyframes[i].resize(n);
+      for (int j = 0; j < n; j++) {
+        int32_t bad;
+        if (fread(&keyframes[i][j].mTimeStamp, 8, 1, k) != 1 || fread(keyframes[i][j].poseInverse.m, 4, 16, k) != 16 || fread(&bad, 4, 1, k) != 1) return 2;
+        keyframes[i][j].bad = bad != 0;
+      }
+    }
+    fclose(k);
+  }
+  std::vector<int32_t> oc_counts;      // per frame: nCorrected, nCulled, database size
+  std::vector<std::vector<double>> oc_order(N);
+
   try {
     ITMLibSettings *settings = new ITMLibSettings();  // SystemEntry.cpp:238
     settings->sceneParams = ITMSceneParams(sp[1], ip[0], sp[0], sp[2], sp[3], false);
@@ -128,7 +178,7 @@ int main(int argc, char **argv) {
 
     VoxelDecayParams dp = {atoi(argv[3]) != 0, 2, 1};
     SlideWindowParams sw = {atoi(argv[4]) >= 0, atoi(argv[4])};
-    DriverHarness drv(settings, calib, Vector2i(W, H), dp, sw);
+    DriverHarness drv(settings, calib, Vector2i(W, H), dp, sw, oc);
 
     // before the first keyframe: GetImage must be a no-op, not a crash
     ITMFloatImage out_float(Vector2i(W, H), true, true);
@@ -142,8 +192,41 @@ int main(int argc, char **argv) {
     drv.GetMapManager()->setEstimatedGlobalPose(idx, tempPose);
     ITMLocalMap *currentLocalMap = drv.GetMapManager()->getLocalMap(idx);
 
+    if (oc.enabled) {
+      // DenseSlam::ProcessFrame with online_correction: 1 (DenseSlam.cpp:156-158,178-181,210-232)
+      struct Recorder {  // forwards to the driver and notes the order keyframes are re-fused in
+        DriverHarness &d; std::vector<double> *order; double last_ts;
+        void SetPoseLocalMap(const ITMLocalMap *m, const Matrix4f &p) { d.SetPoseLocalMap(m, p); }
+        void UpdateViewFromStore(const dslam_frame_store *s, int slot, double ts) { last_ts = ts; d.UpdateViewFromStore(s, slot, ts); }
+        void DeIntegrateLocalMap(const ITMLocalMap *m) { d.DeIntegrateLocalMap(m); }
+        void IntegrateLocalMap(const ITMLocalMap *m, bool a, bool b) { order->push_back(last_ts); d.IntegrateLocalMap(m, a, b); }
+      };
+      SparsetoDense::FusionFrameDataBase mfusionFrameDataBase(drv.GetDslamEngine(), Vector2i(W, H), Vector2i(W, H), N);
+      for (int i = 0; i < N; i++) {
+        const double currBAKFTime = (double)i;
+        Matrix4f orbSLAM2_Pose;
+        poses[i].inv(orbSLAM2_Pose);                                            // Twc
+        drv.UpdateView(rgba[i].data(), depth[i].data(), currBAKFTime);          // the one upload of this keyframe
+        mfusionFrameDataBase.InsertFromView(currBAKFTime, orbSLAM2_Pose, drv.GetView());  // DenseSlam.cpp:156-157
+        Recorder rec{drv, &oc_order[i], 0.0};
+        int culled = 0;
+        const int corrected = mfusionFrameDataBase.OnlineCorrection(rec, currentLocalMap, keyframes[i], oc, &culled);  // :178-181
+        drv.SetPoseLocalMap(currentLocalMap, orbSLAM2_Pose);                    // :189
+        if (mfusionFrameDataBase.entries().count(currBAKFTime)) {
+          drv.UpdateViewFromStore(mfusionFrameDataBase.store(), mfusionFrameDataBase.entries().at(currBAKFTime).slot, currBAKFTime);  // :212
+          drv.IntegrateLocalMap(currentLocalMap);                               // :213
+        }
+        if ((int)mfusionFrameDataBase.size() > sw.max_age && sw.enabled) {      // :215-225
+          drv.SlideWindow(currentLocalMap);
+          for (int k = 0; k < oc.CorrectionNum; k++) drv.SlideWindowDefusionPart(currentLocalMap);
+          mfusionFrameDataBase.SlideWindowPose(sw.max_age);
+        }
+        drv.Decay(currentLocalMap);                                             // :227-232
+        oc_counts.push_back(corrected); oc_counts.push_back(culled); oc_counts.push_back((int32_t)mfusionFrameDataBase.size());
+      }
+    }
     int fused = 0;
-    for (int i = 0; i < N; i++) {
+    for (int i = 0; i < N && !oc.enabled; i++) {
       currentLocalMap->trackingState->pose_d->SetM(poses[i]);                 // SetPoseLocalMap (InfiniTamDriver.h:173-178)
       drv.UpdateView(rgba[i].data(), depth[i].data(), (double)i);             // DenseSlam.cpp:212
       drv.IntegrateLocalMap(currentLocalMap);                                 // DenseSlam.cpp:213
@@ -173,6 +256,12 @@ int main(int argc, char **argv) {
     fwrite(sums, 8, 2, o);
     fwrite(out_float.GetData(MEMORYDEVICE_CPU), 4, (size_t)W * H, o);
     fwrite(out_rgba.GetData(MEMORYDEVICE_CPU), 4, (size_t)W * H, o);
+    for (int i = 0; i < N && oc.enabled; i++) {
+      const int32_t n = (int32_t)oc_order[i].size();
+      fwrite(&n, 4, 1, o);
+      fwrite(oc_order[i].data(), 8, oc_order[i].size(), o);
+      fwrite(&oc_counts[3 * i + 1], 4, 2, o);
+    }
     fclose(o);
     printf("driver_harness ok: %d frames, lastFreeBlockId %d, visible %d, decayed %d\n", N, st[0], st[1], st[3]);
     delete calib;

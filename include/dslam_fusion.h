@@ -174,6 +174,32 @@ int dslam_view_update_bgr_device(dslam_engine *e, dslam_view *v, const void *bgr
 /* test / debug read-back of the view's RGBA image (what IntegrateIntoScene will read). */
 int dslam_download_view_rgba(dslam_engine *e, const dslam_view *v, uint8_t *out_rgba);
 
+/* ---- keyframe store --------------------------------------------------------------------------- */
+/* The image payload of DenseSlam's mfusionFrameDataBase (fusionFrameInfo::rgbinfo / depthinfo, DenseSlam.h:431-433)
+ * kept resident in HBM: `capacity` slots of one RGBA + one int16-millimetre depth image.  The
+ * reference re-uploads every keyframe through UpdateView for each de-/re-integration (DenseSlam.cpp:389-403,
+ * 420-422); with the store OnlineCorrection's UpdateView becomes dslam_view_update_from_store -- no copy at all.
+ * Slot bookkeeping (timestamp -> slot) stays with the caller's std::map.  640x480: 1.8 MB per keyframe. */
+typedef struct dslam_frame_store dslam_frame_store;
+int dslam_frame_store_create(dslam_engine *e, int width_rgb, int height_rgb, int width_d, int height_d, int capacity,
+                             dslam_frame_store **out);
+int dslam_frame_store_destroy(dslam_frame_store *fs);
+/* host images in (the same layouts as dslam_view_update / dslam_view_update_bgr) */
+int dslam_frame_store_put(dslam_engine *e, dslam_frame_store *fs, int slot, const uint8_t *rgba_host,
+                          const int16_t *depth_mm_host);
+int dslam_frame_store_put_bgr(dslam_engine *e, dslam_frame_store *fs, int slot, const uint8_t *bgr_host,
+                              const int16_t *depth_mm_host);
+/* device-to-device from the view that was just fused (mfusionFrameDataBase insert, DenseSlam.cpp:196-208):
+ * the keyframe never crosses PCIe a second time */
+int dslam_frame_store_put_view(dslam_engine *e, dslam_frame_store *fs, int slot, const dslam_view *v);
+int dslam_frame_store_get(dslam_engine *e, const dslam_frame_store *fs, int slot, uint8_t *rgba_out,
+                          int16_t *depth_mm_out);
+int dslam_frame_store_device_ptrs(const dslam_frame_store *fs, int slot, void **rgba_dev, void **depth_mm_dev);
+/* static_scene_->UpdateView(currRGBInfo, currDepthInfo, timestamp) for a stored keyframe (DenseSlam.cpp:392,421):
+ * the view reads the slot in place until its next update; overwriting the slot before that changes what it sees */
+int dslam_view_update_from_store(dslam_engine *e, dslam_view *v, const dslam_frame_store *fs, int slot,
+                                 float affine_a, float affine_b, double timestamp, int use_bilateral_filter);
+
 /* DenseSlam::depthPostProcessing's pixel loop (DenseSlam.cpp:488-529): blanks (sets to 0) every pixel of the
  * current keyframe's depth whose reprojection into the previous keyframe disagrees with that keyframe's depth by
  * more than `filter_threshold` (relative) and which lies below row `filter_area * rows`

@@ -177,6 +177,7 @@ struct oracle_view {
   std::vector<uint8_t> rgba;
   std::vector<float> depth;
   std::vector<float> float_image;  // ITMViewBuilder::floatImage (bilateral filter scratch)
+  std::vector<int16_t> raw_depth;  // the millimetre image of the last update (copied into the keyframe store)
   double timestamp;
 };
 
@@ -608,6 +609,7 @@ static void filter_depth_pass(const float *in, float *out, int W, int H) {
 
 static int view_finish(oracle_view *v, const int16_t *depth_mm, float a, float b, double timestamp, int use_bilateral) {
   const size_t n = (size_t)v->w_d * v->h_d;
+  v->raw_depth.assign(depth_mm, depth_mm + n);
   for (size_t i = 0; i < n; i++) {
     int d = depth_mm[i];
     v->depth[i] = (d <= 0 || d > 32000) ? -1.0f : (float)d * a + b;
@@ -652,6 +654,57 @@ extern "C" int oracle_view_update_bgr(oracle_engine *, oracle_view *v, const uin
 extern "C" int oracle_download_view_rgba(oracle_engine *, const oracle_view *v, uint8_t *out) {
   memcpy(out, v->rgba.data(), v->rgba.size());
   return 0;
+}
+
+// keyframe store (the images of DenseSlam's mfusionFrameDataBase, DenseSlam.h:46-60,431-433): plain host vectors here
+struct oracle_frame_store {
+  int w_rgb, h_rgb, w_d, h_d, capacity;
+  std::vector<std::vector<uint8_t>> rgba;
+  std::vector<std::vector<int16_t>> depth;
+};
+extern "C" int oracle_frame_store_create(oracle_engine *, int w_rgb, int h_rgb, int w_d, int h_d, int capacity, oracle_frame_store **out) {
+  if (capacity <= 0 || w_rgb <= 0 || h_rgb <= 0 || w_d <= 0 || h_d <= 0) return DSLAM_ERR_INVALID;
+  oracle_frame_store *fs = new oracle_frame_store{w_rgb, h_rgb, w_d, h_d, capacity, {}, {}};
+  fs->rgba.assign(capacity, std::vector<uint8_t>((size_t)w_rgb * h_rgb * 4, 0));
+  fs->depth.assign(capacity, std::vector<int16_t>((size_t)w_d * h_d, 0));
+  *out = fs;
+  return 0;
+}
+extern "C" int oracle_frame_store_destroy(oracle_frame_store *fs) { delete fs; return 0; }
+extern "C" int oracle_frame_store_put(oracle_engine *, oracle_frame_store *fs, int slot, const uint8_t *rgba, const int16_t *depth) {
+  if (slot < 0 || slot >= fs->capacity) return DSLAM_ERR_INVALID;
+  memcpy(fs->rgba[slot].data(), rgba, fs->rgba[slot].size());
+  memcpy(fs->depth[slot].data(), depth, fs->depth[slot].size() * 2);
+  return 0;
+}
+extern "C" int oracle_frame_store_put_bgr(oracle_engine *, oracle_frame_store *fs, int slot, const uint8_t *bgr, const int16_t *depth) {
+  if (slot < 0 || slot >= fs->capacity) return DSLAM_ERR_INVALID;
+  const size_t n = (size_t)fs->w_rgb * fs->h_rgb;
+  uint8_t *o = fs->rgba[slot].data();
+  for (size_t i = 0; i < n; i++) { o[4 * i] = bgr[3 * i + 2]; o[4 * i + 1] = bgr[3 * i + 1]; o[4 * i + 2] = bgr[3 * i]; o[4 * i + 3] = 255u; }
+  memcpy(fs->depth[slot].data(), depth, fs->depth[slot].size() * 2);
+  return 0;
+}
+extern "C" int oracle_frame_store_put_view(oracle_engine *, oracle_frame_store *fs, int slot, const oracle_view *v) {
+  if (slot < 0 || slot >= fs->capacity) return DSLAM_ERR_INVALID;
+  if (v->w_rgb != fs->w_rgb || v->h_rgb != fs->h_rgb || v->w_d != fs->w_d || v->h_d != fs->h_d) return DSLAM_ERR_INVALID;
+  if (v->raw_depth.size() != fs->depth[slot].size()) return DSLAM_ERR_INVALID;  // view never updated
+  fs->rgba[slot] = v->rgba;
+  fs->depth[slot] = v->raw_depth;
+  return 0;
+}
+extern "C" int oracle_frame_store_get(oracle_engine *, const oracle_frame_store *fs, int slot, uint8_t *rgba_out, int16_t *depth_out) {
+  if (slot < 0 || slot >= fs->capacity) return DSLAM_ERR_INVALID;
+  if (rgba_out) memcpy(rgba_out, fs->rgba[slot].data(), fs->rgba[slot].size());
+  if (depth_out) memcpy(depth_out, fs->depth[slot].data(), fs->depth[slot].size() * 2);
+  return 0;
+}
+extern "C" int oracle_view_update_from_store(oracle_engine *, oracle_view *v, const oracle_frame_store *fs, int slot, float a, float b,
+                                  double timestamp, int use_bilateral) {
+  if (slot < 0 || slot >= fs->capacity) return DSLAM_ERR_INVALID;
+  if (v->w_rgb != fs->w_rgb || v->h_rgb != fs->h_rgb || v->w_d != fs->w_d || v->h_d != fs->h_d) return DSLAM_ERR_INVALID;
+  memcpy(v->rgba.data(), fs->rgba[slot].data(), v->rgba.size());
+  return view_finish(v, fs->depth[slot].data(), a, b, timestamp, use_bilateral);
 }
 
 // DenseSlam::depthPostProcessing, the pixel loop (DenseSlam.cpp:488-529).  Arithmetic types follow the C++ of the
