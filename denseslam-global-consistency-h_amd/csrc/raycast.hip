@@ -296,7 +296,9 @@ __device__ __forceinline__ float rd_sdf(const VolumeRef &vol, int x, int y, int 
   return (float)(short)(read_voxel(vol, x, y, z, found, c).x & 0xffffu);
 }
 
-__device__ __forceinline__ int iround(float x) { return (int)((x < 0) ? (x - 0.5f) : (x + 0.5f)); }
+// (int)(x < 0 ? x - 0.5f : x + 0.5f); copysign folds the compare + select into one bit-field insert (-0.0 gives 0
+// either way)
+__device__ __forceinline__ int iround(float x) { return (int)(x + __builtin_copysignf(0.5f, x)); }
 
 __device__ __forceinline__ float read_sdf_uninterp(const VolumeRef &vol, const Vec3 &pt, bool &found, IndexCache &c) {
   return rd_sdf(vol, iround(pt.x), iround(pt.y), iround(pt.z), found, c) / 32767.0f;
@@ -316,6 +318,54 @@ __device__ __forceinline__ int lookup_block(const VolumeRef &vol, int bx, int by
     }
     if (e.offset < 1) return -1;
     h = vol.num_buckets + e.offset - 1;
+  }
+}
+
+// Block base pointers (voxel index of the block's first voxel, or -1) of the 8 corners of a trilinear cell whose
+// per-axis block coordinates are bxa/bya/bza[0..1]; corner k = (k & 1, (k >> 1) & 1, k >> 2).  All eight bucket heads
+// are loaded in ONE round trip (equal blocks hit the same address); corners whose head holds another block follow
+// their excess chains together, one round trip per link.
+__device__ __forceinline__ void resolve_cell_blocks(const VolumeRef &vol, const int bxa[2], const int bya[2],
+                                                    const int bza[2], int base[8]) {
+  const unsigned hx[2] = {(unsigned)bxa[0] * 73856093u, (unsigned)bxa[1] * 73856093u};
+  const unsigned hy[2] = {(unsigned)bya[0] * 19349669u, (unsigned)bya[1] * 19349669u};
+  const unsigned hz[2] = {(unsigned)bza[0] * 83492791u, (unsigned)bza[1] * 83492791u};
+  // packed position words of an entry: x = pos0 | pos1 << 16, y = pos2 (| pad); a block coordinate outside the
+  // short range can never be stored, so it never matches
+  const unsigned tx[2] = {(unsigned)bxa[0] & 0xffffu, (unsigned)bxa[1] & 0xffffu};
+  const unsigned ty[2] = {(unsigned)bya[0] << 16, (unsigned)bya[1] << 16};
+  const unsigned tz[2] = {(unsigned)bza[0] & 0xffffu, (unsigned)bza[1] & 0xffffu};
+  const bool okx[2] = {bxa[0] == (short)bxa[0], bxa[1] == (short)bxa[1]};
+  const bool oky[2] = {bya[0] == (short)bya[0], bya[1] == (short)bya[1]};
+  const bool okz[2] = {bza[0] == (short)bza[0], bza[1] == (short)bza[1]};
+  int h[8];
+  u32x4 e[8];
+#pragma unroll
+  for (int k = 0; k < 8; k++) {
+    h[k] = (int)((hx[k & 1] ^ hy[(k >> 1) & 1] ^ hz[k >> 2]) & vol.mask);
+    e[k] = *reinterpret_cast<const u32x4 *>(vol.hash + h[k]);
+  }
+  unsigned pending = 0;
+#pragma unroll
+  for (int k = 0; k < 8; k++) {
+    const bool ok = okx[k & 1] && oky[(k >> 1) & 1] && okz[k >> 2];
+    const bool match = ok && e[k].x == (tx[k & 1] | ty[(k >> 1) & 1]) && (e[k].y & 0xffffu) == tz[k >> 2] && (int)e[k].w >= 0;
+    base[k] = match ? (int)e[k].w * kBlock3 : -1;
+    if (!match && (int)e[k].z >= 1) { pending |= 1u << k; h[k] = vol.num_buckets + (int)e[k].z - 1; }
+  }
+  while (pending) {
+#pragma unroll
+    for (int k = 0; k < 8; k++)
+      if (pending & (1u << k)) e[k] = *reinterpret_cast<const u32x4 *>(vol.hash + h[k]);
+#pragma unroll
+    for (int k = 0; k < 8; k++)
+      if (pending & (1u << k)) {
+        const bool ok = okx[k & 1] && oky[(k >> 1) & 1] && okz[k >> 2];
+        const bool match = ok && e[k].x == (tx[k & 1] | ty[(k >> 1) & 1]) && (e[k].y & 0xffffu) == tz[k >> 2] && (int)e[k].w >= 0;
+        if (match) { base[k] = (int)e[k].w * kBlock3; pending &= ~(1u << k); }
+        else if ((int)e[k].z >= 1) h[k] = vol.num_buckets + (int)e[k].z - 1;
+        else pending &= ~(1u << k);
+      }
   }
 }
 
@@ -366,6 +416,32 @@ __device__ __forceinline__ float trilinear_sdf(const uint2 t[8], float cx, float
   float res2 = (1.0f - cx) * s[4] + cx * s[5];
   res2 = (1.0f - cy) * res2 + cy * ((1.0f - cx) * s[6] + cx * s[7]);
   return div_exact((1.0f - cz) * res1 + cz * res2, 32767.0f, 1.0f / 32767.0f);
+}
+
+// readFromSDF_float_interpolated in two load round trips: every block of the cell resolved together, then the 8
+// taps together (a tap whose block is not allocated reads the empty voxel).  Same values as read_sdf_interp.
+__device__ __forceinline__ float read_sdf_interp_batched(const VolumeRef &vol, const Vec3 &pt, float inv_32767) {
+  const float fx = floorf(pt.x), fy = floorf(pt.y), fz = floorf(pt.z);
+  const int x0 = (int)fx, y0 = (int)fy, z0 = (int)fz;
+  const int bxa[2] = {x0 >> 3, (x0 + 1) >> 3}, bya[2] = {y0 >> 3, (y0 + 1) >> 3}, bza[2] = {z0 >> 3, (z0 + 1) >> 3};
+  int base[8];
+  resolve_cell_blocks(vol, bxa, bya, bza, base);
+  const unsigned lx[2] = {(unsigned)x0 & 7u, (unsigned)(x0 + 1) & 7u};
+  const unsigned ly[2] = {((unsigned)y0 & 7u) << 3, ((unsigned)(y0 + 1) & 7u) << 3};
+  const unsigned lz[2] = {((unsigned)z0 & 7u) << 6, ((unsigned)(z0 + 1) & 7u) << 6};
+  const char *vbytes = reinterpret_cast<const char *>(vol.voxels);
+  uint2 t[8];
+#pragma unroll
+  for (int k = 0; k < 8; k++) {
+    const unsigned lin = lx[k & 1] | ly[(k >> 1) & 1] | lz[k >> 2];
+    const unsigned off = (base[k] < 0) ? 0u : ((unsigned)base[k] + lin) * 8u;
+    t[k].x = *reinterpret_cast<const unsigned *>(vbytes + off);
+    t[k].y = 0u;
+  }
+#pragma unroll
+  for (int k = 0; k < 8; k++) t[k].x = (base[k] < 0) ? kEmptyVoxelLo : t[k].x;
+  (void)inv_32767;
+  return trilinear_sdf(t, pt.x - fx, pt.y - fy, pt.z - fz);
 }
 
 __device__ __forceinline__ float read_sdf_interp(const VolumeRef &vol, const Vec3 &pt, bool &found, IndexCache &c) {
@@ -471,7 +547,6 @@ __device__ __forceinline__ bool cast_ray(Vec4 &out, int x, int y, const RenderPa
                                          int &iters_out) {
   Vec4 pc;
   Vec3 ps, pe, dir, res;
-  bool hash_found;
   float sdf = 1.0f;
   float total, step, total_max;
   const float step_scale = p.mu * p.one_over_vs;
@@ -500,12 +575,16 @@ __device__ __forceinline__ bool cast_ray(Vec4 &out, int x, int y, const RenderPa
   int iter = 0;
   while (total < total_max) {
     ++iter;
-    // Measured on MI355X: the memory system is nearly idle during the march (TA ~16 % busy); a wave's time is its
-    // count of SERIALISED load round trips (~600 cycles each), and added scattered loads (bucket bitmap, prefetch
-    // of next heads, speculative multi-step batches) cost more than they save.  What does pay: once the block of
-    // the nearest voxel ROUND(p) is resolved, the taps of the trilinear cell floor(p)..floor(p)+1 that lie in the
-    // SAME block (all 8 at 67 % of the positions; ROUND(p) is always one of them) ride in the same round trip, so
-    // near the surface the interpolated value needs no second lookup + gather.
+    // Measured on MI355X (DSLAM_DBG_WAVETIME dump): the launch keeps only ~1.1 waves per SIMD resident on average
+    // and ends when its longest wave ends, and a lone wave64 issues one VALU instruction per 4 cycles -- a step costs
+    // its load round trips (~700 cycles each) PLUS 4 cycles for every instruction ANY lane of the wave executes.
+    // Hence: (a) the common step is kept short -- one probe for the block of the nearest voxel ROUND(p), then the
+    // 8 taps of the trilinear cell floor(p)..floor(p)+1 in one batch from THAT block (in-block offsets wrap, so the
+    // loads are unconditional; all 8 taps lie in it at 67 % of the positions, ROUND(p) always does); (b) the
+    // uncommon step -- near the surface with the cell straddling blocks -- resolves all its blocks in one further
+    // round trip and re-reads the taps in a second (read_sdf_interp_batched), instead of readFromSDF_float_
+    // interpolated's eight lookups one after the other.  Variants that add loads or instructions to the common
+    // step (bitmap, prefetch, speculation, resolving the whole cell every step) all measured slower.
     const int vx = iround(res.x), vy = iround(res.y), vz = iround(res.z);
     const int bx = vx >> 3, by = vy >> 3, bz = vz >> 3;
     const int base = lookup_block(p.vol, bx, by, bz, cache);
@@ -516,34 +595,35 @@ __device__ __forceinline__ bool cast_ray(Vec4 &out, int x, int y, const RenderPa
       const float f0x = floorf(res.x), f0y = floorf(res.y), f0z = floorf(res.z);
       const int x0 = (int)f0x, y0 = (int)f0y, z0 = (int)f0z;
       unsigned raw[8];
-      // per-axis "tap is inside the resolved block" flags and in-block offsets (2 per axis instead of 8 x 3)
-      const bool inx[2] = {(x0 >> 3) == bx, ((x0 + 1) >> 3) == bx};
-      const bool iny[2] = {(y0 >> 3) == by, ((y0 + 1) >> 3) == by};
-      const bool inz[2] = {(z0 >> 3) == bz, ((z0 + 1) >> 3) == bz};
-      const int ox[2] = {x0 & 7, (x0 + 1) & 7};
-      const int oy[2] = {(y0 & 7) * kBlock, ((y0 + 1) & 7) * kBlock};
-      const int oz[2] = {(z0 & 7) * kBlock * kBlock, ((z0 + 1) & 7) * kBlock * kBlock};
-      const bool all_in = inx[0] && inx[1] && iny[0] && iny[1] && inz[0] && inz[1];
-      const uint2 *blockp = p.vol.voxels + (size_t)base;
+      // The 8 taps as 32-bit byte offsets from the (uniform) voxel array: one or3 + one shift-add per tap and the
+      // load takes the scalar base.  A tap that belongs to a neighbouring block still reads a valid address inside
+      // this block; its value is only used when all 8 taps are inside (all_in).
+      const unsigned lx[2] = {(unsigned)x0 & 7u, (unsigned)(x0 + 1) & 7u};
+      const unsigned ly[2] = {((unsigned)y0 & 7u) << 3, ((unsigned)(y0 + 1) & 7u) << 3};
+      const unsigned lz[2] = {((unsigned)z0 & 7u) << 6, ((unsigned)(z0 + 1) & 7u) << 6};
+      const char *vbytes = reinterpret_cast<const char *>(p.vol.voxels);
+      const unsigned off0 = (unsigned)base * 8u;  // base < 2^27 voxels -> < 2^30 bytes
 #pragma unroll
       for (int k = 0; k < 8; k++) {
-        const bool in = inx[k & 1] && iny[(k >> 1) & 1] && inz[k >> 2];
-        const int lin = ox[k & 1] + oy[(k >> 1) & 1] + oz[k >> 2];
-        raw[k] = blockp[in ? lin : 0].x;  // unconditional, batched; out-of-block taps ignored
+        const unsigned off = off0 + ((lx[k & 1] | ly[(k >> 1) & 1] | lz[k >> 2]) << 3);
+        raw[k] = *reinterpret_cast<const unsigned *>(vbytes + off);  // unconditional, batched
       }
-      const int near = (vx - x0) | ((vy - y0) << 1) | ((vz - z0) << 2);
-      unsigned rn = raw[0];
-#pragma unroll
-      for (int k = 1; k < 8; k++) rn = (near == k) ? raw[k] : rn;
+      // nearest voxel ROUND(p) = tap (vx - x0, vy - y0, vz - z0): a 3-level select tree
+      const bool nx = vx != x0, ny = vy != y0, nz = vz != z0;
+      const unsigned r01 = nx ? raw[1] : raw[0], r23 = nx ? raw[3] : raw[2];
+      const unsigned r45 = nx ? raw[5] : raw[4], r67 = nx ? raw[7] : raw[6];
+      const unsigned rn = nz ? (ny ? r67 : r45) : (ny ? r23 : r01);
       sdf = div_exact((float)(short)(rn & 0xffffu), 32767.0f, p.inv_32767);
       if ((sdf <= 0.1f) && (sdf >= -0.5f)) {
+        const bool all_in = (x0 >> 3) == bx && ((x0 + 1) >> 3) == bx && (y0 >> 3) == by && ((y0 + 1) >> 3) == by &&
+                            (z0 >> 3) == bz && ((z0 + 1) >> 3) == bz;
         if (all_in) {
           uint2 t[8];
 #pragma unroll
           for (int k = 0; k < 8; k++) t[k] = make_uint2(raw[k], 0u);
           sdf = trilinear_sdf(t, res.x - f0x, res.y - f0y, res.z - f0z);
         } else {
-          sdf = read_sdf_interp(p.vol, res, hash_found, cache);
+          sdf = read_sdf_interp_batched(p.vol, res, p.inv_32767);
         }
       }
       if (sdf <= 0.0f) break;
@@ -557,7 +637,7 @@ __device__ __forceinline__ bool cast_ray(Vec4 &out, int x, int y, const RenderPa
   if (sdf <= 0.0f) {
     step = sdf * step_scale;
     res.x += step * dir.x; res.y += step * dir.y; res.z += step * dir.z;
-    sdf = read_sdf_interp(p.vol, res, hash_found, cache);
+    sdf = read_sdf_interp_batched(p.vol, res, p.inv_32767);
     step = sdf * step_scale;
     res.x += step * dir.x; res.y += step * dir.y; res.z += step * dir.z;
     pt_found = true;
@@ -577,6 +657,8 @@ __global__ __launch_bounds__(WAVES * 64) void k_render(RenderParams p) {
   // Single-wave workgroups let the dispatcher backfill a SIMD the moment a short tile finishes (ray lengths vary
   // by 10x between tiles), instead of holding 4 waves until the slowest of a 16x16 tile is done.
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  // (measured: dealing each XCD a contiguous band of tiles for L2 locality is slower, 104 vs 100 us -- the long
+  // rays of one image region then pile up on one XCD; the march is bound by its longest dependent-load chain)
   const int x = (WAVES == 4) ? blockIdx.x * 16 + (wave & 1) * 8 + (lane & 7) : blockIdx.x * 8 + (lane & 7);
   const int y = (WAVES == 4) ? blockIdx.y * 16 + (wave >> 1) * 8 + (lane >> 3) : blockIdx.y * 8 + (lane >> 3);
   if (x >= p.W || y >= p.H) return;

@@ -1411,10 +1411,11 @@ extern "C" int oracle_create_expected_depths(oracle_engine *, const oracle_scene
 namespace {
 // debug counters (oracle_raycast_stats): ray-march steps, interpolated reads, rays
 static long long g_dbg_steps = 0, g_dbg_interp = 0, g_dbg_rays = 0, g_dbg_maxsteps = 0;
+static int *g_dbg_pixel_steps = nullptr;  // optional [2 * W * H]: per ray (steps, steps that found no block)
 
 // castRay
 static inline bool cast_ray(const oracle_scene *s, V4f &out, int x, int y, const float *invM, const float *intr,
-                            float one_over_vs, float mu, const V2f &minmax) {
+                            float one_over_vs, float mu, const V2f &minmax, int dbg_loc = 0) {
   V4f pc; V3f ps, pe, dir, res;
   bool hash_found;
   float sdf = 1.0f;
@@ -1443,11 +1444,12 @@ static inline bool cast_ray(const oracle_scene *s, V4f &out, int x, int y, const
   dir.x *= dn; dir.y *= dn; dir.z *= dn;
   res = ps;
   IndexCache cache;
-  long long nsteps = 0, ninterp = 0;
+  long long nsteps = 0, ninterp = 0, nmiss = 0;
   while (total < total_max) {
     nsteps++;
     sdf = read_sdf_uninterp(s, res, hash_found, cache);
     if (!hash_found) {
+      nmiss++;
       step = (float)DSLAM_BLOCK_SIZE;
     } else {
       if ((sdf <= 0.1f) && (sdf >= -0.5f)) { sdf = read_sdf_interp(s, res, hash_found, cache); ninterp++; }
@@ -1465,6 +1467,7 @@ static inline bool cast_ray(const oracle_scene *s, V4f &out, int x, int y, const
 #pragma omp atomic
   g_dbg_rays += 1;
   if (nsteps > g_dbg_maxsteps) g_dbg_maxsteps = nsteps;
+  if (g_dbg_pixel_steps) { g_dbg_pixel_steps[2 * dbg_loc] = nsteps; g_dbg_pixel_steps[2 * dbg_loc + 1] = nmiss; }
   if (sdf <= 0.0f) {
     step = sdf * step_scale;
     res.x += step * dir.x; res.y += step * dir.y; res.z += step * dir.z;
@@ -1485,7 +1488,7 @@ static void generic_raycast(oracle_engine *e, const oracle_scene *s, oracle_rend
   for (int loc = 0; loc < W * H; loc++) {
     int y = loc / W, x = loc - y * W;
     int loc2 = (int)floorf((float)x / 8.0f) + (int)floorf((float)y / 8.0f) * W;
-    cast_ray(s, r->raycast[loc], x, y, invM, intr, one_over_vs, s->p.mu, r->range[loc2]);
+    cast_ray(s, r->raycast[loc], x, y, invM, intr, one_over_vs, s->p.mu, r->range[loc2], loc);
   }
 }
 
@@ -1696,6 +1699,7 @@ extern "C" int oracle_upload_visible_ids(oracle_engine *, oracle_render_state *r
   memcpy(r->visible_ids.data(), ids, (size_t)count * 4); r->no_visible = count; return 0;
 }
 
+extern "C" int oracle_raycast_debug_buffer(int *buf) { g_dbg_pixel_steps = buf; return 0; }
 extern "C" int oracle_raycast_stats(long long *out4, int reset) {
   out4[0] = g_dbg_steps; out4[1] = g_dbg_interp; out4[2] = g_dbg_rays; out4[3] = g_dbg_maxsteps;
   if (reset) { g_dbg_steps = g_dbg_interp = g_dbg_rays = g_dbg_maxsteps = 0; }
