@@ -353,19 +353,24 @@ __device__ __forceinline__ void resolve_cell_blocks(const VolumeRef &vol, const 
     base[k] = match ? (int)e[k].w * kBlock3 : -1;
     if (!match && (int)e[k].z >= 1) { pending |= 1u << k; h[k] = vol.num_buckets + (int)e[k].z - 1; }
   }
+  // excess chains: all unresolved corners advance one link per round trip.  Branch-free on purpose -- a wave64
+  // executes every instruction any of its lanes needs, and eight predicated blocks with a branch each cost five
+  // times the instructions of selects (resolved corners just re-read their last entry and ignore it).
   while (pending) {
 #pragma unroll
-    for (int k = 0; k < 8; k++)
-      if (pending & (1u << k)) e[k] = *reinterpret_cast<const u32x4 *>(vol.hash + h[k]);
+    for (int k = 0; k < 8; k++) e[k] = *reinterpret_cast<const u32x4 *>(vol.hash + h[k]);
+    unsigned still = 0;
 #pragma unroll
-    for (int k = 0; k < 8; k++)
-      if (pending & (1u << k)) {
-        const bool ok = okx[k & 1] && oky[(k >> 1) & 1] && okz[k >> 2];
-        const bool match = ok && e[k].x == (tx[k & 1] | ty[(k >> 1) & 1]) && (e[k].y & 0xffffu) == tz[k >> 2] && (int)e[k].w >= 0;
-        if (match) { base[k] = (int)e[k].w * kBlock3; pending &= ~(1u << k); }
-        else if ((int)e[k].z >= 1) h[k] = vol.num_buckets + (int)e[k].z - 1;
-        else pending &= ~(1u << k);
-      }
+    for (int k = 0; k < 8; k++) {
+      const bool pk = (pending & (1u << k)) != 0;
+      const bool ok = okx[k & 1] && oky[(k >> 1) & 1] && okz[k >> 2];
+      const bool match = ok && e[k].x == (tx[k & 1] | ty[(k >> 1) & 1]) && (e[k].y & 0xffffu) == tz[k >> 2] && (int)e[k].w >= 0;
+      const bool cont = pk && !match && (int)e[k].z >= 1;
+      base[k] = (pk && match) ? (int)e[k].w * kBlock3 : base[k];
+      h[k] = cont ? vol.num_buckets + (int)e[k].z - 1 : h[k];
+      still |= cont ? (1u << k) : 0u;
+    }
+    pending = still;
   }
 }
 
@@ -418,11 +423,9 @@ __device__ __forceinline__ float trilinear_sdf(const uint2 t[8], float cx, float
   return div_exact((1.0f - cz) * res1 + cz * res2, 32767.0f, 1.0f / 32767.0f);
 }
 
-// readFromSDF_float_interpolated in two load round trips: every block of the cell resolved together, then the 8
-// taps together (a tap whose block is not allocated reads the empty voxel).  Same values as read_sdf_interp.
-__device__ __forceinline__ float read_sdf_interp_batched(const VolumeRef &vol, const Vec3 &pt, float inv_32767) {
-  const float fx = floorf(pt.x), fy = floorf(pt.y), fz = floorf(pt.z);
-  const int x0 = (int)fx, y0 = (int)fy, z0 = (int)fz;
+// The 8 taps (low voxel words) of the trilinear cell at (x0, y0, z0) in two load round trips: every block of the
+// cell resolved together, then the 8 taps together; a tap whose block is not allocated reads the empty voxel.
+__device__ __forceinline__ void gather_taps_batched(const VolumeRef &vol, int x0, int y0, int z0, unsigned raw[8]) {
   const int bxa[2] = {x0 >> 3, (x0 + 1) >> 3}, bya[2] = {y0 >> 3, (y0 + 1) >> 3}, bza[2] = {z0 >> 3, (z0 + 1) >> 3};
   int base[8];
   resolve_cell_blocks(vol, bxa, bya, bza, base);
@@ -430,18 +433,29 @@ __device__ __forceinline__ float read_sdf_interp_batched(const VolumeRef &vol, c
   const unsigned ly[2] = {((unsigned)y0 & 7u) << 3, ((unsigned)(y0 + 1) & 7u) << 3};
   const unsigned lz[2] = {((unsigned)z0 & 7u) << 6, ((unsigned)(z0 + 1) & 7u) << 6};
   const char *vbytes = reinterpret_cast<const char *>(vol.voxels);
-  uint2 t[8];
 #pragma unroll
   for (int k = 0; k < 8; k++) {
     const unsigned lin = lx[k & 1] | ly[(k >> 1) & 1] | lz[k >> 2];
     const unsigned off = (base[k] < 0) ? 0u : ((unsigned)base[k] + lin) * 8u;
-    t[k].x = *reinterpret_cast<const unsigned *>(vbytes + off);
-    t[k].y = 0u;
+    raw[k] = *reinterpret_cast<const unsigned *>(vbytes + off);
   }
 #pragma unroll
-  for (int k = 0; k < 8; k++) t[k].x = (base[k] < 0) ? kEmptyVoxelLo : t[k].x;
-  (void)inv_32767;
-  return trilinear_sdf(t, pt.x - fx, pt.y - fy, pt.z - fz);
+  for (int k = 0; k < 8; k++) raw[k] = (base[k] < 0) ? kEmptyVoxelLo : raw[k];
+}
+
+__device__ __forceinline__ float trilinear_raw(const unsigned raw[8], float cx, float cy, float cz) {
+  uint2 t[8];
+#pragma unroll
+  for (int k = 0; k < 8; k++) t[k] = make_uint2(raw[k], 0u);
+  return trilinear_sdf(t, cx, cy, cz);
+}
+
+// readFromSDF_float_interpolated; same values as read_sdf_interp, two round trips instead of up to nine
+__device__ __forceinline__ float read_sdf_interp_batched(const VolumeRef &vol, const Vec3 &pt) {
+  const float fx = floorf(pt.x), fy = floorf(pt.y), fz = floorf(pt.z);
+  unsigned raw[8];
+  gather_taps_batched(vol, (int)fx, (int)fy, (int)fz, raw);
+  return trilinear_raw(raw, pt.x - fx, pt.y - fy, pt.z - fz);
 }
 
 __device__ __forceinline__ float read_sdf_interp(const VolumeRef &vol, const Vec3 &pt, bool &found, IndexCache &c) {
@@ -617,14 +631,8 @@ __device__ __forceinline__ bool cast_ray(Vec4 &out, int x, int y, const RenderPa
       if ((sdf <= 0.1f) && (sdf >= -0.5f)) {
         const bool all_in = (x0 >> 3) == bx && ((x0 + 1) >> 3) == bx && (y0 >> 3) == by && ((y0 + 1) >> 3) == by &&
                             (z0 >> 3) == bz && ((z0 + 1) >> 3) == bz;
-        if (all_in) {
-          uint2 t[8];
-#pragma unroll
-          for (int k = 0; k < 8; k++) t[k] = make_uint2(raw[k], 0u);
-          sdf = trilinear_sdf(t, res.x - f0x, res.y - f0y, res.z - f0z);
-        } else {
-          sdf = read_sdf_interp_batched(p.vol, res, p.inv_32767);
-        }
+        if (!all_in) gather_taps_batched(p.vol, x0, y0, z0, raw);  // the cell straddles blocks: fetch it properly
+        sdf = trilinear_raw(raw, res.x - f0x, res.y - f0y, res.z - f0z);
       }
       if (sdf <= 0.0f) break;
       step = fmaxf(sdf * step_scale, 1.0f);
@@ -637,7 +645,7 @@ __device__ __forceinline__ bool cast_ray(Vec4 &out, int x, int y, const RenderPa
   if (sdf <= 0.0f) {
     step = sdf * step_scale;
     res.x += step * dir.x; res.y += step * dir.y; res.z += step * dir.z;
-    sdf = read_sdf_interp_batched(p.vol, res, p.inv_32767);
+    sdf = read_sdf_interp_batched(p.vol, res);
     step = sdf * step_scale;
     res.x += step * dir.x; res.y += step * dir.y; res.z += step * dir.z;
     pt_found = true;
@@ -652,7 +660,7 @@ __device__ __forceinline__ bool cast_ray(Vec4 &out, int x, int y, const RenderPa
 // shading code, which keeps it at <= 64 VGPRs = 8 waves per SIMD (the march is latency-bound, occupancy is what
 // hides its load round trips).  SHADE = true adds the normal / colour modes.
 template <int WAVES, bool SHADE, bool DIAG = false>
-__global__ __launch_bounds__(WAVES * 64) void k_render(RenderParams p) {
+__global__ __launch_bounds__(WAVES * 64, 5) void k_render(RenderParams p) {
   // one wavefront = one workgroup = an 8x8 pixel tile = exactly one cell of the 1/8-resolution range image.
   // Single-wave workgroups let the dispatcher backfill a SIMD the moment a short tile finishes (ray lengths vary
   // by 10x between tiles), instead of holding 4 waves until the slowest of a 16x16 tile is done.
