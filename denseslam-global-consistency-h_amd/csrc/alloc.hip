@@ -325,21 +325,30 @@ __global__ __launch_bounds__(256) void k_visible_count(unsigned char *vis_type, 
       }
     }
   }
+  __shared__ TileVisScratch vis_scratch;
   const int t0 = blockIdx.x * kTileEntries + threadIdx.x * 4;
+  unsigned char v[4] = {0, 0, 0, 0};
+  bool cand[4] = {false, false, false, false};
+  short4 pos[4];
+  if (t0 < n_entries) {
+    const uchar4 v4 = *reinterpret_cast<const uchar4 *>(vis_type + t0);
+    v[0] = v4.x; v[1] = v4.y; v[2] = v4.z; v[3] = v4.w;
+#pragma unroll
+    for (int k = 0; k < 4; k++)
+      if (v[k] == 3) {
+        const HashEntry e = load_entry(hash, t0 + k);
+        cand[k] = true;
+        pos[k] = make_short4(e.pos[0], e.pos[1], e.pos[2], 0);
+      }
+  }
+  unsigned char f[4];
+  tile_block_vis<SWAPPING>(vis_scratch, cand, pos, p.M, p.fx, p.fy, p.cx, p.cy, p.voxel_size, p.W, p.H, f);
   int c = 0;
   if (t0 < n_entries) {
-    uchar4 v4 = *reinterpret_cast<const uchar4 *>(vis_type + t0);
-    unsigned char v[4] = {v4.x, v4.y, v4.z, v4.w};
     bool changed = false;
 #pragma unroll
     for (int k = 0; k < 4; k++) {
-      if (v[k] == 3) {
-        const HashEntry e = load_entry(hash, t0 + k);
-        bool vis, vis_enl;
-        check_block_vis<SWAPPING>(vis, vis_enl, e.pos[0], e.pos[1], e.pos[2], p.M, p.fx, p.fy, p.cx, p.cy, p.voxel_size,
-                                  p.W, p.H);
-        if (SWAPPING ? !vis_enl : !vis) { v[k] = 0; changed = true; }
-      }
+      if (v[k] == 3 && !(f[k] & (SWAPPING ? 2 : 1))) { v[k] = 0; changed = true; }
       if (SWAPPING && v[k] > 0 && swap_state[t0 + k] != 2) swap_state[t0 + k] = 1;
       c += (v[k] > 0);
     }

@@ -148,6 +148,45 @@ __device__ __forceinline__ void check_block_vis(bool &vis, bool &vis_enl, int px
   check_point_vis<SWAPPING>(vis, vis_enl, pt, M, fx, fy, cx, cy, W, H);  // 1 0 1
 }
 
+// Frustum test for a SPARSE subset of a tile's entries.  In the table sweeps only ~10 % of the entries need the
+// 8-corner test, scattered over the lanes; tested in place, every wavefront would run the ~250-instruction test once
+// per entry slot (4 per lane) with a handful of lanes active.  Instead the workgroup compacts its candidates into
+// LDS and tests them densely (one candidate per lane), then hands every lane its own results back:
+// out[k] bit 0 = visible, bit 1 = visible in the enlarged frustum (0 for non-candidates).
+struct TileVisScratch {
+  short4 pos[kTileEntries];
+  unsigned short idx[kTileEntries];
+  unsigned char res[kTileEntries];
+  int n;
+};
+
+template <bool SWAPPING>
+__device__ __forceinline__ void tile_block_vis(TileVisScratch &s, const bool cand[4], const short4 pos[4], const Mat4 &M,
+                                               float fx, float fy, float cx, float cy, float voxel_size, int W, int H,
+                                               unsigned char out[4]) {
+  if (threadIdx.x == 0) s.n = 0;
+  *reinterpret_cast<unsigned *>(&s.res[threadIdx.x * 4]) = 0u;
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < 4; k++)
+    if (cand[k]) {
+      const int j = atomicAdd(&s.n, 1);
+      s.pos[j] = pos[k];
+      s.idx[j] = (unsigned short)(threadIdx.x * 4 + k);
+    }
+  __syncthreads();
+  const int n = s.n;
+  for (int j = threadIdx.x; j < n; j += blockDim.x) {
+    const short4 b = s.pos[j];
+    bool vis, vis_enl;
+    check_block_vis<SWAPPING>(vis, vis_enl, b.x, b.y, b.z, M, fx, fy, cx, cy, voxel_size, W, H);
+    s.res[s.idx[j]] = (unsigned char)((vis ? 1 : 0) | (vis_enl ? 2 : 0));
+  }
+  __syncthreads();
+  const unsigned r = *reinterpret_cast<const unsigned *>(&s.res[threadIdx.x * 4]);
+  out[0] = r & 0xff; out[1] = (r >> 8) & 0xff; out[2] = (r >> 16) & 0xff; out[3] = r >> 24;
+}
+
 // ---- workgroup-level ordered ranks -------------------------------------------------------------------------
 // Exclusive prefix sum of one int per thread over a 256-thread workgroup (4 waves), in thread order.
 // `total` receives the workgroup sum.  Uses wave64 ballot-free shuffles + one LDS hop.

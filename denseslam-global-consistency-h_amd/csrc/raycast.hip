@@ -7,7 +7,7 @@
 //
 // Mapping: the ray march is latency/gather bound (random 16-B hash probes + 8-B voxel reads).  One wavefront (= one
 // workgroup) renders an 8x8 pixel tile, i.e. exactly one cell of the 1/8-resolution range image, so (zmin, zmax)
-// and -- mostly -- the marched blocks are wave-uniform.  Runs of equal steps are prefetched 4 samples deep.
+// and -- mostly -- the marched blocks are wave-uniform.
 #include <cstdio>
 #include <cstdlib>
 
@@ -30,20 +30,24 @@ __global__ __launch_bounds__(256) void k_frustum_flags(const HashEntry *__restri
                                                        FrustumParams p, unsigned char *__restrict__ flags,
                                                        int *__restrict__ tile_counts) {
   __shared__ int red[4];
+  __shared__ TileVisScratch vis_scratch;
   const int t0 = blockIdx.x * kTileEntries + threadIdx.x * 4;
-  int c = 0;
+  bool cand[4] = {false, false, false, false};
+  short4 pos[4];
   if (t0 < n_entries) {
-    unsigned char f[4];
 #pragma unroll
     for (int k = 0; k < 4; k++) {
       const HashEntry e = load_entry(hash, t0 + k);
-      bool vis = false, vis_enl = false;
-      if (e.ptr >= 0)
-        check_block_vis<false>(vis, vis_enl, e.pos[0], e.pos[1], e.pos[2], p.M, p.fx, p.fy, p.cx, p.cy, p.voxel_size, p.W,
-                               p.H);
-      f[k] = vis ? 1 : 0;
-      c += f[k];
+      cand[k] = e.ptr >= 0;
+      pos[k] = make_short4(e.pos[0], e.pos[1], e.pos[2], 0);
     }
+  }
+  unsigned char f[4];
+  tile_block_vis<false>(vis_scratch, cand, pos, p.M, p.fx, p.fy, p.cx, p.cy, p.voxel_size, p.W, p.H, f);
+  int c = 0;
+  if (t0 < n_entries) {
+#pragma unroll
+    for (int k = 0; k < 4; k++) { f[k] &= 1; c += f[k]; }
     *reinterpret_cast<uchar4 *>(flags + t0) = make_uchar4(f[0], f[1], f[2], f[3]);
   }
   int tot;
