@@ -152,6 +152,9 @@ class CApi:
     def set_async(self, flag):
         self._call("engine_set_async", self._engine, C.c_int(int(flag)))
 
+    def debug_set_render_tile_budget(self, budget):
+        self._call("debug_set_render_tile_budget", self._engine, C.c_int(budget))
+
     def synchronize(self):
         self._call("engine_synchronize", self._engine)
 

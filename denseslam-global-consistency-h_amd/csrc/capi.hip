@@ -159,6 +159,12 @@ int dslam_engine_destroy(dslam_engine *e) {
   return DSLAM_OK;
 }
 
+int dslam_debug_set_render_tile_budget(dslam_engine *e, int budget) {
+  DSLAM_REQUIRE(e && budget > 0, "bad argument");
+  e->render_tile_budget = budget;
+  return DSLAM_OK;
+}
+
 int dslam_engine_set_async(dslam_engine *e, int async_mode) {
   DSLAM_REQUIRE(e, "null engine");
   e->async_mode = async_mode != 0;
@@ -700,8 +706,7 @@ int dslam_get_image(dslam_engine *e, const dslam_scene *s, dslam_render_state *r
   DSLAM_REQUIRE(e && s && r && M && intr, "null argument");
   DSLAM_REQUIRE(type >= 0 && type <= DSLAM_IMAGE_DEPTH, "unknown image type");
   int rc;
-  if ((rc = launch_find_visible(e, s, r, M, intr))) return rc;
-  if ((rc = launch_expected_depths(e, s, r, M, intr))) return rc;
+  if ((rc = launch_find_visible_and_depths(e, s, r, M, intr))) return rc;
   if ((rc = launch_render(e, s, r, M, intr, type))) return rc;
   return image_out(e, r, type, out_rgba, out_float);
 }

@@ -58,9 +58,9 @@ struct SceneCounters {
 
 struct RenderCounters {
   int no_visible;       // ITMRenderState_VH::noVisibleEntries
-  int render_tiles;     // total render tiles requested by CreateExpectedDepths
   int count_result;     // CountVisibleBlocks result
-  int pad;
+  int render_tiles[2];  // total render tiles requested by CreateExpectedDepths; the two slots alternate per call
+                        // (the range-image kernel reads this call's slot and zeroes the other for the next call)
 };
 
 // ---- arithmetic helpers (operation order = ORUtils operators) --------------------------------------------

@@ -66,6 +66,7 @@ struct dslam_engine {
   long long timer_blocks = 0;
   int *timer_counts_dev = nullptr;    // visible-block count of each timed launch (written by the kernel)
   int sm_count = 256;
+  int render_tile_budget = DSLAM_MAX_RENDERING_BLOCKS;  // MAX_RENDERING_BLOCKS; lowered only by the budget test
   int *misc_counter = nullptr;        // device: small result counters of one-off kernels (depthPostProcessing)
 };
 
@@ -113,6 +114,7 @@ struct dslam_render_state {
   int4 *proj_boxes = nullptr;   // per visible block: render bbox (ul.x, ul.y, lr.x, lr.y)
   float2 *proj_z = nullptr;     // per visible block: z range
   int *proj_req = nullptr;      // per visible block: render tiles required (0 = invalid projection)
+  int proj_parity = 0;          // which RenderCounters::render_tiles slot the current CreateExpectedDepths uses
   dslam::RenderCounters *counters = nullptr;  // device
 };
 
@@ -164,6 +166,8 @@ int launch_count_visible(dslam_engine *e, const dslam_scene *s, const dslam_rend
                          int *out);
 int launch_expected_depths(dslam_engine *e, const dslam_scene *s, dslam_render_state *r, const float *M,
                            const float *intr);
+int launch_find_visible_and_depths(dslam_engine *e, const dslam_scene *s, dslam_render_state *r, const float *M,
+                                   const float *intr);
 int launch_render(dslam_engine *e, const dslam_scene *s, dslam_render_state *r, const float *M, const float *intr,
                   int type);
 int launch_icp_maps(dslam_engine *e, const dslam_scene *s, dslam_render_state *r, const float *M, const float *intr);

@@ -110,11 +110,51 @@ struct ProjParams {
   int W, H;
 };
 
+// ProjectSingleBlock: bbox (in 1/8-resolution cells) and z-range of one block; returns the number of 16x16 render
+// tiles it needs (0 = nothing to render)
+__device__ __forceinline__ int project_single_block(const HashEntry &e, const ProjParams &p, int4 &box, float2 &zr) {
+  if (e.ptr < 0) return 0;
+  int ulx = p.W / 8, uly = p.H / 8, lrx = -1, lry = -1;
+  float zmin = kFarAway, zmax = kVeryClose;
+#pragma unroll
+  for (int corner = 0; corner < 8; corner++) {
+    short tx = e.pos[0], ty = e.pos[1], tz = e.pos[2];
+    tx += (corner & 1) ? 1 : 0; ty += (corner & 2) ? 1 : 0; tz += (corner & 4) ? 1 : 0;
+    Vec4 q;
+    q.x = (float)tx * (float)kBlock * p.voxel_size;
+    q.y = (float)ty * (float)kBlock * p.voxel_size;
+    q.z = (float)tz * (float)kBlock * p.voxel_size;
+    q.w = 1.0f;
+    q = mul(p.M, q);
+    if (q.z < 1e-6f) continue;
+    const float px = (p.fx * q.x / q.z + p.cx) / 8.0f;
+    const float py = (p.fy * q.y / q.z + p.cy) / 8.0f;
+    if ((float)ulx > floorf(px)) ulx = (int)floorf(px);
+    if ((float)lrx < ceilf(px)) lrx = (int)ceilf(px);
+    if ((float)uly > floorf(py)) uly = (int)floorf(py);
+    if ((float)lry < ceilf(py)) lry = (int)ceilf(py);
+    if (zmin > q.z) zmin = q.z;
+    if (zmax < q.z) zmax = q.z;
+  }
+  if (ulx < 0) ulx = 0;
+  if (uly < 0) uly = 0;
+  if (lrx >= p.W) lrx = p.W - 1;
+  if (lry >= p.H) lry = p.H - 1;
+  bool valid = !(ulx > lrx) && !(uly > lry);
+  if (zmin < kVeryClose) zmin = kVeryClose;
+  if (zmax < kVeryClose) valid = false;
+  if (!valid) return 0;
+  const int rx = (int)ceilf((float)(lrx - ulx + 1) / 16.0f), ry = (int)ceilf((float)(lry - uly + 1) / 16.0f);
+  box = make_int4(ulx, uly, lrx, lry);
+  zr = make_float2(zmin, zmax);
+  return rx * ry;
+}
+
 // ProjectSingleBlock for every visible block; records bbox / z-range / required render tiles
 __global__ __launch_bounds__(256) void k_project_blocks(const int *__restrict__ ids, RenderCounters *rc,
                                                         const HashEntry *__restrict__ hash, ProjParams p,
                                                         int4 *__restrict__ boxes, float2 *__restrict__ zr_out,
-                                                        int *__restrict__ req_out, float2 *range, int npix) {
+                                                        int *req_out, float2 *range, int npix, int parity) {
   // (independent job in the same launch) reset the range image to (FAR_AWAY, VERY_CLOSE)
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < npix; i += gridDim.x * blockDim.x)
     range[i] = make_float2(kFarAway, kVeryClose);
@@ -122,63 +162,64 @@ __global__ __launch_bounds__(256) void k_project_blocks(const int *__restrict__ 
   int local_tiles = 0;
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
     const HashEntry e = load_entry(hash, ids[i]);
-    int req = 0;
-    if (e.ptr >= 0) {
-      int ulx = p.W / 8, uly = p.H / 8, lrx = -1, lry = -1;
-      float zmin = kFarAway, zmax = kVeryClose;
-#pragma unroll
-      for (int corner = 0; corner < 8; corner++) {
-        short tx = e.pos[0], ty = e.pos[1], tz = e.pos[2];
-        tx += (corner & 1) ? 1 : 0; ty += (corner & 2) ? 1 : 0; tz += (corner & 4) ? 1 : 0;
-        Vec4 q;
-        q.x = (float)tx * (float)kBlock * p.voxel_size;
-        q.y = (float)ty * (float)kBlock * p.voxel_size;
-        q.z = (float)tz * (float)kBlock * p.voxel_size;
-        q.w = 1.0f;
-        q = mul(p.M, q);
-        if (q.z < 1e-6f) continue;
-        const float px = (p.fx * q.x / q.z + p.cx) / 8.0f;
-        const float py = (p.fy * q.y / q.z + p.cy) / 8.0f;
-        if ((float)ulx > floorf(px)) ulx = (int)floorf(px);
-        if ((float)lrx < ceilf(px)) lrx = (int)ceilf(px);
-        if ((float)uly > floorf(py)) uly = (int)floorf(py);
-        if ((float)lry < ceilf(py)) lry = (int)ceilf(py);
-        if (zmin > q.z) zmin = q.z;
-        if (zmax < q.z) zmax = q.z;
-      }
-      if (ulx < 0) ulx = 0;
-      if (uly < 0) uly = 0;
-      if (lrx >= p.W) lrx = p.W - 1;
-      if (lry >= p.H) lry = p.H - 1;
-      bool valid = !(ulx > lrx) && !(uly > lry);
-      if (zmin < kVeryClose) zmin = kVeryClose;
-      if (zmax < kVeryClose) valid = false;
-      if (valid) {
-        const int rx = (int)ceilf((float)(lrx - ulx + 1) / 16.0f), ry = (int)ceilf((float)(lry - uly + 1) / 16.0f);
-        req = rx * ry;
-        boxes[i] = make_int4(ulx, uly, lrx, lry);
-        zr_out[i] = make_float2(zmin, zmax);
-      }
-    }
+    int4 box;
+    float2 zr;
+    const int req = project_single_block(e, p, box, zr);
+    if (req) { boxes[i] = box; zr_out[i] = zr; }
     req_out[i] = req;
     local_tiles += req;
   }
   for (int d = 32; d > 0; d >>= 1) local_tiles += __shfl_down(local_tiles, d, 64);
-  if ((threadIdx.x & 63) == 0 && local_tiles) atomicAdd(&rc->render_tiles, local_tiles);
+  if ((threadIdx.x & 63) == 0 && local_tiles) atomicAdd(&rc->render_tiles[parity], local_tiles);
 }
 
-// The render-tile budget (MAX_RENDERING_BLOCKS) is applied in visible-list order; only when the total exceeds
-// it does the order matter, and then one lane replays the sequential rule (rare: > 262144 tiles).
-__global__ void k_cap_render_tiles(RenderCounters *rc, int *req) {
-  if (rc->render_tiles < kMaxRenderingBlocks) return;
-  if (threadIdx.x != 0) return;
-  const int n = rc->no_visible;
-  int num = 0;
-  for (int i = 0; i < n; i++) {
-    const int r = req[i];
-    if (r == 0) continue;
-    if (num + r >= kMaxRenderingBlocks) req[i] = 0;
-    else num += r;
+// FindVisibleBlocks' ordered compaction and CreateExpectedDepths' projection in one pass (GetImage runs them back
+// to back with the same pose): the lane that emits visible entry number r also projects it.  The handful of
+// visible entries of a tile are first gathered in LDS so that the projection runs once, densely.
+__global__ __launch_bounds__(256) void k_compact_project(const unsigned char *__restrict__ flags, int n_entries,
+                                                         const int *__restrict__ tile_counts, int *__restrict__ ids,
+                                                         int capacity, RenderCounters *rc,
+                                                         const HashEntry *__restrict__ hash, ProjParams p,
+                                                         int4 *__restrict__ boxes, float2 *__restrict__ zr_out,
+                                                         int *req_out, float2 *range, int npix, int parity) {
+  __shared__ int red[4];
+  __shared__ int s_entry[kTileEntries];
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < npix; i += gridDim.x * blockDim.x)
+    range[i] = make_float2(kFarAway, kVeryClose);
+  const int t0 = blockIdx.x * kTileEntries + threadIdx.x * 4;
+  unsigned char f[4] = {0, 0, 0, 0};
+  if (t0 < n_entries) {
+    const uchar4 v = *reinterpret_cast<const uchar4 *>(flags + t0);
+    f[0] = v.x; f[1] = v.y; f[2] = v.z; f[3] = v.w;
+  }
+  const int c = (f[0] > 0) + (f[1] > 0) + (f[2] > 0) + (f[3] > 0);
+  int tot;
+  int r = block_excl_scan<4>(c, red, tot);
+  const bool last = blockIdx.x == gridDim.x - 1;
+  if (tot == 0 && !last) return;
+  {
+    const int offset = block_sum_strided(tile_counts, blockIdx.x, 1, red);
+    if (last && threadIdx.x == 0) rc->no_visible = (offset + tot) < capacity ? (offset + tot) : capacity;
+#pragma unroll
+    for (int k = 0; k < 4; k++)
+      if (f[k] > 0) s_entry[r++] = t0 + k;
+    __syncthreads();
+    int local_tiles = 0;
+    for (int j = threadIdx.x; j < tot; j += blockDim.x) {
+      const int i = offset + j;
+      if (i >= capacity) break;
+      const int id = s_entry[j];
+      ids[i] = id;
+      const HashEntry e = load_entry(hash, id);
+      int4 box;
+      float2 zr;
+      const int req = project_single_block(e, p, box, zr);
+      if (req) { boxes[i] = box; zr_out[i] = zr; }
+      req_out[i] = req;
+      local_tiles += req;
+    }
+    for (int d = 32; d > 0; d >>= 1) local_tiles += __shfl_down(local_tiles, d, 64);
+    if ((threadIdx.x & 63) == 0 && local_tiles) atomicAdd(&rc->render_tiles[parity], local_tiles);
   }
 }
 
@@ -191,25 +232,27 @@ __global__ void k_cap_render_tiles(RenderCounters *rc, int *req) {
 constexpr int kRangeTile = 16;
 constexpr int kRangeSlices = 32;  // workgroups per tile; each strides over the visible list
 
-__global__ __launch_bounds__(256) void k_fill_range_tiles(const RenderCounters *rc, const int4 *__restrict__ boxes,
+__global__ __launch_bounds__(256) void k_fill_range_tiles(RenderCounters *rc, const int4 *__restrict__ boxes,
                                                           const float2 *__restrict__ zr, const int *__restrict__ req,
-                                                          float2 *range, int W, int tiles_x) {
+                                                          float2 *range, int W, int tiles_x, int parity, int budget) {
   __shared__ int s_min[kRangeTile * kRangeTile], s_max[kRangeTile * kRangeTile];
   const int n = rc->no_visible;
-  // render_tiles was consumed by k_cap_render_tiles; re-arm it for the next CreateExpectedDepths (stream order)
-  if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) const_cast<RenderCounters *>(rc)->render_tiles = 0;
-  if ((int)(blockIdx.y * 256) >= n) return;
+  // the other slot is not used by this call: zero it for the next one (stream order)
+  if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) rc->render_tiles[parity ^ 1] = 0;
+  // The render-tile budget (MAX_RENDERING_BLOCKS) is applied in visible-list order; only when the total exceeds it
+  // does the order matter.  That case (> 262144 tiles) is replayed below, by every workgroup for itself.
+  const bool over_budget = rc->render_tiles[parity] >= budget;
+  if ((int)(blockIdx.y * 256) >= n && !over_budget) return;
   const int tx0 = (blockIdx.x % tiles_x) * kRangeTile, ty0 = (blockIdx.x / tiles_x) * kRangeTile;
   const int far_i = __float_as_int(kFarAway), close_i = __float_as_int(kVeryClose);
   s_min[threadIdx.x] = far_i;
   s_max[threadIdx.x] = close_i;
   __syncthreads();
-  for (int i = blockIdx.y * 256 + threadIdx.x; i < n; i += gridDim.y * 256) {
-    if (req[i] == 0) continue;
+  auto splat = [&](int i) {
     const int4 b = boxes[i];
     const int x0 = b.x > tx0 ? b.x : tx0, x1 = b.z < tx0 + kRangeTile - 1 ? b.z : tx0 + kRangeTile - 1;
     const int y0 = b.y > ty0 ? b.y : ty0, y1 = b.w < ty0 + kRangeTile - 1 ? b.w : ty0 + kRangeTile - 1;
-    if (x0 > x1 || y0 > y1) continue;
+    if (x0 > x1 || y0 > y1) return;
     const float2 z = zr[i];
     const int zmin_i = __float_as_int(z.x), zmax_i = __float_as_int(z.y);
     for (int y = y0; y <= y1; y++)
@@ -218,6 +261,42 @@ __global__ __launch_bounds__(256) void k_fill_range_tiles(const RenderCounters *
         atomicMin(&s_min[c], zmin_i);
         atomicMax(&s_max[c], zmax_i);
       }
+  };
+  if (!over_budget) {
+    for (int i = blockIdx.y * 256 + threadIdx.x; i < n; i += gridDim.y * 256)
+      if (req[i] != 0) splat(i);
+  } else {
+    // sequential rule of the reference's tile list: entry i is dropped when the tiles accepted so far plus its own
+    // reach the budget (a dropped entry does not count).  Chunks of the request list are staged in LDS, lane 0
+    // replays them in order, then the lanes splat the accepted entries of this workgroup's slice.
+    __shared__ int s_req[1024];
+    __shared__ unsigned char s_keep[1024];
+    __shared__ int s_num;
+    if (threadIdx.x == 0) s_num = 0;
+    for (int c0 = 0; c0 < n; c0 += 1024) {
+      __syncthreads();
+      for (int j = threadIdx.x; j < 1024; j += 256) s_req[j] = (c0 + j < n) ? req[c0 + j] : 0;
+      __syncthreads();
+      if (threadIdx.x == 0) {
+        int num = s_num;
+        for (int j = 0; j < 1024; j++) {
+          const int r = s_req[j];
+          bool keep = r != 0;
+          if (keep) {
+            if (num + r >= budget) keep = false;
+            else num += r;
+          }
+          s_keep[j] = keep;
+        }
+        s_num = num;
+      }
+      __syncthreads();
+      for (int j = threadIdx.x; j < 1024; j += 256) {
+        const int i = c0 + j;
+        // this workgroup's slice of the list, as in the common path: i = blockIdx.y * 256 + t (mod gridDim.y * 256)
+        if (i < n && s_keep[j] && (i / 256) % (int)gridDim.y == (int)blockIdx.y) splat(i);
+      }
+    }
   }
   __syncthreads();
   const int mn = s_min[threadIdx.x], mx = s_max[threadIdx.x];
@@ -233,23 +312,54 @@ __global__ __launch_bounds__(256) void k_fill_range_tiles(const RenderCounters *
 // blocks near the camera spill thousands of cells past the corner.  Nothing ever reads them (castRay indexes
 // floor(x/8) + floor(y/8) * W), so they are not filled here; tests compare the corner.
 
-int launch_expected_depths(dslam_engine *e, const dslam_scene *s, dslam_render_state *r, const float *M,
-                           const float *intr) {
-  ProjParams pp;
-  memcpy(pp.M.m, M, 64);
-  pp.fx = intr[0]; pp.fy = intr[1]; pp.cx = intr[2]; pp.cy = intr[3]; pp.voxel_size = s->p.voxel_size;
-  pp.W = r->w; pp.H = r->h;
-  const int npix = r->w * r->h;
-  hipLaunchKernelGGL(k_project_blocks, dim3(512), dim3(256), 0, e->stream, r->visible_ids, r->counters, s->hash, pp,
-                     r->proj_boxes, r->proj_z, r->proj_req, r->range, npix);
-  hipLaunchKernelGGL(k_cap_render_tiles, dim3(1), dim3(64), 0, e->stream, r->counters, r->proj_req);
+static int launch_fill_range(dslam_engine *e, dslam_render_state *r, int parity) {
   // corner = the tiles covering ceil(W/8) x ceil(H/8) cells (clamped to the image); chunks sized for the pool
   const int cw = (r->w + 7) / 8, ch = (r->h + 7) / 8;
   const int tiles_x = (cw + kRangeTile - 1) / kRangeTile, tiles_y = (ch + kRangeTile - 1) / kRangeTile;
   hipLaunchKernelGGL(k_fill_range_tiles, dim3(tiles_x * tiles_y, kRangeSlices), dim3(256), 0, e->stream, r->counters,
-                     r->proj_boxes, r->proj_z, r->proj_req, r->range, r->w, tiles_x);
+                     r->proj_boxes, r->proj_z, r->proj_req, r->range, r->w, tiles_x, parity, e->render_tile_budget);
   DSLAM_HIP(hipGetLastError());
   return DSLAM_OK;
+}
+
+static ProjParams make_proj_params(const dslam_scene *s, const dslam_render_state *r, const float *M, const float *intr) {
+  ProjParams pp;
+  memcpy(pp.M.m, M, 64);
+  pp.fx = intr[0]; pp.fy = intr[1]; pp.cx = intr[2]; pp.cy = intr[3]; pp.voxel_size = s->p.voxel_size;
+  pp.W = r->w; pp.H = r->h;
+  return pp;
+}
+
+int launch_expected_depths(dslam_engine *e, const dslam_scene *s, dslam_render_state *r, const float *M,
+                           const float *intr) {
+  const ProjParams pp = make_proj_params(s, r, M, intr);
+  const int parity = (r->proj_parity ^= 1);
+  hipLaunchKernelGGL(k_project_blocks, dim3(512), dim3(256), 0, e->stream, r->visible_ids, r->counters, s->hash, pp,
+                     r->proj_boxes, r->proj_z, r->proj_req, r->range, r->w * r->h, parity);
+  return launch_fill_range(e, r, parity);
+}
+
+// FindVisibleBlocks + CreateExpectedDepths for the same pose (ITMMainEngine::GetImage's FREECAMERA path): three
+// launches instead of five
+int launch_find_visible_and_depths(dslam_engine *e, const dslam_scene *s, dslam_render_state *r, const float *M,
+                                   const float *intr) {
+  const int N = s->n_entries;
+  DSLAM_REQUIRE(r->n_entries == N, "render state was created for a different scene size");
+  int rc = ensure_scratch(e, N, s->p.num_local_blocks);
+  if (rc) return rc;
+  FrustumParams fp;
+  memcpy(fp.M.m, M, 64);
+  fp.fx = intr[0]; fp.fy = intr[1]; fp.cx = intr[2]; fp.cy = intr[3]; fp.voxel_size = s->p.voxel_size;
+  fp.W = r->w; fp.H = r->h;
+  const int n_tiles = num_tiles(N);
+  unsigned char *flags = reinterpret_cast<unsigned char *>(e->list_c);
+  hipLaunchKernelGGL(k_frustum_flags, dim3(n_tiles), dim3(256), 0, e->stream, s->hash, N, fp, flags, e->tile_counts);
+  const ProjParams pp = make_proj_params(s, r, M, intr);
+  const int parity = (r->proj_parity ^= 1);
+  hipLaunchKernelGGL(k_compact_project, dim3(n_tiles), dim3(256), 0, e->stream, flags, N, e->tile_counts, r->visible_ids,
+                     r->n_local, r->counters, s->hash, pp, r->proj_boxes, r->proj_z, r->proj_req, r->range, r->w * r->h,
+                     parity);
+  return launch_fill_range(e, r, parity);
 }
 
 // ---------------------------------------------------------------------------------------------------------

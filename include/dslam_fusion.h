@@ -131,6 +131,10 @@ int dslam_engine_set_async(dslam_engine *e, int async_mode);
 int dslam_engine_synchronize(dslam_engine *e);
 /* native hipStream_t of the engine, for callers that enqueue their own work (RCCL, torch). */
 void *dslam_engine_stream(dslam_engine *e);
+/* Test hook: CreateExpectedDepths' render-tile budget (MAX_RENDERING_BLOCKS, default DSLAM_MAX_RENDERING_BLOCKS).
+ * Upstream drops, in visible-list order, every block whose tiles would reach the budget; real scenes never get
+ * there (it takes > 262144 tiles), so the parity test of that rule lowers the budget instead. */
+int dslam_debug_set_render_tile_budget(dslam_engine *e, int budget);
 
 /* ---- scene ------------------------------------------------------------------------------------- */
 /* new ITMScene(sceneParams, useSwapping, memoryType) + ResetScene.  ext_voxel_blocks_dev may be NULL

@@ -129,6 +129,7 @@ static const dslam_voxel kEmptyVoxel = {32767, 0, {0, 0, 0}, 0, 0};
 struct oracle_engine {
   dslam_weight_params wp;
   int threads;
+  int render_tile_budget = DSLAM_MAX_RENDERING_BLOCKS;
 };
 
 struct oracle_scene {
@@ -1382,7 +1383,9 @@ static bool project_single_block(const int16_t *bp, const float *M, const float 
 }
 }  // namespace
 
-extern "C" int oracle_create_expected_depths(oracle_engine *, const oracle_scene *s, oracle_render_state *r, const float *M,
+extern "C" int oracle_debug_set_render_tile_budget(oracle_engine *e, int budget) { e->render_tile_budget = budget; return 0; }
+
+extern "C" int oracle_create_expected_depths(oracle_engine *eng, const oracle_scene *s, oracle_render_state *r, const float *M,
                                   const float *intr) {
   const int W = r->w, H = r->h;
   for (auto &px : r->range) { px.x = FAR_AWAY; px.y = VERY_CLOSE; }
@@ -1395,7 +1398,7 @@ extern "C" int oracle_create_expected_depths(oracle_engine *, const oracle_scene
     if (!valid) continue;
     int rx = (int)ceilf((float)(lr.x - ul.x + 1) / 16.0f), ry = (int)ceilf((float)(lr.y - ul.y + 1) / 16.0f);
     int req = rx * ry;
-    if (num_rb + req >= DSLAM_MAX_RENDERING_BLOCKS) continue;
+    if (num_rb + req >= eng->render_tile_budget) continue;
     num_rb += req;
     // the render tiles partition the bbox exactly, so filling the bbox equals filling its tiles
     for (int y = ul.y; y <= lr.y; y++)

@@ -133,3 +133,38 @@ def test_full_size_properties_default_pools(pkg, synth, gpu):
     gpu.deprocess_frame(s, v, rs, M, wl.intr)
     vox = gpu.download_voxel_blocks(s, 0x40000 - 9000, 9000).view(np.uint64)
     assert (vox == 0x7FFF).all()
+
+
+@pytest.mark.parametrize("budget", [40, 300, 1500])
+def test_render_tile_budget_rule(pkg, synth, gpu, oracle, budget):
+    """CreateExpectedDepths drops, in visible-list order, every block whose render tiles would reach
+    MAX_RENDERING_BLOCKS (a dropped block does not count, so later smaller blocks still get in).  Real scenes never
+    reach the 262144-tile budget; the test lowers it through the debug hook on both engines and compares the range
+    image and the raycast that follows, through both call sequences (GetImage and the separate calls)."""
+    wl = synth.s_tiny()
+    p = util.small_params(pkg, wl)
+    imgs, ranges = {}, {}
+    for name, api in (("gpu", gpu), ("oracle", oracle)):
+        s = api.create_scene(p)
+        rs, v = api.create_render_state(s, wl.W, wl.H), api.create_view(wl.W, wl.H)
+        for i in range(4):
+            rgba, mm, M = wl.frame(i)
+            api.view_update(v, rgba, mm, timestamp=float(i))
+            api.process_frame(s, v, rs, M, wl.intr)
+        api.debug_set_render_tile_budget(budget)
+        try:
+            free = api.create_render_state(s, wl.W, wl.H)
+            imgs[name] = api.get_image(s, free, M, wl.intr, pkg.IMAGE_DEPTH)
+            # the tracking path: CreateExpectedDepths on the fusion render state's visible list
+            api.create_expected_depths(s, rs, M, wl.intr)
+            ranges[name] = api.download_range_image(rs)
+            n_vis = api.stats(s, rs)["no_visible_entries"]
+        finally:
+            api.debug_set_render_tile_budget(65536 * 4)
+    cw, ch = (wl.W + 7) // 8, (wl.H + 7) // 8
+    assert np.array_equal(ranges["gpu"][:ch, :cw], ranges["oracle"][:ch, :cw])
+    assert np.array_equal(imgs["gpu"] > 0, imgs["oracle"] > 0)
+    assert np.abs(imgs["gpu"] - imgs["oracle"]).max() <= 1e-4
+    assert budget >= n_vis or (imgs["gpu"] > 0).sum() <= (full > 0).sum()
+    if budget == 40:
+        assert (imgs["gpu"] > 0).sum() < (full > 0).sum(), "a budget far below the visible count must lose surface"
