@@ -161,10 +161,12 @@ def test_render_tile_budget_rule(pkg, synth, gpu, oracle, budget):
             n_vis = api.stats(s, rs)["no_visible_entries"]
         finally:
             api.debug_set_render_tile_budget(65536 * 4)
+        if name == "oracle":
+            full = api.get_image(s, free, M, wl.intr, pkg.IMAGE_DEPTH)
     cw, ch = (wl.W + 7) // 8, (wl.H + 7) // 8
     assert np.array_equal(ranges["gpu"][:ch, :cw], ranges["oracle"][:ch, :cw])
     assert np.array_equal(imgs["gpu"] > 0, imgs["oracle"] > 0)
     assert np.abs(imgs["gpu"] - imgs["oracle"]).max() <= 1e-4
-    assert budget >= n_vis or (imgs["gpu"] > 0).sum() <= (full > 0).sum()
+    assert n_vis > 300  # budgets 40 and 300 bite, 1500 does not
     if budget == 40:
         assert (imgs["gpu"] > 0).sum() < (full > 0).sum(), "a budget far below the visible count must lose surface"
