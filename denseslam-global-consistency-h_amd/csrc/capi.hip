@@ -289,6 +289,7 @@ int dslam_render_state_create(dslam_engine *e, const dslam_scene *s, int w, int 
   DSLAM_HIP(hipMalloc(&r->proj_boxes, (size_t)r->n_local * sizeof(int4)));
   DSLAM_HIP(hipMalloc(&r->proj_z, (size_t)r->n_local * sizeof(float2)));
   DSLAM_HIP(hipMalloc(&r->proj_req, (size_t)r->n_local * sizeof(int)));
+  DSLAM_HIP(hipMalloc(&r->proj_wg_tiles, (size_t)(r->n_entries / 1024 + 1024) * sizeof(int)));
   DSLAM_HIP(hipMalloc(&r->counters, sizeof(RenderCounters)));
   DSLAM_HIP(hipMemsetAsync(r->visible_type, 0, r->n_entries, e->stream));
   DSLAM_HIP(hipMemsetAsync(r->counters, 0, sizeof(RenderCounters), e->stream));
@@ -306,7 +307,7 @@ int dslam_render_state_destroy(dslam_render_state *r) {
   (void)hipStreamSynchronize(r->engine->stream);
   free_dev(r->visible_ids); free_dev(r->visible_type); free_dev(r->range); free_dev(r->raycast);
   free_dev(r->image_rgba); free_dev(r->image_float); free_dev(r->icp_points); free_dev(r->icp_normals);
-  free_dev(r->proj_boxes); free_dev(r->proj_z); free_dev(r->proj_req); free_dev(r->counters);
+  free_dev(r->proj_boxes); free_dev(r->proj_z); free_dev(r->proj_req); free_dev(r->proj_wg_tiles); free_dev(r->counters);
   delete r;
   return DSLAM_OK;
 }

@@ -59,8 +59,7 @@ struct SceneCounters {
 struct RenderCounters {
   int no_visible;       // ITMRenderState_VH::noVisibleEntries
   int count_result;     // CountVisibleBlocks result
-  int render_tiles[2];  // total render tiles requested by CreateExpectedDepths; the two slots alternate per call
-                        // (the range-image kernel reads this call's slot and zeroes the other for the next call)
+  int pad[2];
 };
 
 // ---- arithmetic helpers (operation order = ORUtils operators) --------------------------------------------

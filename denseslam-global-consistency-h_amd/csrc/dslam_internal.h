@@ -114,7 +114,7 @@ struct dslam_render_state {
   int4 *proj_boxes = nullptr;   // per visible block: render bbox (ul.x, ul.y, lr.x, lr.y)
   float2 *proj_z = nullptr;     // per visible block: z range
   int *proj_req = nullptr;      // per visible block: render tiles required (0 = invalid projection)
-  int proj_parity = 0;          // which RenderCounters::render_tiles slot the current CreateExpectedDepths uses
+  int *proj_wg_tiles = nullptr; // render tiles requested per workgroup of the projection pass (summed by the next kernel)
   dslam::RenderCounters *counters = nullptr;  // device
 };
 

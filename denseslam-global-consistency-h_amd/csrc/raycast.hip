@@ -154,7 +154,10 @@ __device__ __forceinline__ int project_single_block(const HashEntry &e, const Pr
 __global__ __launch_bounds__(256) void k_project_blocks(const int *__restrict__ ids, RenderCounters *rc,
                                                         const HashEntry *__restrict__ hash, ProjParams p,
                                                         int4 *__restrict__ boxes, float2 *__restrict__ zr_out,
-                                                        int *req_out, float2 *range, int npix, int parity) {
+                                                        int *req_out, float2 *range, int npix, int *wg_tiles) {
+  __shared__ int s_tiles;
+  if (threadIdx.x == 0) s_tiles = 0;
+  __syncthreads();
   // (independent job in the same launch) reset the range image to (FAR_AWAY, VERY_CLOSE)
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < npix; i += gridDim.x * blockDim.x)
     range[i] = make_float2(kFarAway, kVeryClose);
@@ -170,7 +173,10 @@ __global__ __launch_bounds__(256) void k_project_blocks(const int *__restrict__ 
     local_tiles += req;
   }
   for (int d = 32; d > 0; d >>= 1) local_tiles += __shfl_down(local_tiles, d, 64);
-  if ((threadIdx.x & 63) == 0 && local_tiles) atomicAdd(&rc->render_tiles[parity], local_tiles);
+  if ((threadIdx.x & 63) == 0 && local_tiles) atomicAdd(&s_tiles, local_tiles);
+  __syncthreads();
+  // per-workgroup totals instead of one contended global counter; the range-image kernel sums them
+  if (threadIdx.x == 0) wg_tiles[blockIdx.x] = s_tiles;
 }
 
 // FindVisibleBlocks' ordered compaction and CreateExpectedDepths' projection in one pass (GetImage runs them back
@@ -181,9 +187,11 @@ __global__ __launch_bounds__(256) void k_compact_project(const unsigned char *__
                                                          int capacity, RenderCounters *rc,
                                                          const HashEntry *__restrict__ hash, ProjParams p,
                                                          int4 *__restrict__ boxes, float2 *__restrict__ zr_out,
-                                                         int *req_out, float2 *range, int npix, int parity) {
+                                                         int *req_out, float2 *range, int npix, int *wg_tiles) {
   __shared__ int red[4];
+  __shared__ int s_tiles;
   __shared__ int s_entry[kTileEntries];
+  if (threadIdx.x == 0) s_tiles = 0;
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < npix; i += gridDim.x * blockDim.x)
     range[i] = make_float2(kFarAway, kVeryClose);
   const int t0 = blockIdx.x * kTileEntries + threadIdx.x * 4;
@@ -196,7 +204,10 @@ __global__ __launch_bounds__(256) void k_compact_project(const unsigned char *__
   int tot;
   int r = block_excl_scan<4>(c, red, tot);
   const bool last = blockIdx.x == gridDim.x - 1;
-  if (tot == 0 && !last) return;
+  if (tot == 0 && !last) {
+    if (threadIdx.x == 0) wg_tiles[blockIdx.x] = 0;
+    return;
+  }
   {
     const int offset = block_sum_strided(tile_counts, blockIdx.x, 1, red);
     if (last && threadIdx.x == 0) rc->no_visible = (offset + tot) < capacity ? (offset + tot) : capacity;
@@ -219,8 +230,10 @@ __global__ __launch_bounds__(256) void k_compact_project(const unsigned char *__
       local_tiles += req;
     }
     for (int d = 32; d > 0; d >>= 1) local_tiles += __shfl_down(local_tiles, d, 64);
-    if ((threadIdx.x & 63) == 0 && local_tiles) atomicAdd(&rc->render_tiles[parity], local_tiles);
+    if ((threadIdx.x & 63) == 0 && local_tiles) atomicAdd(&s_tiles, local_tiles);
   }
+  __syncthreads();
+  if (threadIdx.x == 0) wg_tiles[blockIdx.x] = s_tiles;
 }
 
 // Fill the range image.  The render tiles of a block partition its bbox, so min/max over the bbox is identical to
@@ -232,16 +245,17 @@ __global__ __launch_bounds__(256) void k_compact_project(const unsigned char *__
 constexpr int kRangeTile = 16;
 constexpr int kRangeSlices = 32;  // workgroups per tile; each strides over the visible list
 
-__global__ __launch_bounds__(256) void k_fill_range_tiles(RenderCounters *rc, const int4 *__restrict__ boxes,
+__global__ __launch_bounds__(256) void k_fill_range_tiles(const RenderCounters *rc, const int4 *__restrict__ boxes,
                                                           const float2 *__restrict__ zr, const int *__restrict__ req,
-                                                          float2 *range, int W, int tiles_x, int parity, int budget) {
+                                                          float2 *range, int W, int tiles_x,
+                                                          const int *__restrict__ wg_tiles, int n_wg_tiles, int budget) {
   __shared__ int s_min[kRangeTile * kRangeTile], s_max[kRangeTile * kRangeTile];
+  __shared__ int red[4];
   const int n = rc->no_visible;
-  // the other slot is not used by this call: zero it for the next one (stream order)
-  if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) rc->render_tiles[parity ^ 1] = 0;
-  // The render-tile budget (MAX_RENDERING_BLOCKS) is applied in visible-list order; only when the total exceeds it
-  // does the order matter.  That case (> 262144 tiles) is replayed below, by every workgroup for itself.
-  const bool over_budget = rc->render_tiles[parity] >= budget;
+  // The render-tile budget (MAX_RENDERING_BLOCKS) is applied in visible-list order; only when the total (the sum of
+  // the projection pass' per-workgroup counts) exceeds it does the order matter.  That case (> 262144 tiles) is
+  // replayed below, by every workgroup for itself.
+  const bool over_budget = block_sum_strided(wg_tiles, n_wg_tiles, 1, red) >= budget;
   if ((int)(blockIdx.y * 256) >= n && !over_budget) return;
   const int tx0 = (blockIdx.x % tiles_x) * kRangeTile, ty0 = (blockIdx.x / tiles_x) * kRangeTile;
   const int far_i = __float_as_int(kFarAway), close_i = __float_as_int(kVeryClose);
@@ -312,12 +326,15 @@ __global__ __launch_bounds__(256) void k_fill_range_tiles(RenderCounters *rc, co
 // blocks near the camera spill thousands of cells past the corner.  Nothing ever reads them (castRay indexes
 // floor(x/8) + floor(y/8) * W), so they are not filled here; tests compare the corner.
 
-static int launch_fill_range(dslam_engine *e, dslam_render_state *r, int parity) {
+constexpr int kProjectGrid = 512;
+
+static int launch_fill_range(dslam_engine *e, dslam_render_state *r, int n_wg_tiles) {
   // corner = the tiles covering ceil(W/8) x ceil(H/8) cells (clamped to the image); chunks sized for the pool
   const int cw = (r->w + 7) / 8, ch = (r->h + 7) / 8;
   const int tiles_x = (cw + kRangeTile - 1) / kRangeTile, tiles_y = (ch + kRangeTile - 1) / kRangeTile;
   hipLaunchKernelGGL(k_fill_range_tiles, dim3(tiles_x * tiles_y, kRangeSlices), dim3(256), 0, e->stream, r->counters,
-                     r->proj_boxes, r->proj_z, r->proj_req, r->range, r->w, tiles_x, parity, e->render_tile_budget);
+                     r->proj_boxes, r->proj_z, r->proj_req, r->range, r->w, tiles_x, r->proj_wg_tiles, n_wg_tiles,
+                     e->render_tile_budget);
   DSLAM_HIP(hipGetLastError());
   return DSLAM_OK;
 }
@@ -333,10 +350,9 @@ static ProjParams make_proj_params(const dslam_scene *s, const dslam_render_stat
 int launch_expected_depths(dslam_engine *e, const dslam_scene *s, dslam_render_state *r, const float *M,
                            const float *intr) {
   const ProjParams pp = make_proj_params(s, r, M, intr);
-  const int parity = (r->proj_parity ^= 1);
-  hipLaunchKernelGGL(k_project_blocks, dim3(512), dim3(256), 0, e->stream, r->visible_ids, r->counters, s->hash, pp,
-                     r->proj_boxes, r->proj_z, r->proj_req, r->range, r->w * r->h, parity);
-  return launch_fill_range(e, r, parity);
+  hipLaunchKernelGGL(k_project_blocks, dim3(kProjectGrid), dim3(256), 0, e->stream, r->visible_ids, r->counters, s->hash,
+                     pp, r->proj_boxes, r->proj_z, r->proj_req, r->range, r->w * r->h, r->proj_wg_tiles);
+  return launch_fill_range(e, r, kProjectGrid);
 }
 
 // FindVisibleBlocks + CreateExpectedDepths for the same pose (ITMMainEngine::GetImage's FREECAMERA path): three
@@ -355,11 +371,10 @@ int launch_find_visible_and_depths(dslam_engine *e, const dslam_scene *s, dslam_
   unsigned char *flags = reinterpret_cast<unsigned char *>(e->list_c);
   hipLaunchKernelGGL(k_frustum_flags, dim3(n_tiles), dim3(256), 0, e->stream, s->hash, N, fp, flags, e->tile_counts);
   const ProjParams pp = make_proj_params(s, r, M, intr);
-  const int parity = (r->proj_parity ^= 1);
   hipLaunchKernelGGL(k_compact_project, dim3(n_tiles), dim3(256), 0, e->stream, flags, N, e->tile_counts, r->visible_ids,
                      r->n_local, r->counters, s->hash, pp, r->proj_boxes, r->proj_z, r->proj_req, r->range, r->w * r->h,
-                     parity);
-  return launch_fill_range(e, r, parity);
+                     r->proj_wg_tiles);
+  return launch_fill_range(e, r, n_tiles);
 }
 
 // ---------------------------------------------------------------------------------------------------------
