@@ -332,7 +332,8 @@ static int launch_fill_range(dslam_engine *e, dslam_render_state *r, int n_wg_ti
   // corner = the tiles covering ceil(W/8) x ceil(H/8) cells (clamped to the image); chunks sized for the pool
   const int cw = (r->w + 7) / 8, ch = (r->h + 7) / 8;
   const int tiles_x = (cw + kRangeTile - 1) / kRangeTile, tiles_y = (ch + kRangeTile - 1) / kRangeTile;
-  hipLaunchKernelGGL(k_fill_range_tiles, dim3(tiles_x * tiles_y, kRangeSlices), dim3(256), 0, e->stream, r->counters,
+  static const int slices = getenv("DSLAM_DBG_SLICES") ? atoi(getenv("DSLAM_DBG_SLICES")) : kRangeSlices;
+  hipLaunchKernelGGL(k_fill_range_tiles, dim3(tiles_x * tiles_y, slices), dim3(256), 0, e->stream, r->counters,
                      r->proj_boxes, r->proj_z, r->proj_req, r->range, r->w, tiles_x, r->proj_wg_tiles, n_wg_tiles,
                      e->render_tile_budget);
   DSLAM_HIP(hipGetLastError());
@@ -682,12 +683,18 @@ struct RenderParams {
   uchar4 *out_rgba;
   float *out_float;
   int type;  // dslam_image_type, or -1: raycast only
-  unsigned long long *dbg_waves;  // diagnostics only (env DSLAM_DBG_WAVETIME=<file>): per wave {cycles, max iterations}
+  unsigned long long *dbg_waves;  // diagnostics only (env DSLAM_DBG_WAVETIME=<file>): per wave {cycles, max iterations, straddling iterations, their cycles, setup cycles, refinement cycles}
   int dbg_flags;  // diagnostics only (env DSLAM_DBG_FLAGS: 4 = probe the bucket bitmap first, 8 = 16x16 workgroups)
 };
 
+// DIAG instantiation only: wave-level split of the march (single-wave workgroups): iterations in which some lane took
+// the straddling-cell path, and the cycles of those iterations
+struct MarchDiag { int iters, wave_iters, slow_iters; unsigned long long slow_cycles, setup_cycles, tail_cycles; };
+
+template <bool DIAG>
 __device__ __forceinline__ bool cast_ray(Vec4 &out, int x, int y, const RenderParams &p, const float2 minmax,
-                                         int &iters_out) {
+                                         MarchDiag &diag) {
+  const unsigned long long t_enter = DIAG ? __builtin_amdgcn_s_memtime() : 0ull;
   Vec4 pc;
   Vec3 ps, pe, dir, res;
   float sdf = 1.0f;
@@ -716,8 +723,25 @@ __device__ __forceinline__ bool cast_ray(Vec4 &out, int x, int y, const RenderPa
   res = ps;
   IndexCache cache = {0x7fffffff, 0x7fffffff, 0x7fffffff, -1};
   int iter = 0;
+  __shared__ int s_slow_flag;
+  unsigned long long t_iter = 0;
+  if (DIAG) {
+    diag.slow_iters = 0; diag.wave_iters = 0; diag.slow_cycles = 0;
+    diag.setup_cycles = __builtin_amdgcn_s_memtime() - t_enter;
+    s_slow_flag = 0;
+    t_iter = __builtin_amdgcn_s_memtime();
+  }
   while (total < total_max) {
     ++iter;
+    if (DIAG) {  // account the previous wave iteration
+      const unsigned long long now = __builtin_amdgcn_s_memtime();
+      if (iter > 1) {
+        diag.wave_iters++;
+        if (s_slow_flag) { diag.slow_iters++; diag.slow_cycles += now - t_iter; }
+      }
+      s_slow_flag = 0;
+      t_iter = now;
+    }
     // Measured on MI355X (DSLAM_DBG_WAVETIME dump): the launch keeps only ~1.1 waves per SIMD resident on average
     // and ends when its longest wave ends, and a lone wave64 issues one VALU instruction per 4 cycles -- a step costs
     // its load round trips (~700 cycles each) PLUS 4 cycles for every instruction ANY lane of the wave executes.
@@ -760,7 +784,10 @@ __device__ __forceinline__ bool cast_ray(Vec4 &out, int x, int y, const RenderPa
       if ((sdf <= 0.1f) && (sdf >= -0.5f)) {
         const bool all_in = (x0 >> 3) == bx && ((x0 + 1) >> 3) == bx && (y0 >> 3) == by && ((y0 + 1) >> 3) == by &&
                             (z0 >> 3) == bz && ((z0 + 1) >> 3) == bz;
-        if (!all_in) gather_taps_batched(p.vol, x0, y0, z0, raw);  // the cell straddles blocks: fetch it properly
+        if (!all_in) {  // the cell straddles blocks: fetch it properly
+          if (DIAG) s_slow_flag = 1;
+          gather_taps_batched(p.vol, x0, y0, z0, raw);
+        }
         sdf = trilinear_raw(raw, res.x - f0x, res.y - f0y, res.z - f0z);
       }
       if (sdf <= 0.0f) break;
@@ -769,7 +796,8 @@ __device__ __forceinline__ bool cast_ray(Vec4 &out, int x, int y, const RenderPa
     res.x += step * dir.x; res.y += step * dir.y; res.z += step * dir.z;
     total += step;
   }
-  iters_out = iter;
+  diag.iters = iter;
+  const unsigned long long t_tail = DIAG ? __builtin_amdgcn_s_memtime() : 0ull;
   bool pt_found;
   if (sdf <= 0.0f) {
     step = sdf * step_scale;
@@ -782,6 +810,7 @@ __device__ __forceinline__ bool cast_ray(Vec4 &out, int x, int y, const RenderPa
     pt_found = false;
   }
   out.x = res.x; out.y = res.y; out.z = res.z; out.w = pt_found ? 1.0f : 0.0f;
+  if (DIAG) diag.tail_cycles = __builtin_amdgcn_s_memtime() - t_tail;
   return pt_found;
 }
 
@@ -802,17 +831,22 @@ __global__ __launch_bounds__(WAVES * 64, 5) void k_render(RenderParams p) {
   const int loc = x + y * p.W;
   const int loc2 = (int)floorf((float)x / 8.0f) + (int)floorf((float)y / 8.0f) * p.W;
   Vec4 pr;
-  int iters = 0;
+  MarchDiag diag;
   const unsigned long long t_start = DIAG ? __builtin_amdgcn_s_memtime() : 0ull;
-  cast_ray(pr, x, y, p, p.range[loc2], iters);
+  cast_ray<DIAG>(pr, x, y, p, p.range[loc2], diag);
   if (DIAG) {  // diagnostic instantiation (DSLAM_DBG_WAVETIME): per-wave cycles and march length
     const unsigned long long dt = __builtin_amdgcn_s_memtime() - t_start;
-    int mx = iters;
+    // the lane with the longest march saw every wave iteration
+    int mx = diag.iters;
     for (int d = 32; d > 0; d >>= 1) { const int o = __shfl_xor(mx, d, 64); mx = mx > o ? mx : o; }
-    if (lane == 0) {
+    if (diag.iters == mx) {  // (several lanes may tie; they write the same values)
       const int wid = (blockIdx.y * gridDim.x + blockIdx.x) * WAVES + wave;
-      p.dbg_waves[2 * wid] = dt;
-      p.dbg_waves[2 * wid + 1] = (unsigned long long)mx;
+      p.dbg_waves[6 * wid] = dt;
+      p.dbg_waves[6 * wid + 1] = (unsigned long long)mx;
+      p.dbg_waves[6 * wid + 2] = (unsigned long long)diag.slow_iters;
+      p.dbg_waves[6 * wid + 3] = diag.slow_cycles;
+      p.dbg_waves[6 * wid + 4] = diag.setup_cycles;
+      p.dbg_waves[6 * wid + 5] = diag.tail_cycles;
     }
   }
   p.raycast[loc] = make_float4(pr.x, pr.y, pr.z, pr.w);
@@ -889,8 +923,8 @@ int launch_render(dslam_engine *e, const dslam_scene *s, dslam_render_state *r, 
   const int n_waves = ((r->w + 7) / 8) * ((r->h + 7) / 8);
   unsigned long long *dbg_host = nullptr;
   if (dbg_file && ++dbg_calls == 30) {  // one snapshot, well into the run
-    DSLAM_HIP(hipHostMalloc((void **)&dbg_host, (size_t)n_waves * 16, hipHostMallocDefault));
-    memset(dbg_host, 0, (size_t)n_waves * 16);
+    DSLAM_HIP(hipHostMalloc((void **)&dbg_host, (size_t)n_waves * 48, hipHostMallocDefault));
+    memset(dbg_host, 0, (size_t)n_waves * 48);
     rp.dbg_waves = dbg_host;
   }
   const dim3 grid1((r->w + 7) / 8, (r->h + 7) / 8);
@@ -906,7 +940,7 @@ int launch_render(dslam_engine *e, const dslam_scene *s, dslam_render_state *r, 
   if (dbg_host) {
     DSLAM_HIP(hipStreamSynchronize(e->stream));
     FILE *f = fopen(dbg_file, "wb");
-    if (f) { fwrite(dbg_host, 16, n_waves, f); fclose(f); }
+    if (f) { fwrite(dbg_host, 48, n_waves, f); fclose(f); }
     (void)hipHostFree(dbg_host);
   }
   return DSLAM_OK;
