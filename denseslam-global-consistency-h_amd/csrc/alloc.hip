@@ -42,26 +42,6 @@ __global__ __launch_bounds__(256) void k_reset_tables(HashEntry *hash, int n_ent
   }
 }
 
-// bucket occupancy bitmap from scratch (after a bulk upload of the hash table)
-__global__ __launch_bounds__(256) void k_rebuild_bucket_bits(const HashEntry *__restrict__ hash, int num_buckets,
-                                                             unsigned *__restrict__ bits) {
-  const int words = (num_buckets + 31) / 32;
-  for (int w = blockIdx.x * blockDim.x + threadIdx.x; w < words; w += gridDim.x * blockDim.x) {
-    unsigned v = 0;
-    for (int b = 0; b < 32; b++) {
-      const int t = w * 32 + b;
-      if (t < num_buckets && hash[t].ptr >= -1) v |= 1u << b;
-    }
-    bits[w] = v;
-  }
-}
-
-int launch_rebuild_bucket_bits(dslam_engine *e, dslam_scene *s) {
-  hipLaunchKernelGGL(k_rebuild_bucket_bits, dim3(256), dim3(256), 0, e->stream, s->hash, s->p.num_buckets, s->bucket_bits);
-  DSLAM_HIP(hipGetLastError());
-  return DSLAM_OK;
-}
-
 int launch_scene_reset(dslam_engine *e, dslam_scene *s) {
   const size_t n16 = (size_t)s->p.num_local_blocks * kBlock3 / 2;
   hipLaunchKernelGGL(k_fill_voxels, dim3(4096), dim3(256), 0, e->stream, reinterpret_cast<uint4 *>(s->voxels), n16);
@@ -69,7 +49,6 @@ int launch_scene_reset(dslam_engine *e, dslam_scene *s) {
                      s->last_seen, s->p.num_local_blocks, s->excess_list, s->p.num_excess, s->counters);
   DSLAM_HIP(hipMemsetAsync(s->masks, 0, (size_t)s->p.num_local_blocks * 2 * s->history_words * sizeof(unsigned long long),
                            e->stream));
-  DSLAM_HIP(hipMemsetAsync(s->bucket_bits, 0, (size_t)((s->p.num_buckets + 31) / 32) * sizeof(unsigned), e->stream));
   if (s->swap_state) DSLAM_HIP(hipMemsetAsync(s->swap_state, 0, s->n_entries, e->stream));
   DSLAM_HIP(hipGetLastError());
   return DSLAM_OK;
@@ -152,10 +131,13 @@ struct MarkParams {
 template <int PHASE>
 __global__ __launch_bounds__(256) void k_mark(MarkParams p) {
   const int idx = blockIdx.x * 256 + threadIdx.x;
-  if (idx >= p.W * p.H) return;
-  const int y = idx / p.W, x = idx - y * p.W;
-  const float d = p.depth[idx];
-  if (d <= 0 || (d - p.mu) < 0 || (d - p.mu) < p.frustum_min || (d + p.mu) > p.frustum_max) return;
+  const int lane = threadIdx.x & 63;
+  // every lane stays in the kernel (invalid pixels march zero steps): the order-key atomics below are aggregated
+  // per wavefront, which needs the wave converged
+  const bool in_image = idx < p.W * p.H;
+  const int y = in_image ? idx / p.W : 0, x = in_image ? idx - y * p.W : 0;
+  const float d = in_image ? p.depth[idx] : -1.0f;
+  const bool valid = !(d <= 0 || (d - p.mu) < 0 || (d - p.mu) < p.frustum_min || (d + p.mu) > p.frustum_max);
 
   Vec3 pc;
   pc.z = d;
@@ -171,50 +153,66 @@ __global__ __launch_bounds__(256) void k_mark(MarkParams p) {
   Vec3 pe = {q.x * p.one_over_block, q.y * p.one_over_block, q.z * p.one_over_block};
   Vec3 dir = {pe.x - pt.x, pe.y - pt.y, pe.z - pt.z};
   norm = sqrtf(dir.x * dir.x + dir.y * dir.y + dir.z * dir.z);
-  const int no_steps = (int)ceilf(2.0f * norm);
+  int no_steps = valid ? (int)ceilf(2.0f * norm) : 0;
   const float div = (float)(no_steps - 1);
   dir.x /= div; dir.y /= div; dir.z /= div;
+  if (no_steps > p.step_cap) {  // the order key cannot encode later steps: report instead of mis-ordering
+    if (PHASE == 0) atomicOr(&p.cnt->error_flags, 1);
+    no_steps = p.step_cap;
+  }
+  int wave_steps = no_steps;
+  for (int o = 32; o > 0; o >>= 1) { const int v = __shfl_xor(wave_steps, o, 64); wave_steps = v > wave_steps ? v : wave_steps; }
 
-  for (int i = 0; i < no_steps; i++) {
-    if (i >= p.step_cap) {  // the order key cannot encode this step: report instead of mis-ordering
-      if (PHASE == 0) atomicOr(&p.cnt->error_flags, 1);
-      break;
-    }
-    const short bx = (short)(int)floorf(pt.x), by = (short)(int)floorf(pt.y), bz = (short)(int)floorf(pt.z);
-    int h = hash_index(bx, by, bz, p.mask);
-    HashEntry e = load_entry(p.hash, h);
-    bool found = false;
-    if (e.pos[0] == bx && e.pos[1] == by && e.pos[2] == bz && e.ptr >= -1) {
-      if (PHASE == 0) p.vis_type[h] = (e.ptr == -1) ? 2 : 1;
-      found = true;
-    }
-    if (!found) {
-      bool excess = false;
-      if (e.ptr >= -1) {
-        while (e.offset >= 1) {
-          h = p.num_buckets + e.offset - 1;
-          e = load_entry(p.hash, h);
-          if (e.pos[0] == bx && e.pos[1] == by && e.pos[2] == bz && e.ptr >= -1) {
-            if (PHASE == 0) p.vis_type[h] = (e.ptr == -1) ? 2 : 1;
-            found = true;
-            break;
-          }
-        }
-        excess = true;
+  for (int i = 0; i < wave_steps; i++) {
+    bool need = false;    // this lane asks for slot h at this step
+    bool excess = false;
+    int h = 0;
+    short bx = 0, by = 0, bz = 0;
+    if (i < no_steps) {
+      bx = (short)(int)floorf(pt.x); by = (short)(int)floorf(pt.y); bz = (short)(int)floorf(pt.z);
+      h = hash_index(bx, by, bz, p.mask);
+      HashEntry e = load_entry(p.hash, h);
+      bool found = false;
+      if (e.pos[0] == bx && e.pos[1] == by && e.pos[2] == bz && e.ptr >= -1) {
+        if (PHASE == 0) p.vis_type[h] = (e.ptr == -1) ? 2 : 1;
+        found = true;
       }
       if (!found) {
-        const unsigned key = (unsigned)idx * (unsigned)p.step_cap + (unsigned)i + 1u;
-        if (PHASE == 0) {
-          atomicMax(&p.keys[h], key);
-        } else if (p.keys[h] == key) {
-          atomicAdd(&p.tile_counts[(h / kTileEntries) * 2 + (excess ? 1 : 0)], 1);  // commit pass 1, for free
-          p.alloc_type[h] = excess ? 2 : 1;
-          if (!excess) p.vis_type[h] = 1;
-          p.coords[h] = make_short4(bx, by, bz, 1);
+        if (e.ptr >= -1) {
+          while (e.offset >= 1) {
+            h = p.num_buckets + e.offset - 1;
+            e = load_entry(p.hash, h);
+            if (e.pos[0] == bx && e.pos[1] == by && e.pos[2] == bz && e.ptr >= -1) {
+              if (PHASE == 0) p.vis_type[h] = (e.ptr == -1) ? 2 : 1;
+              found = true;
+              break;
+            }
+          }
+          excess = true;
         }
+        need = !found;
       }
+      pt.x += dir.x; pt.y += dir.y; pt.z += dir.z;
     }
-    pt.x += dir.x; pt.y += dir.y; pt.z += dir.z;
+    const unsigned key = (unsigned)idx * (unsigned)p.step_cap + (unsigned)i + 1u;
+    if (PHASE == 0) {
+      // Neighbouring pixels ask for the same slot (a block covers hundreds of pixels), and same-address atomics
+      // serialise at ~10 ns each on this part.  Keys grow with the pixel index, so within a wavefront the highest
+      // lane of each group of equal slots holds the group's maximum: only that lane issues the atomicMax.
+      unsigned long long todo = __ballot(need);
+      while (todo) {
+        const int leader = __ffsll((long long)todo) - 1;
+        const int hl = __shfl(h, leader, 64);
+        const unsigned long long grp = __ballot(need && h == hl);
+        if (lane == 63 - __clzll((long long)grp)) atomicMax(&p.keys[h], key);
+        todo &= ~grp;
+      }
+    } else if (need && p.keys[h] == key) {
+      atomicAdd(&p.tile_counts[(h / kTileEntries) * 2 + (excess ? 1 : 0)], 1);  // commit pass 1, for free
+      p.alloc_type[h] = excess ? 2 : 1;
+      if (!excess) p.vis_type[h] = 1;
+      p.coords[h] = make_short4(bx, by, bz, 1);
+    }
   }
 }
 
@@ -226,7 +224,7 @@ __global__ __launch_bounds__(256) void k_commit_apply(const unsigned char *__res
                                                       const int *__restrict__ tile_counts, HashEntry *hash,
                                                       int num_buckets, const int *__restrict__ alloc_list,
                                                       const int *__restrict__ excess_list, unsigned char *vis_type,
-                                                      SceneCounters *cnt, unsigned *bucket_bits, int n_tiles) {
+                                                      SceneCounters *cnt, int n_tiles) {
   __shared__ int red[2][8];
   const int t0 = blockIdx.x * kTileEntries + threadIdx.x * 4;
   unsigned char a[4] = {0, 0, 0, 0};
@@ -264,7 +262,6 @@ __global__ __launch_bounds__(256) void k_commit_apply(const unsigned char *__res
       if (a[k] == 1) {
         if (vr < avail_vba) {
           store_entry(hash, t, b.x, b.y, b.z, 0, alloc_list[base_free - vr]);
-          atomicOr(&bucket_bits[t >> 5], 1u << (t & 31));  // type 1 = an ordered entry (t < num_buckets) got a block
           succ_vba++;
         } else {
           vis_type[t] = 0;
@@ -466,7 +463,7 @@ int launch_allocate(dslam_engine *e, dslam_scene *s, const dslam_view *v, dslam_
   if (!only_update_visible_list) {
     hipLaunchKernelGGL(k_commit_apply, dim3(n_tiles), dim3(256), 0, e->stream, e->alloc_type, e->block_coords, N,
                        e->tile_counts, s->hash, s->p.num_buckets, s->alloc_list, s->excess_list, r->visible_type,
-                       s->counters, s->bucket_bits, n_tiles);
+                       s->counters, n_tiles);
   }
   const int fin = only_update_visible_list ? 0 : 1;
   VisParams vp;

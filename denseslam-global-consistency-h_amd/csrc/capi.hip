@@ -210,7 +210,6 @@ int dslam_scene_create(dslam_engine *e, const dslam_scene_params *p, void *ext_v
   DSLAM_HIP(hipMalloc(&s->last_seen, (size_t)s->p.num_local_blocks * sizeof(int)));
   DSLAM_HIP(hipMalloc(&s->masks, (size_t)s->p.num_local_blocks * 2 * s->history_words * sizeof(unsigned long long)));
   DSLAM_HIP(hipMalloc(&s->counters, sizeof(SceneCounters)));
-  DSLAM_HIP(hipMalloc(&s->bucket_bits, (size_t)((s->p.num_buckets + 31) / 32) * sizeof(unsigned)));
   if (s->p.use_swapping) {
     DSLAM_HIP(hipMalloc(&s->swap_state, s->n_entries));
     s->has_stored = (unsigned char *)calloc(s->n_entries, 1);
@@ -235,7 +234,7 @@ int dslam_scene_destroy(dslam_scene *s) {
   (void)hipStreamSynchronize(s->engine->stream);
   free_dev(s->hash);
   if (!s->voxels_external) free_dev(s->voxels);
-  free_dev(s->alloc_list); free_dev(s->excess_list); free_dev(s->last_seen); free_dev(s->masks); free_dev(s->counters); free_dev(s->bucket_bits);
+  free_dev(s->alloc_list); free_dev(s->excess_list); free_dev(s->last_seen); free_dev(s->masks); free_dev(s->counters);
   free_dev(s->swap_state); free_dev(s->transfer_dev);
   if (s->transfer_host) (void)hipHostFree(s->transfer_host);
   if (s->transfer_ids_host) (void)hipHostFree(s->transfer_ids_host);
@@ -837,7 +836,6 @@ int dslam_upload_scene_state(dslam_engine *e, dslam_scene *s, const dslam_hash_e
   int rc = 0;
   if (hash) {
     rc = h2d(e, s->hash, hash, (size_t)s->n_entries * sizeof(HashEntry));
-    if (!rc) rc = launch_rebuild_bucket_bits(e, s);
     if (!rc) rc = finish_call(e);
   }
   SceneCounters *sc = reinterpret_cast<SceneCounters *>(e->pinned);

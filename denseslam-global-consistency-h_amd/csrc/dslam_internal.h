@@ -80,8 +80,6 @@ struct dslam_scene {
   int *alloc_list = nullptr;
   int *excess_list = nullptr;
   int *last_seen = nullptr;           // per voxel-block slot
-  unsigned *bucket_bits = nullptr;    // 1 bit per bucket: head entry occupied (ptr >= -1); kept in step by
-                                      // allocation / release so ray marching can skip empty buckets unprobed
   dslam::SceneCounters *counters = nullptr;  // device
   // visible-list history: per voxel-block slot two bit rings (0 fusion, 1 defusion); list k of ring q
   // owns bit k % (64*history_words) of masks[(slot*2+q)*history_words ...]
@@ -146,7 +144,6 @@ struct dslam_frame_store {
 namespace dslam {
 // kernels' host launchers (one translation unit per subsystem)
 int launch_scene_reset(dslam_engine *e, dslam_scene *s);
-int launch_rebuild_bucket_bits(dslam_engine *e, dslam_scene *s);
 int launch_view_convert(dslam_engine *e, dslam_view *v, const void *rgba_dev, const void *depth_dev, float a, float b);
 int launch_bgr_to_rgba(dslam_engine *e, const void *bgr_dev, uchar4 *rgba_dev, int npix);
 int launch_bilateral(dslam_engine *e, dslam_view *v);

@@ -165,8 +165,7 @@ __global__ __launch_bounds__(256) void k_find_leaders(const int *__restrict__ re
 __global__ __launch_bounds__(256) void k_unlink(const int *__restrict__ leader_bucket, const SceneCounters *cnt,
                                                 HashEntry *hash, int num_buckets,
                                                 const unsigned char *__restrict__ remove_flags,
-                                                unsigned char *freed_flags, unsigned char *vis_type,
-                                                unsigned *bucket_bits) {
+                                                unsigned char *freed_flags, unsigned char *vis_type) {
   const int n = cnt->remove_count;
   for (int r = blockIdx.x * blockDim.x + threadIdx.x; r < n; r += gridDim.x * blockDim.x) {
     const int head = leader_bucket[r];
@@ -197,7 +196,6 @@ __global__ __launch_bounds__(256) void k_unlink(const int *__restrict__ leader_b
       c = next;
     }
     if (prev >= 0) hash[prev].offset = 0;
-    else atomicAnd(&bucket_bits[head >> 5], ~(1u << (head & 31)));  // no survivor: the bucket is empty now
   }
 }
 
@@ -276,7 +274,7 @@ static int release_flagged(dslam_engine *e, dslam_scene *s, dslam_render_state *
                      s->p.num_buckets, (unsigned)(s->p.num_buckets - 1), rem_flags, m.leaders);
   DSLAM_HIP(hipMemsetAsync(m.freed_flags, 0, (size_t)x_tiles * kTileEntries, e->stream));
   hipLaunchKernelGGL(k_unlink, dim3(256), dim3(256), 0, e->stream, m.leaders, s->counters, s->hash, s->p.num_buckets,
-                     rem_flags, m.freed_flags, r ? r->visible_type : (unsigned char *)nullptr, s->bucket_bits);
+                     rem_flags, m.freed_flags, r ? r->visible_type : (unsigned char *)nullptr);
   hipLaunchKernelGGL(k_flag_count, dim3(x_tiles), dim3(256), 0, e->stream, m.freed_flags, s->p.num_excess,
                      e->tile_counts);
   hipLaunchKernelGGL(k_scan_count, dim3(1), dim3(1024), 0, e->stream, e->tile_counts, e->tile_offsets, x_tiles,

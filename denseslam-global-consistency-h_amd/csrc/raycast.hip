@@ -383,7 +383,6 @@ int launch_find_visible_and_depths(dslam_engine *e, const dslam_scene *s, dslam_
 // ---------------------------------------------------------------------------------------------------------
 struct VolumeRef {
   const HashEntry *hash;
-  const unsigned *bucket_bits;  // 1 bit per bucket: head occupied.  128 KB, L2-resident: empty buckets cost no table probe
   const uint2 *voxels;
   unsigned mask;
   int num_buckets;
@@ -403,10 +402,6 @@ __device__ __forceinline__ uint2 read_voxel(const VolumeRef &vol, int px, int py
     return vol.voxels[(size_t)c.block_ptr + lin];
   }
   int h = hash_index(bx, by, bz, vol.mask);
-  if (vol.bucket_bits && !((vol.bucket_bits[h >> 5] >> (h & 31)) & 1u)) {  // empty bucket head => not allocated
-    found = false;
-    return make_uint2(kEmptyVoxelLo, kEmptyVoxelHi);
-  }
   while (true) {
     const HashEntry e = load_entry(vol.hash, h);
     if (e.pos[0] == bx && e.pos[1] == by && e.pos[2] == bz && e.ptr >= 0) {
@@ -438,7 +433,6 @@ __device__ __forceinline__ float read_sdf_uninterp(const VolumeRef &vol, const V
 __device__ __forceinline__ int lookup_block(const VolumeRef &vol, int bx, int by, int bz, IndexCache &c) {
   if (bx == c.bx && by == c.by && bz == c.bz) return c.block_ptr;
   int h = hash_index(bx, by, bz, vol.mask);
-  if (vol.bucket_bits && !((vol.bucket_bits[h >> 5] >> (h & 31)) & 1u)) return -1;
   while (true) {
     const HashEntry e = load_entry(vol.hash, h);
     if (e.pos[0] == bx && e.pos[1] == by && e.pos[2] == bz && e.ptr >= 0) {
@@ -684,7 +678,7 @@ struct RenderParams {
   float *out_float;
   int type;  // dslam_image_type, or -1: raycast only
   unsigned long long *dbg_waves;  // diagnostics only (env DSLAM_DBG_WAVETIME=<file>): per wave {cycles, max iterations, straddling iterations, their cycles, setup cycles, refinement cycles}
-  int dbg_flags;  // diagnostics only (env DSLAM_DBG_FLAGS: 4 = probe the bucket bitmap first, 8 = 16x16 workgroups)
+  int dbg_flags;  // diagnostics only (env DSLAM_DBG_FLAGS: 8 = 16x16 workgroups)
 };
 
 // DIAG instantiation only: wave-level split of the march (single-wave workgroups): iterations in which some lane took
@@ -895,7 +889,7 @@ __global__ __launch_bounds__(WAVES * 64, 5) void k_render(RenderParams p) {
 
 static int fill_render_params(RenderParams &rp, const dslam_scene *s, dslam_render_state *r, const float *M,
                               const float *intr, int type) {
-  rp.vol.hash = s->hash; rp.vol.bucket_bits = s->bucket_bits; rp.vol.voxels = s->voxels; rp.vol.mask = (unsigned)(s->p.num_buckets - 1);
+  rp.vol.hash = s->hash; rp.vol.voxels = s->voxels; rp.vol.mask = (unsigned)(s->p.num_buckets - 1);
   rp.vol.num_buckets = s->p.num_buckets;
   memcpy(rp.M.m, M, 64);
   if (!invert_matrix(M, rp.invM.m)) { set_last_error("pose matrix is singular"); return DSLAM_ERR_INVALID; }
@@ -907,9 +901,6 @@ static int fill_render_params(RenderParams &rp, const dslam_scene *s, dslam_rend
   rp.type = type;
   static const int dbg_flags = getenv("DSLAM_DBG_FLAGS") ? atoi(getenv("DSLAM_DBG_FLAGS")) : 0;
   rp.dbg_flags = dbg_flags; rp.dbg_waves = nullptr;
-  // measured on MI355X: the bucket-occupancy bitmap does not pay in the ray march (125 vs 132 us: an extra load on
-  // every hit outweighs the cheaper miss), so it is off unless DSLAM_DBG_FLAGS bit 2 asks for it
-  if (!(dbg_flags & 4)) rp.vol.bucket_bits = nullptr;
   return DSLAM_OK;
 }
 

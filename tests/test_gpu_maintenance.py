@@ -41,7 +41,7 @@ def _run_pair(gpu, oracle, pkg, wl, params, n_frames, decay=None, slide=None, sw
             assert (st0["last_swapped_in"], st0["last_swapped_out"]) == (st1["last_swapped_in"], st1["last_swapped_out"])
         last = snaps
     util.check_invariants(last["gpu"], objs["gpu"][1].params)
-    # raycast the maintained maps too: exercises the engine's bucket-occupancy bitmap after releases
+    # raycast the maintained maps too: released / relinked chains must still resolve
     rgba, mm, M = wl.frame(n_frames - 1)
     imgs = {}
     for name, (api, s, rs, v) in objs.items():
