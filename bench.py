@@ -48,7 +48,7 @@ def generate_frames(name, W, H, n, workers):
     return (np.stack([r[0] for r in res]), np.stack([r[1] for r in res]), np.stack([r[2] for r in res]))
 
 
-def cpu_baseline(pkg, wl, params, frames, budget_s=15.0, max_frames=64):
+def cpu_baseline(pkg, wl, params, frames, budget_s=20.0, max_frames=400):
     """CPU oracle (kind "port": the reference's CPU engine cannot be built here) on the first frames of
     the same workload, same call sequence, all host threads (OpenMP over visible blocks / pixels)."""
     orc_pkg = ge.load_oracle()
@@ -59,13 +59,14 @@ def cpu_baseline(pkg, wl, params, frames, budget_s=15.0, max_frames=64):
     rgba, depth, Ms = frames
     s = orc.create_scene(params)
     rs = orc.create_render_state(s, wl.W, wl.H)
+    rs_free = orc.create_render_state(s, wl.W, wl.H)  # renderState_freeview, as in the GPU step
     v = orc.create_view(wl.W, wl.H)
     n = 0
     t0 = time.perf_counter()
     while n < min(max_frames, len(Ms)):
         orc.view_update(v, rgba[n], depth[n], timestamp=float(n))
         orc.process_frame(s, v, rs, Ms[n], wl.intr)
-        orc.get_image(s, rs, Ms[n], wl.intr, pkg.IMAGE_DEPTH, download=False)
+        orc.get_image(s, rs_free, Ms[n], wl.intr, pkg.IMAGE_DEPTH, download=False)
         n += 1
         if time.perf_counter() - t0 > budget_s:
             break
@@ -133,6 +134,9 @@ def main():
     vox_t = torch.empty(nlb * 512 * 8, dtype=torch.uint8, device=dev)
     scene = eng.create_scene(params, ext_voxel_blocks_dev=vox_t.data_ptr())
     rs = eng.create_render_state(scene, wl.W, wl.H)
+    # ITMMainEngine::GetImage(FREECAMERA_*) raycasts through its own renderState_freeview, not the local map's
+    # render state: the fusion visible list must survive from keyframe to keyframe
+    rs_free = eng.create_render_state(scene, wl.W, wl.H)
     view = eng.create_view(wl.W, wl.H)
     eng.set_async(not args.sync)
     rgba_stride = wl.W * wl.H * 4
@@ -145,7 +149,7 @@ def main():
             eng.view_update_device(view, rgba_d.data_ptr() + i * rgba_stride, depth_d.data_ptr() + i * depth_stride,
                                    timestamp=float(i))
         eng.process_frame(scene, view, rs, Ms[i], wl.intr)
-        eng.get_image(scene, rs, Ms[i], wl.intr, pkg.IMAGE_DEPTH, download=args.host_io)
+        eng.get_image(scene, rs_free, Ms[i], wl.intr, pkg.IMAGE_DEPTH, download=args.host_io)
 
     for i in range(Wm):
         step(i)
@@ -174,7 +178,7 @@ def main():
     int_ms, launches, blocks = eng.kernel_timer_read()
     eng.kernel_timer_enable(False)
     st = eng.stats(scene, rs)
-    hits = int((eng.get_image(scene, rs, Ms[Wm + K - 1], wl.intr, pkg.IMAGE_DEPTH) > 0).sum())
+    hits = int((eng.get_image(scene, rs_free, Ms[Wm + K - 1], wl.intr, pkg.IMAGE_DEPTH) > 0).sum())
 
     # ---- sharded global re-integration (BASELINE configs[4]): de-integrate + re-integrate the last
     # `--reint` keyframes at corrected poses, blocks sharded over the ranks, one RCCL all-gather at the end.
