@@ -11,7 +11,8 @@ import os
 import subprocess
 
 from ._capi import (BLOCK_SIZE3, HASH_ENTRY_DTYPE, IMAGE_COLOUR_FROM_NORMAL, IMAGE_COLOUR_FROM_VOLUME, IMAGE_DEPTH,
-                    IMAGE_SHADED, VOXEL_DTYPE, CApi, DslamError, SceneParams, Stats, WeightParams, mat_to_abi)
+                    IMAGE_SHADED, VOXEL_DTYPE, CApi, DslamError, SceneParams, Stats, TrackerParams, TrackerResult,
+                    WeightParams, mat_to_abi)
 
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 CSRC_DIR = os.path.join(PKG_DIR, "csrc")

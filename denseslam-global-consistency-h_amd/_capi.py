@@ -38,6 +38,21 @@ class SceneParams(C.Structure):
                          num_local_blocks, num_buckets, num_excess, use_swapping, history_words)
 
 
+class TrackerParams(C.Structure):
+    """dslam_tracker_params (ITMLibSettings' depth-tracker fields; upstream defaults)."""
+    _fields_ = [("no_hierarchy_levels", C.c_int32), ("no_icp_run_till_level", C.c_int32), ("dist_thresh", C.c_float),
+                ("termination_threshold", C.c_float), ("regime", C.c_int32 * 8)]
+
+    def __init__(self, levels=5, run_till_level=0, dist_thresh=0.1 * 0.1, termination_threshold=1e-3, regime=None):
+        regime = list(regime) if regime is not None else [3, 3, 1, 1, 1]
+        regime = (regime + [4] * 8)[:8]
+        super().__init__(levels, run_till_level, dist_thresh, termination_threshold, (C.c_int32 * 8)(*regime))
+
+
+class TrackerResult(C.Structure):
+    _fields_ = [("iterations", C.c_int32), ("valid_points_last", C.c_int32), ("f_last", C.c_float), ("pad", C.c_int32)]
+
+
 class WeightParams(C.Structure):
     _fields_ = [("depth_weighting", C.c_int32), ("max_new_w", C.c_int32), ("max_distance", C.c_float)]
 
@@ -368,6 +383,16 @@ class CApi:
     def create_expected_depths(self, scene, rs, M, intr):
         m, k = self._mi(M, intr)
         self._call("create_expected_depths", self._engine, scene.ptr, rs.ptr, _fptr(m), _fptr(k))
+
+    def track_camera(self, view, rs, scene_pose_M, pose_M, intr, params=None):
+        """ITMDepthTracker::TrackCamera; returns (tracked world->camera pose as a 4x4 row-major array, result)."""
+        params = params or TrackerParams()
+        sp, k = self._mi(scene_pose_M, intr)
+        pose = mat_to_abi(pose_M).copy()
+        res = TrackerResult()
+        self._call("track_camera", self._engine, view.ptr, rs.ptr, _fptr(sp), _fptr(pose), _fptr(k), C.byref(params),
+                   C.byref(res))
+        return pose.reshape(4, 4).T.copy(), res
 
     def _image_call(self, name, scene, rs, M, intr, image_type, download=True):
         m, k = self._mi(M, intr)

@@ -152,6 +152,8 @@ int dslam_engine_destroy(dslam_engine *e) {
   if (e->pinned) (void)hipHostFree(e->pinned);
   if (e->timer_counts_dev) (void)hipFree(e->timer_counts_dev);
   free_dev(e->misc_counter);
+  free_dev(e->icp_partials);
+  if (e->icp_partials_host) (void)hipHostFree(e->icp_partials_host);
   for (auto ev : e->ev_pool) (void)hipEventDestroy(ev);
   (void)hipStreamDestroy(e->stream);
   (void)hipStreamDestroy(e->copy_stream);
@@ -330,7 +332,7 @@ int dslam_view_create(dslam_engine *e, int w_rgb, int h_rgb, int w_d, int h_d, d
 int dslam_view_destroy(dslam_view *v) {
   if (!v) return DSLAM_OK;
   (void)hipStreamSynchronize(v->engine->stream);
-  free_dev(v->rgba); free_dev(v->depth); free_dev(v->raw_depth); free_dev(v->filter_tmp);
+  free_dev(v->rgba); free_dev(v->depth); free_dev(v->raw_depth); free_dev(v->filter_tmp); free_dev(v->pyramid);
   delete v;
   return DSLAM_OK;
 }
@@ -598,6 +600,15 @@ int dslam_deprocess_frame(dslam_engine *e, dslam_scene *s, const dslam_view *v, 
   if ((rc = launch_allocate(e, s, v, r, M_d, intr_d, 1))) return rc;
   if ((rc = launch_integrate(e, s, v, r, M_d, intr_d, M_rgb, intr_rgb, true))) return rc;
   return finish_call(e);
+}
+
+// ---- depth tracker -------------------------------------------------------------------------------------------
+int dslam_track_camera(dslam_engine *e, const dslam_view *v, dslam_render_state *r, const float scene_pose_M[16],
+                       float pose_M[16], const float intr[4], const dslam_tracker_params *params,
+                       dslam_tracker_result *result) {
+  DSLAM_REQUIRE(e && v && r && scene_pose_M && pose_M && intr && params, "null argument");
+  DSLAM_REQUIRE(v->engine == e && r->engine == e, "objects belong to a different engine");
+  return launch_track_camera(e, v, r, scene_pose_M, pose_M, intr, params, result);
 }
 
 // ---- decay / sliding window ----------------------------------------------------------------------------------

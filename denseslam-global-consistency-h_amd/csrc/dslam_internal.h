@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -67,6 +68,8 @@ struct dslam_engine {
   int *timer_counts_dev = nullptr;    // visible-block count of each timed launch (written by the kernel)
   int sm_count = 256;
   int render_tile_budget = DSLAM_MAX_RENDERING_BLOCKS;  // MAX_RENDERING_BLOCKS; lowered only by the budget test
+  double *icp_partials = nullptr;       // depth tracker: per-workgroup partial sums (device) and their pinned mirror
+  double *icp_partials_host = nullptr;
   int *misc_counter = nullptr;        // device: small result counters of one-off kernels (depthPostProcessing)
 };
 
@@ -122,6 +125,7 @@ struct dslam_view {
   uchar4 *rgba = nullptr;       // own buffers (host uploads land here)
   float *depth = nullptr;
   short *raw_depth = nullptr;
+  float *pyramid = nullptr;     // depth tracker: levels 1.. of the depth pyramid, allocated on first use
   float *filter_tmp = nullptr;  // ITMViewBuilder::floatImage, allocated when the bilateral filter is first used
   // what the kernels read: own buffers, or the caller's resident frame (dslam_view_update_device: no copy)
   const uchar4 *rgba_src = nullptr;
@@ -165,6 +169,8 @@ int launch_expected_depths(dslam_engine *e, const dslam_scene *s, dslam_render_s
                            const float *intr);
 int launch_find_visible_and_depths(dslam_engine *e, const dslam_scene *s, dslam_render_state *r, const float *M,
                                    const float *intr);
+int launch_track_camera(dslam_engine *e, const dslam_view *v, dslam_render_state *r, const float *scenePose, float *pose_M,
+                        const float *intr, const dslam_tracker_params *tp, dslam_tracker_result *res);
 int launch_render(dslam_engine *e, const dslam_scene *s, dslam_render_state *r, const float *M, const float *intr,
                   int type);
 int launch_icp_maps(dslam_engine *e, const dslam_scene *s, dslam_render_state *r, const float *M, const float *intr);

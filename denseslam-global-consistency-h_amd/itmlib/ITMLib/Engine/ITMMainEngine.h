@@ -138,21 +138,39 @@ class ITMViewBuilder {
   }
 };
 
-/// ITMTrackingController: Prepare = raycast into ICP maps (InfiniTamDriver.h:212-215); Track (ICP) is out of scope
-/// for this path -- the reference runs with ORB-SLAM2 poses (use_orbslam_vo, SystemEntry.cpp:189).
+/// ITMTrackingController: Prepare = raycast into ICP maps (InfiniTamDriver.h:212-215); Track = ITMDepthTracker's
+/// point-to-plane ICP of the view against those maps (InfiniTamDriver.h:151-163), both on the device.
 class ITMTrackingController {
   dslam_engine *eng_;
+  dslam_tracker_params params_;
  public:
-  explicit ITMTrackingController(dslam_engine *e) : eng_(e) {}
+  explicit ITMTrackingController(dslam_engine *e, const ITMLibSettings *settings = nullptr) : eng_(e) {
+    ITMLibSettings defaults;
+    if (settings == nullptr) settings = &defaults;
+    params_.no_hierarchy_levels = settings->noHierarchyLevels;
+    params_.no_icp_run_till_level = settings->noICPRunTillLevel;
+    params_.dist_thresh = settings->depthTrackerICPThreshold;
+    params_.termination_threshold = settings->depthTrackerTerminationThreshold;
+    for (int i = 0; i < DSLAM_TRACKER_MAX_LEVELS; i++) params_.regime[i] = (int)settings->trackingRegime[i];
+  }
   void Prepare(ITMTrackingState *ts, const ITMScene<ITMVoxel, ITMVoxelIndex> *scene, const ITMView *view, ITMRenderState *rs) {
     const Matrix4f M = ts->pose_d->GetM();
     const Vector4f k = view->calib->intrinsics_d.projectionParamsSimple.all;
     dslam_check(dslam_create_icp_maps(eng_, scene->handle, rs->handle, M.m, k.v, &ts->pointsMap->GetData(MEMORYDEVICE_CPU)->x,
                                       &ts->normalsMap->GetData(MEMORYDEVICE_CPU)->x), "dslam_create_icp_maps");
+    ts->pose_pointCloud->SetM(M);
+    ts->preparedWith = rs;
     ts->age_pointCloud = 0;
   }
-  void Track(ITMTrackingState *, const ITMView *) {
-    throw std::runtime_error("ITMTrackingController::Track (ICP) is outside the fusion/raycast path; run with orbslam_vo: 1");
+  void Track(ITMTrackingState *ts, const ITMView *view) {
+    if (ts->preparedWith == nullptr) throw std::runtime_error("ITMTrackingController::Track: Prepare has not been called");
+    const Vector4f k = view->calib->intrinsics_d.projectionParamsSimple.all;
+    Matrix4f M = ts->pose_d->GetM();
+    dslam_tracker_result res;
+    dslam_check(dslam_track_camera(eng_, view->handle, ts->preparedWith->handle, ts->pose_pointCloud->GetM().m, M.m, k.v,
+                                   &params_, &res), "dslam_track_camera");
+    ts->pose_d->SetM(M);
+    ts->age_pointCloud++;
   }
 };
 
@@ -227,7 +245,7 @@ class ITMMainEngine {
     dslam_check(dslam_engine_create(settings->hipDeviceIndex, &engine_), "dslam_engine_create");
     denseMapper = new ITMDenseMapper(engine_, calib);
     viewBuilder = new ITMViewBuilder(engine_, calib);
-    trackingController = new ITMTrackingController(engine_);
+    trackingController = new ITMTrackingController(engine_, settings);
     visualisationEngine = new ITMVisualisationEngine<ITMVoxel, ITMVoxelIndex>(engine_);
     mapManager = new ITMVoxelMapGraphManager(settings, engine_, visualisationEngine, imgSize_d);
     mActiveDataManger = new ITMActiveMapManager(mapManager);

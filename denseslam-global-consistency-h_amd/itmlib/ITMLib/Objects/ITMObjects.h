@@ -98,13 +98,25 @@ class ITMLibSettings {
   DeviceType deviceType;
   bool useSwapping, useApproximateRaycast, useBilateralFilter, modelSensorNoise, skipPoints;
   ITMSceneParams sceneParams;
+  // depth tracker (upstream ITMLibSettings defaults)
+  typedef enum { TRACKER_ITERATION_ROTATION = 1, TRACKER_ITERATION_TRANSLATION = 2, TRACKER_ITERATION_BOTH = 3, TRACKER_ITERATION_NONE = 4 } TrackerIterationType;
+  int noHierarchyLevels, noICPRunTillLevel;
+  TrackerIterationType trackingRegime[8];
+  float depthTrackerICPThreshold, depthTrackerTerminationThreshold;
   int hipDeviceIndex;
   // pool sizes (ITMLibDefines.h constants upstream; runtime here)
   int numLocalBlocks, numBuckets, numExcess;
   ITMLibSettings()
       : deviceType(DEVICE_HIP), useSwapping(false), useApproximateRaycast(false), useBilateralFilter(false),
-        modelSensorNoise(false), skipPoints(true), sceneParams(0.02f, 100, 0.005f, 0.2f, 3.0f, false), hipDeviceIndex(0),
-        numLocalBlocks(SDF_LOCAL_BLOCK_NUM), numBuckets(SDF_BUCKET_NUM), numExcess(SDF_EXCESS_LIST_SIZE) {}
+        modelSensorNoise(false), skipPoints(true), sceneParams(0.02f, 100, 0.005f, 0.2f, 3.0f, false),
+        noHierarchyLevels(5), noICPRunTillLevel(0), depthTrackerICPThreshold(0.1f * 0.1f),
+        depthTrackerTerminationThreshold(1e-3f), hipDeviceIndex(0),
+        numLocalBlocks(SDF_LOCAL_BLOCK_NUM), numBuckets(SDF_BUCKET_NUM), numExcess(SDF_EXCESS_LIST_SIZE) {
+    trackingRegime[0] = TRACKER_ITERATION_BOTH; trackingRegime[1] = TRACKER_ITERATION_BOTH;
+    trackingRegime[2] = TRACKER_ITERATION_ROTATION; trackingRegime[3] = TRACKER_ITERATION_ROTATION;
+    trackingRegime[4] = TRACKER_ITERATION_ROTATION;
+    for (int i = 5; i < 8; i++) trackingRegime[i] = TRACKER_ITERATION_NONE;
+  }
 };
 
 class ITMView {
@@ -122,17 +134,21 @@ class ITMView {
   ~ITMView() { dslam_view_destroy(handle); delete rgb; delete depth; }
 };
 
+class ITMRenderState;
 class ITMTrackingState {
  public:
   ITMPose *pose_d;
-  ITMFloat4Image *pointsMap, *normalsMap;  ///< ICP maps filled by trackingController->Prepare
+  ITMPose *pose_pointCloud;                ///< the pose the ICP maps were rendered from (set by Prepare)
+  ITMFloat4Image *pointsMap, *normalsMap;  ///< ICP maps filled by trackingController->Prepare (host copies)
+  ITMRenderState *preparedWith;            ///< render state whose device-resident ICP maps Track reads
   int age_pointCloud;
-  explicit ITMTrackingState(Vector2i sz) : age_pointCloud(-1) {
+  explicit ITMTrackingState(Vector2i sz) : preparedWith(nullptr), age_pointCloud(-1) {
     pose_d = new ITMPose();
+    pose_pointCloud = new ITMPose();
     pointsMap = new ITMFloat4Image(sz, true, false);
     normalsMap = new ITMFloat4Image(sz, true, false);
   }
-  ~ITMTrackingState() { delete pose_d; delete pointsMap; delete normalsMap; }
+  ~ITMTrackingState() { delete pose_d; delete pose_pointCloud; delete pointsMap; delete normalsMap; }
 };
 
 class ITMRenderState {

@@ -10,7 +10,8 @@
 // frames.bin: int32 W, H, N, then per frame: uint8 rgba[W*H*4], int16 depth_mm[W*H], float M_d[16] (column-major),
 //             then float intr[4], then scene params: float voxel, mu, fmin, fmax, int32 maxW, nLocal, nBuckets, nExcess
 // out.bin:    int32 lastFreeBlockId, noVisibleEntries, usedBytesLo, decayedBlocks; uint64 fnv(hash table), fnv(voxels);
-//             float depth[W*H]; uint8 colour[W*H*4];
+//             float depth[W*H]; uint8 colour[W*H*4]; float trackedM[16] (TrackLocalMap of the last frame, started
+//             from the pose of the frame before it);
 //             with keyframes.bin, per frame: int32 nCorrected, double ts[nCorrected] (in re-fusion order),
 //             int32 nCulled, int32 databaseSize
 #include <cstdint>
@@ -83,6 +84,8 @@ class DriverHarness : public ITMMainEngine {
     const ITMRenderState_VH *rs = (ITMRenderState_VH *)(m->renderState);
     if (rs->noVisibleEntries > 0) this->trackingController->Prepare(m->trackingState, m->scene, this->view, m->renderState);
   }
+  // InfiniTamDriver::TrackLocalMap (InfiniTamDriver.h:151-163); last_egomotion_ feeds only the GUI
+  void TrackLocalMap(ITMLocalMap *m) { this->trackingController->Track(m->trackingState, this->view); }
   // InfiniTamDriver::GetLocalMapUsedMemoryBytes (InfiniTamDriver.h:344-347)
   size_t GetLocalMapUsedMemoryBytes(ITMLocalMap *m) {
     int num_used_blocks = m->scene->index.getNumAllocatedVoxelBlocks() - m->scene->localVBA.lastFreeBlockId;
@@ -238,6 +241,15 @@ int main(int argc, char **argv) {
     drv.GetFloatImage(&out_float, free_pose, currentLocalMap);                // DenseSlam.h:146-153
     drv.GetImage(&out_rgba, ITMMainEngine::InfiniTAM_IMAGE_FREECAMERA_COLOUR_FROM_VOLUME, free_pose, currentLocalMap);
     drv.PrepareNextStepLocalMap(currentLocalMap);
+    // DenseSlam::ProcessFrame without ORB-SLAM2 odometry (DenseSlam.cpp:200-206): Prepare, UpdateView, TrackLocalMap.
+    // The view still holds the last frame; start from the previous frame's pose and let the tracker pull it over.
+    Matrix4f trackedM = poses[N - 1];
+    if (N >= 2) {
+      if (oc.enabled) drv.UpdateView(rgba[N - 1].data(), depth[N - 1].data(), (double)(N - 1));
+      currentLocalMap->trackingState->pose_d->SetM(poses[N - 2]);
+      drv.TrackLocalMap(currentLocalMap);
+      trackedM = currentLocalMap->trackingState->pose_d->GetM();
+    }
 
     dslam_engine *e = drv.GetDslamEngine();
     std::vector<dslam_hash_entry> hash((size_t)ip[2] + ip[3]);
@@ -256,6 +268,7 @@ int main(int argc, char **argv) {
     fwrite(sums, 8, 2, o);
     fwrite(out_float.GetData(MEMORYDEVICE_CPU), 4, (size_t)W * H, o);
     fwrite(out_rgba.GetData(MEMORYDEVICE_CPU), 4, (size_t)W * H, o);
+    fwrite(trackedM.m, 4, 16, o);
     for (int i = 0; i < N && oc.enabled; i++) {
       const int32_t n = (int32_t)oc_order[i].size();
       fwrite(&n, 4, 1, o);

@@ -298,6 +298,36 @@ int dslam_get_image(dslam_engine *e, const dslam_scene *s, dslam_render_state *r
 int dslam_create_icp_maps(dslam_engine *e, const dslam_scene *s, dslam_render_state *r, const float M[16],
                           const float intrinsics[4], float *out_points_host, float *out_normals_host);
 
+/* ---- depth tracker (ICP) ---------------------------------------------------------------------- */
+/* trackingController->Track(trackingState, view) (InfiniTamDriver.h:151-163, reached through
+ * DenseSlam.cpp:200-206 when the reference runs without ORB-SLAM2 odometry): upstream InfiniTAM v2's
+ * ITMDepthTracker::TrackCamera -- point-to-plane ICP of the view's depth image against the points / normals maps
+ * that dslam_create_icp_maps left in the render state, coarse to fine over a depth-image pyramid
+ * (FilterSubsampleWithHoles), Levenberg-Marquardt damping, 3x3 / 6x6 Cholesky steps.
+ * iteration types as upstream's TrackerIterationType. */
+enum { DSLAM_TRACKER_ITERATION_ROTATION = 1, DSLAM_TRACKER_ITERATION_TRANSLATION = 2,
+       DSLAM_TRACKER_ITERATION_BOTH = 3, DSLAM_TRACKER_ITERATION_NONE = 4 };
+#define DSLAM_TRACKER_MAX_LEVELS 8
+typedef struct {
+  int32_t no_hierarchy_levels;     /* ITMLibSettings::noHierarchyLevels (upstream default 5) */
+  int32_t no_icp_run_till_level;   /* ITMLibSettings::noICPRunTillLevel (0) */
+  float dist_thresh;               /* depthTrackerICPThreshold (0.1 * 0.1) */
+  float termination_threshold;     /* depthTrackerTerminationThreshold (1e-3) */
+  int32_t regime[DSLAM_TRACKER_MAX_LEVELS]; /* trackingRegime per level, level 0 = full resolution
+                                     * (upstream default: BOTH, BOTH, ROTATION, ROTATION, ROTATION) */
+} dslam_tracker_params;
+typedef struct {
+  int32_t iterations;              /* ComputeGandH evaluations */
+  int32_t valid_points_last;       /* noValidPoints of the last evaluation */
+  float f_last;                    /* its error value */
+  int32_t pad;
+} dslam_tracker_result;
+/* scene_pose_M = trackingState->pose_pointCloud->GetM() (the pose the ICP maps were rendered from); pose_M is
+ * trackingState->pose_d->GetM() on entry and the tracked pose on return.  The view must have been updated. */
+int dslam_track_camera(dslam_engine *e, const dslam_view *v, dslam_render_state *r, const float scene_pose_M[16],
+                       float pose_M[16], const float intrinsics_d[4], const dslam_tracker_params *params,
+                       dslam_tracker_result *result);
+
 /* ---- state read-back (stats for the driver; bulk downloads for parity tests and checkpoints) ------ */
 int dslam_get_stats(dslam_engine *e, const dslam_scene *s, const dslam_render_state *r, dslam_stats *out);
 int dslam_download_hash_table(dslam_engine *e, const dslam_scene *s, dslam_hash_entry *out_host);

@@ -171,6 +171,7 @@ struct oracle_render_state {
   std::vector<V4f> raycast;  // raycastResult
   std::vector<uint8_t> image_rgba;
   std::vector<float> image_float;
+  std::vector<V4f> icp_points, icp_normals;  // CreateICPMaps output, kept for the depth tracker
 };
 
 struct oracle_view {
@@ -1566,6 +1567,8 @@ extern "C" int oracle_create_icp_maps(oracle_engine *e, const oracle_scene *s, o
   const int W = r->w, H = r->h;
   float invM[16];
   inv4(M, invM);
+  r->icp_points.resize((size_t)W * H);
+  r->icp_normals.resize((size_t)W * H);
   oracle_create_expected_depths(e, s, r, M, intr);
   generic_raycast(e, s, r, invM, intr);
   V3f light = {-invM[8], -invM[9], -invM[10]};
@@ -1607,16 +1610,238 @@ extern "C" int oracle_create_icp_maps(oracle_engine *e, const oracle_scene *s, o
           if (!(angle > 0.0f)) found = false;
         }
       }
-      float *po = out_points ? out_points + (size_t)loc * 4 : nullptr;
-      float *no = out_normals ? out_normals + (size_t)loc * 4 : nullptr;
+      V4f pv, nv;
       if (found) {
-        if (po) { po[0] = point.x * vs; po[1] = point.y * vs; po[2] = point.z * vs; po[3] = 1.0f; }
-        if (no) { no[0] = n.x; no[1] = n.y; no[2] = n.z; no[3] = 0.0f; }
+        pv = V4f{point.x * vs, point.y * vs, point.z * vs, 1.0f};
+        nv = V4f{n.x, n.y, n.z, 0.0f};
       } else {
-        if (po) { po[0] = po[1] = po[2] = 0.0f; po[3] = -1.0f; }
-        if (no) { no[0] = no[1] = no[2] = 0.0f; no[3] = -1.0f; }
+        pv = V4f{0.0f, 0.0f, 0.0f, -1.0f};
+        nv = V4f{0.0f, 0.0f, 0.0f, -1.0f};
       }
+      r->icp_points[loc] = pv;
+      r->icp_normals[loc] = nv;
+      if (out_points) memcpy(out_points + (size_t)loc * 4, &pv, 16);
+      if (out_normals) memcpy(out_normals + (size_t)loc * 4, &nv, 16);
     }
+  return 0;
+}
+
+// -------------------------------------------------------------------------------------------------
+// ITMDepthTracker::TrackCamera (upstream InfiniTAM v2, [UPSTREAM-RECALL]; reached from
+// trackingController->Track, InfiniTamDriver.h:151-163)
+// -------------------------------------------------------------------------------------------------
+namespace {
+// FilterSubsampleWithHoles: average of the valid (> 0) pixels of each 2x2 group
+void subsample_with_holes(const std::vector<float> &in, int w, int h, std::vector<float> &out) {
+  const int nw = w / 2, nh = h / 2;
+  out.assign((size_t)nw * nh, 0.0f);
+  for (int y = 0; y < nh; y++)
+    for (int x = 0; x < nw; x++) {
+      float acc = 0.0f, good = 0.0f;
+      for (int dy = 0; dy < 2; dy++)
+        for (int dx = 0; dx < 2; dx++) {
+          const float p = in[(2 * x + dx) + (size_t)(2 * y + dy) * w];
+          if (p > 0.0f) { acc += p; good++; }
+        }
+      if (good > 0) acc /= good;
+      out[x + (size_t)y * nw] = acc;
+    }
+}
+
+inline V4f bilinear_with_holes(const V4f *src, float px, float py, int w) {
+  const int ix = (short)floorf(px), iy = (short)floorf(py);
+  const float dx = px - (float)ix, dy = py - (float)iy;
+  const V4f a = src[ix + (size_t)iy * w], b = src[(ix + 1) + (size_t)iy * w];
+  const V4f c = src[ix + (size_t)(iy + 1) * w], d = src[(ix + 1) + (size_t)(iy + 1) * w];
+  if (a.w < 0 || b.w < 0 || c.w < 0 || d.w < 0) return V4f{0, 0, 0, -1.0f};
+  V4f r;
+  r.x = a.x * (1.0f - dx) * (1.0f - dy) + b.x * dx * (1.0f - dy) + c.x * (1.0f - dx) * dy + d.x * dx * dy;
+  r.y = a.y * (1.0f - dx) * (1.0f - dy) + b.y * dx * (1.0f - dy) + c.y * (1.0f - dx) * dy + d.y * dx * dy;
+  r.z = a.z * (1.0f - dx) * (1.0f - dy) + b.z * dx * (1.0f - dy) + c.z * (1.0f - dx) * dy + d.z * dx * dy;
+  r.w = a.w * (1.0f - dx) * (1.0f - dy) + b.w * dx * (1.0f - dy) + c.w * (1.0f - dx) * dy + d.w * dx * dy;
+  return r;
+}
+
+// computePerPointGH_Depth_Ab: the point-to-plane residual b and its Jacobian row A (3 or 6 entries)
+inline bool per_point_ab(float *A, float &b, int x, int y, float depth, const float *view_intr, int sw, int sh,
+                         const float *scene_intr, const float *approxInvPose, const float *scenePose,
+                         const V4f *points, const V4f *normals, float dist_thresh, int type) {
+  if (depth <= 1e-8f) return false;
+  V4f p;
+  p.x = depth * (((float)x - view_intr[2]) / view_intr[0]);
+  p.y = depth * (((float)y - view_intr[3]) / view_intr[1]);
+  p.z = depth;
+  p.w = 1.0f;
+  p = mul(approxInvPose, p);
+  p.w = 1.0f;
+  const V4f q = mul(scenePose, p);
+  if (q.z <= 0.0f) return false;
+  const float u = scene_intr[0] * q.x / q.z + scene_intr[2], v = scene_intr[1] * q.y / q.z + scene_intr[3];
+  if (!((u >= 0.0f) && (u <= (float)(sw - 2)) && (v >= 0.0f) && (v <= (float)(sh - 2)))) return false;
+  const V4f cp = bilinear_with_holes(points, u, v, sw);
+  if (cp.w < 0.0f) return false;
+  const float ddx = cp.x - p.x, ddy = cp.y - p.y, ddz = cp.z - p.z;
+  const float dist = ddx * ddx + ddy * ddy + ddz * ddz;
+  if (dist > dist_thresh) return false;
+  const V4f n = bilinear_with_holes(normals, u, v, sw);
+  b = n.x * ddx + n.y * ddy + n.z * ddz;
+  const float r0 = +p.z * n.y - p.y * n.z, r1 = -p.z * n.x + p.x * n.z, r2 = +p.y * n.x - p.x * n.y;
+  if (type == DSLAM_TRACKER_ITERATION_ROTATION) { A[0] = r0; A[1] = r1; A[2] = r2; }
+  else if (type == DSLAM_TRACKER_ITERATION_TRANSLATION) { A[0] = n.x; A[1] = n.y; A[2] = n.z; }
+  else { A[0] = r0; A[1] = r1; A[2] = r2; A[3] = n.x; A[4] = n.y; A[5] = n.z; }
+  return true;
+}
+
+// Cholesky solve of the (damped) normal equations, float like ORUtils::Cholesky
+void cholesky_solve(const float *Ain, int n, const float *bvec, float *x) {
+  float L[36];
+  for (int i = 0; i < n * n; i++) L[i] = Ain[i];
+  for (int c = 0; c < n; c++) {
+    float inv_diag = 1.0f;
+    for (int r = c; r < n; r++) {
+      float val = L[c + r * n];
+      for (int c2 = 0; c2 < c; c2++) val -= L[c + c2 * n] * L[c2 + r * n];
+      if (r == c) { L[c + r * n] = val; inv_diag = (val == 0.0f) ? 0.0f : 1.0f / val; }
+      else { L[r + c * n] = val; L[c + r * n] = val * inv_diag; }
+    }
+  }
+  float yv[6];
+  for (int i = 0; i < n; i++) {
+    float val = bvec[i];
+    for (int j = 0; j < i; j++) val -= L[j + i * n] * yv[j];
+    yv[i] = val;
+  }
+  for (int i = 0; i < n; i++) yv[i] = (L[i + i * n] == 0.0f) ? 0.0f : yv[i] / L[i + i * n];
+  for (int i = n - 1; i >= 0; i--) {
+    float val = yv[i];
+    for (int j = i + 1; j < n; j++) val -= L[i + j * n] * x[j];
+    x[i] = val;
+  }
+}
+
+// ITMPose::Coerce stand-in: Gram-Schmidt on the rotation columns, bottom row (0,0,0,1)
+void coerce_pose(float *M) {
+  double c0[3] = {M[0], M[1], M[2]}, c1[3] = {M[4], M[5], M[6]}, c2[3];
+  double n = sqrt(c0[0] * c0[0] + c0[1] * c0[1] + c0[2] * c0[2]);
+  if (n > 0) for (double &v : c0) v /= n;
+  const double d = c0[0] * c1[0] + c0[1] * c1[1] + c0[2] * c1[2];
+  for (int i = 0; i < 3; i++) c1[i] -= d * c0[i];
+  n = sqrt(c1[0] * c1[0] + c1[1] * c1[1] + c1[2] * c1[2]);
+  if (n > 0) for (double &v : c1) v /= n;
+  c2[0] = c0[1] * c1[2] - c0[2] * c1[1]; c2[1] = c0[2] * c1[0] - c0[0] * c1[2]; c2[2] = c0[0] * c1[1] - c0[1] * c1[0];
+  for (int i = 0; i < 3; i++) { M[i] = (float)c0[i]; M[4 + i] = (float)c1[i]; M[8 + i] = (float)c2[i]; }
+  M[3] = M[7] = M[11] = 0.0f; M[15] = 1.0f;
+}
+}  // namespace
+
+extern "C" int oracle_track_camera(oracle_engine *, const oracle_view *v, oracle_render_state *r, const float *scenePose,
+                        float *pose_M, const float *intr, const dslam_tracker_params *tp, dslam_tracker_result *res) {
+  const int levels = tp->no_hierarchy_levels;
+  if (levels < 1 || levels > DSLAM_TRACKER_MAX_LEVELS || tp->no_icp_run_till_level < 0) return DSLAM_ERR_INVALID;
+  if (r->icp_points.size() != (size_t)r->w * r->h || v->w_d != r->w || v->h_d != r->h) return DSLAM_ERR_INVALID;
+  // view hierarchy (PrepareForEvaluation); the scene maps stay at level 0
+  std::vector<std::vector<float>> depth(levels);
+  std::vector<int> lw(levels), lh(levels);
+  float lintr[DSLAM_TRACKER_MAX_LEVELS][4];
+  depth[0] = v->depth; lw[0] = v->w_d; lh[0] = v->h_d;
+  for (int k = 0; k < 4; k++) lintr[0][k] = intr[k];
+  for (int i = 1; i < levels; i++) {
+    subsample_with_holes(depth[i - 1], lw[i - 1], lh[i - 1], depth[i]);
+    lw[i] = lw[i - 1] / 2; lh[i] = lh[i - 1] / 2;
+    for (int k = 0; k < 4; k++) lintr[i][k] = lintr[i - 1][k] * 0.5f;
+  }
+  int iters_per_level[DSLAM_TRACKER_MAX_LEVELS];
+  float dist_per_level[DSLAM_TRACKER_MAX_LEVELS];
+  iters_per_level[0] = 2;
+  for (int i = 1; i < levels; i++) iters_per_level[i] = iters_per_level[i - 1] + 2;
+  const float dstep = tp->dist_thresh / levels;
+  dist_per_level[levels - 1] = tp->dist_thresh;
+  for (int i = levels - 2; i >= 0; i--) dist_per_level[i] = dist_per_level[i + 1] - dstep;
+
+  float M[16], approxInvPose[16];
+  memcpy(M, pose_M, 64);
+  float hessian_good[36] = {0}, nabla_good[6] = {0};
+  int total_iters = 0, last_valid = 0;
+  float last_f = 0.0f;
+  for (int level = levels - 1; level >= tp->no_icp_run_till_level; level--) {
+    const int type = tp->regime[level];
+    if (type == DSLAM_TRACKER_ITERATION_NONE) continue;
+    const int npara = (type == DSLAM_TRACKER_ITERATION_BOTH) ? 6 : 3;
+    inv4(M, approxInvPose);
+    float good_M[16];
+    memcpy(good_M, M, 64);
+    float f_old = 1e20f, lambda = 1.0f;
+    for (int it = 0; it < iters_per_level[level]; it++) {
+      // ComputeGandH: sums over the level's pixels; accumulated in double here and on the device (upstream adds
+      // floats in pixel order, which no parallel machine reproduces) and rounded to float once
+      double sumH[21] = {0}, sumN[6] = {0}, sumF = 0;
+      int valid = 0;
+      for (int y = 0; y < lh[level]; y++)
+        for (int x = 0; x < lw[level]; x++) {
+          float A[6], b;
+          if (!per_point_ab(A, b, x, y, depth[level][x + (size_t)y * lw[level]], lintr[level], r->w, r->h, lintr[0],
+                            approxInvPose, scenePose, r->icp_points.data(), r->icp_normals.data(), dist_per_level[level], type))
+            continue;
+          valid++;
+          sumF += (double)(b * b);
+          for (int k = 0, c = 0; k < npara; k++) {
+            sumN[k] += (double)(b * A[k]);
+            for (int j = 0; j <= k; j++, c++) sumH[c] += (double)(A[k] * A[j]);
+          }
+        }
+      float hessian_new[36] = {0}, nabla_new[6] = {0};
+      for (int k = 0, c = 0; k < npara; k++)
+        for (int j = 0; j <= k; j++, c++) hessian_new[k + j * 6] = hessian_new[j + k * 6] = (float)sumH[c];
+      for (int k = 0; k < npara; k++) nabla_new[k] = (float)sumN[k];
+      const float f_new = (valid > 100) ? sqrtf((float)sumF) / (float)valid : 1e5f;
+      total_iters++; last_valid = valid; last_f = f_new;
+
+      if (valid <= 0 || f_new > f_old) {
+        memcpy(M, good_M, 64);
+        inv4(M, approxInvPose);
+        lambda *= 10.0f;
+      } else {
+        memcpy(good_M, M, 64);
+        f_old = f_new;
+        for (int i = 0; i < 36; i++) hessian_good[i] = hessian_new[i] / (float)valid;
+        for (int i = 0; i < 6; i++) nabla_good[i] = nabla_new[i] / (float)valid;
+        lambda /= 10.0f;
+      }
+      float A6[36];
+      for (int i = 0; i < 36; i++) A6[i] = hessian_good[i];
+      for (int i = 0; i < 6; i++) A6[i + i * 6] *= 1.0f + lambda;
+      float step[6] = {0, 0, 0, 0, 0, 0};
+      if (npara == 3) {
+        float small[9];
+        for (int rr = 0; rr < 3; rr++) for (int cc = 0; cc < 3; cc++) small[rr + cc * 3] = A6[rr + cc * 6];
+        cholesky_solve(small, 3, nabla_good, step);
+      } else {
+        cholesky_solve(A6, 6, nabla_good, step);
+      }
+      // ApplyDelta
+      float s6[6] = {0, 0, 0, 0, 0, 0};
+      if (type == DSLAM_TRACKER_ITERATION_ROTATION) { s6[0] = step[0]; s6[1] = step[1]; s6[2] = step[2]; }
+      else if (type == DSLAM_TRACKER_ITERATION_TRANSLATION) { s6[3] = step[0]; s6[4] = step[1]; s6[5] = step[2]; }
+      else for (int i = 0; i < 6; i++) s6[i] = step[i];
+      // Tinc, column-major m[col * 4 + row]
+      const float Tinc[16] = {1.0f, -s6[2], s6[1], 0.0f, s6[2], 1.0f, -s6[0], 0.0f, -s6[1], s6[0], 1.0f, 0.0f, s6[3], s6[4], s6[5], 1.0f};
+      float next[16];
+      for (int c = 0; c < 4; c++)
+        for (int rr = 0; rr < 4; rr++) {
+          float acc = 0;
+          for (int k = 0; k < 4; k++) acc += Tinc[k * 4 + rr] * approxInvPose[c * 4 + k];
+          next[c * 4 + rr] = acc;
+        }
+      inv4(next, M);       // pose_d->SetInvM(approxInvPose)
+      coerce_pose(M);      // pose_d->Coerce()
+      inv4(M, approxInvPose);
+      float len = 0.0f;
+      for (int i = 0; i < 6; i++) len += step[i] * step[i];
+      if (sqrtf(len) / 6 < tp->termination_threshold) break;  // HasConverged
+    }
+  }
+  memcpy(pose_M, M, 64);
+  if (res) { res->iterations = total_iters; res->valid_points_last = last_valid; res->f_last = last_f; res->pad = 0; }
   return 0;
 }
 

@@ -75,3 +75,10 @@ def test_driver_harness_matches_oracle(pkg, synth, oracle, tmp_path, decay, slid
     assert h_vox == fnv1a(oracle.download_voxel_blocks(s).tobytes())
     assert np.abs(g_depth - depth).max() <= 1e-4 and (g_depth > 0).sum() > 500
     assert np.abs(g_colour.astype(int) - colour.astype(int)).max() <= 1
+    # TrackLocalMap (InfiniTamDriver.h:151-163): Prepare at the last pose, then ICP of the last frame started from
+    # the pose before it; tolerance 1e-5 on the matrix entries (double-accumulated sums differ in summation order)
+    g_tracked = np.frombuffer(raw, np.float32, 16, 32 + npx * 8).reshape(4, 4).T
+    oracle.create_icp_maps(s, rs, M_last, wl.intr)
+    t_pose, t_res = oracle.track_camera(v, rs, M_last, frames[-2][2], wl.intr)
+    assert t_res.iterations > 0 and t_res.valid_points_last > 100
+    assert np.abs(g_tracked - t_pose).max() <= 1e-5

@@ -142,7 +142,7 @@ def test_cpp_scheduler_matches_oracle_replay(pkg, synth, oracle, tmp_path):
 
     raw = open(fout, "rb").read()
     npx = wl.W * wl.H
-    off = 32 + npx * 8
+    off = 32 + npx * 8 + 64  # header, depth + colour images, tracked pose
     cpp_log = []
     for i in range(n_frames):
         (n,) = struct.unpack_from("<i", raw, off); off += 4
