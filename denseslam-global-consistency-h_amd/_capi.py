@@ -412,8 +412,12 @@ class CApi:
     def get_image(self, scene, rs, M, intr, image_type, download=True):
         return self._image_call("get_image", scene, rs, M, intr, image_type, download)
 
-    def create_icp_maps(self, scene, rs, M, intr):
+    def create_icp_maps(self, scene, rs, M, intr, download=True):
+        """trackingController->Prepare.  download=False leaves the maps on the device (all the depth tracker needs)."""
         m, k = self._mi(M, intr)
+        if not download:
+            self._call("create_icp_maps", self._engine, scene.ptr, rs.ptr, _fptr(m), _fptr(k), None, None)
+            return None, None
         pts = np.empty((rs.height, rs.width, 4), dtype=np.float32)
         nrm = np.empty((rs.height, rs.width, 4), dtype=np.float32)
         self._call("create_icp_maps", self._engine, scene.ptr, rs.ptr, _fptr(m), _fptr(k), _fptr(pts), _fptr(nrm))

@@ -10,3 +10,4 @@ rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $R/gpurun_out/f
 cd $R
 python denseslam-global-consistency-h_amd/harness/stress.py 64 > gpurun_out/final_stress.json; cat gpurun_out/final_stress.json
 python bench.py --sync --steps 100 --warmup 10 --no-cpu-baseline --reint 0 > gpurun_out/final_bench_sync.json 2>/dev/null; grep -o '"value": [0-9.]*' gpurun_out/final_bench_sync.json
+python denseslam-global-consistency-h_amd/harness/side_bench.py 50 > gpurun_out/final_side_bench.json 2>gpurun_out/final_side_bench.err; cat gpurun_out/final_side_bench.json
