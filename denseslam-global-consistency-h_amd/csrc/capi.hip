@@ -332,7 +332,7 @@ int dslam_view_create(dslam_engine *e, int w_rgb, int h_rgb, int w_d, int h_d, d
 int dslam_view_destroy(dslam_view *v) {
   if (!v) return DSLAM_OK;
   (void)hipStreamSynchronize(v->engine->stream);
-  free_dev(v->rgba); free_dev(v->depth); free_dev(v->raw_depth); free_dev(v->filter_tmp); free_dev(v->pyramid);
+  free_dev(v->rgba); free_dev(v->depth); free_dev(v->raw_depth); free_dev(v->pyramid);
   delete v;
   return DSLAM_OK;
 }

@@ -126,7 +126,6 @@ struct dslam_view {
   float *depth = nullptr;
   short *raw_depth = nullptr;
   float *pyramid = nullptr;     // depth tracker: levels 1.. of the depth pyramid, allocated on first use
-  float *filter_tmp = nullptr;  // ITMViewBuilder::floatImage, allocated when the bilateral filter is first used
   // what the kernels read: own buffers, or the caller's resident frame (dslam_view_update_device: no copy)
   const uchar4 *rgba_src = nullptr;
   const short *raw_src = nullptr;

@@ -4,7 +4,7 @@
 //     (upstream InfiniTAM v2 ITMViewBuilder_Shared.h filterDepth, call site [REF InfiniTamDriver.cpp:280-288])
 //   * DenseSlam::depthPostProcessing: reprojection consistency filter against the previous keyframe's depth
 //                                                                           [REF DenseSlam.cpp:434-552]
-// All three are one thread per pixel, HBM-bound byte/float work; nothing here is GEMM shaped.
+// Pixel-parallel byte/float work (the five filter passes share one LDS-tiled launch); nothing here is GEMM shaped.
 #include "dslam_internal.h"
 
 namespace dslam {
@@ -68,18 +68,18 @@ __device__ __forceinline__ float det_exp(float x) {
 
 constexpr float kMeanSigmaL = 1.2232f;
 
-// One pass of filterDepth over the interior [2, W-2) x [2, H-2); border pixels of `out` are not written
-// (upstream's loop bounds), which is why the two buffers keep different borders -- see launch_bilateral.
-__global__ __launch_bounds__(256) void k_filter_depth(const float *__restrict__ in, float *__restrict__ out, int W, int H) {
-  const int x = blockIdx.x * 32 + (threadIdx.x & 31), y = blockIdx.y * 8 + (threadIdx.x >> 5);
-  if (x < 2 || y < 2 || x >= W - 2 || y >= H - 2) return;
-  const float z = in[x + y * W];
-  if (z < 0.0f) { out[x + y * W] = -1.0f; return; }
+// filterDepth for one pixel, reading its 5x5 neighbourhood from an LDS tile of row stride S
+template <int S>
+__device__ __forceinline__ float filter_depth_pixel(const float *in, int c) {
+  const float z = in[c];
+  if (z < 0.0f) return -1.0f;
   const float sigma_z = 1.0f / (0.0012f + 0.0019f * (z - 0.4f) * (z - 0.4f) + 0.0001f / sqrtf(z) * 0.25f);
   float final_depth = 0.0f, w_sum = 0.0f;
+#pragma unroll
   for (int i = -2; i <= 2; i++)
+#pragma unroll
     for (int j = -2; j <= 2; j++) {
-      const float tmpz = in[(x + j) + (y + i) * W];
+      const float tmpz = in[c + j + i * S];
       if (tmpz < 0.0f) continue;
       float dz = tmpz - z;
       dz *= dz;
@@ -87,39 +87,60 @@ __global__ __launch_bounds__(256) void k_filter_depth(const float *__restrict__ 
       w_sum += w;
       final_depth += w * tmpz;
     }
-  out[x + y * W] = final_depth / w_sum;
+  return final_depth / w_sum;
 }
 
-__global__ __launch_bounds__(256) void k_convert_depth_plain(const short *__restrict__ raw, float *__restrict__ depth, int n, float a, float b) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  const int d = raw[i];
-  depth[i] = (d <= 0 || d > 32000) ? -1.0f : (float)d * a + b;
-}
-
-// UpdateView with useBilateralFilter: depth = convert(raw); then
+// UpdateView with useBilateralFilter, all of it in one launch: depth = convert(raw); then
 //   filter(float_image <- depth); filter(depth <- float_image); ... five passes; depth = float_image.
-// float_image is zero-initialised once and its border is never written, so the final depth has a 2-pixel border of
-// 0.0 (= invalid for the fusion path) and passes 2 and 4 see zeros as neighbours there -- both as upstream.
+// Upstream's filter writes only the interior [2, W-2) x [2, H-2) and its float_image is zero-initialised, so the
+// result has a 2-pixel border of 0.0 (= invalid for the fusion path) and passes 2 and 4 see zeros as neighbours
+// there.  Five launches take 180 us for 640x480; instead a workgroup keeps a 16x16 output tile plus the 10-pixel
+// halo the five passes need in two LDS images and ping-pongs between them, the valid region shrinking by 2 per
+// pass (one read of the raw image, one write of the result; 86 us).  The filter is arithmetic-bound (25 taps x 5
+// passes x ~40 instructions per pixel), so the tile is small: 1200 workgroups fill the SIMDs where 32x32 tiles
+// (300 workgroups, 1.6x instead of 2.3x redundant arithmetic) left them one wave each and took 118 us.
+constexpr int kFilterTile = 16, kFilterHalo = 10, kFilterSpan = kFilterTile + 2 * kFilterHalo;
+
+__global__ __launch_bounds__(256) void k_bilateral5(const short *__restrict__ raw, float *__restrict__ out, int W, int H,
+                                                    float a, float b) {
+  constexpr int S = kFilterSpan;
+  __shared__ float A[S * S], B[S * S];
+  const int gx0 = blockIdx.x * kFilterTile - kFilterHalo, gy0 = blockIdx.y * kFilterTile - kFilterHalo;
+  for (int c = threadIdx.x; c < S * S; c += blockDim.x) {
+    const int gx = gx0 + c % S, gy = gy0 + c / S;
+    float d = -1.0f;
+    if (gx >= 0 && gx < W && gy >= 0 && gy < H) {
+      const int r = raw[gx + (size_t)gy * W];
+      d = (r <= 0 || r > 32000) ? -1.0f : (float)r * a + b;
+    }
+    A[c] = d;     // view->depth: converted depth everywhere
+    B[c] = 0.0f;  // float_image: zero wherever no pass writes
+  }
+  __syncthreads();
+#pragma unroll 1
+  for (int pass = 1; pass <= 5; pass++) {
+    const float *src = (pass & 1) ? A : B;
+    float *dst = (pass & 1) ? B : A;
+    const int m = 2 * pass, n = S - 2 * m;  // cells [m, S - m)^2 are computable from the previous pass
+    for (int k = threadIdx.x; k < n * n; k += blockDim.x) {
+      const int tx = m + k % n, ty = m + k / n;
+      const int gx = gx0 + tx, gy = gy0 + ty;
+      if (gx >= 2 && gx < W - 2 && gy >= 2 && gy < H - 2) dst[tx + ty * S] = filter_depth_pixel<S>(src, tx + ty * S);
+    }
+    __syncthreads();
+  }
+  for (int k = threadIdx.x; k < kFilterTile * kFilterTile; k += blockDim.x) {
+    const int tx = kFilterHalo + k % kFilterTile, ty = kFilterHalo + k / kFilterTile;
+    const int gx = gx0 + tx, gy = gy0 + ty;
+    if (gx < W && gy < H) out[gx + (size_t)gy * W] = B[tx + ty * S];
+  }
+}
+
 int launch_bilateral(dslam_engine *e, dslam_view *v) {
-  const int W = v->w_d, H = v->h_d, n = W * H;
-  if (!v->filter_tmp) {
-    DSLAM_HIP(hipMalloc(&v->filter_tmp, (size_t)n * sizeof(float)));
-    DSLAM_HIP(hipMemsetAsync(v->filter_tmp, 0, (size_t)n * sizeof(float), e->stream));
-  }
-  hipLaunchKernelGGL(k_convert_depth_plain, dim3((n + 255) / 256), dim3(256), 0, e->stream, v->raw_src, v->depth, n,
-                     v->affine_a, v->affine_b);
-  const dim3 grid((W + 31) / 32, (H + 7) / 8);
-  float *a = v->depth, *b = v->filter_tmp;
-  for (int pass = 0; pass < 5; pass++) {
-    hipLaunchKernelGGL(k_filter_depth, grid, dim3(256), 0, e->stream, a, b, W, H);
-    float *t = a; a = b; b = t;
-  }
+  const int W = v->w_d, H = v->h_d;
+  hipLaunchKernelGGL(k_bilateral5, dim3((W + kFilterTile - 1) / kFilterTile, (H + kFilterTile - 1) / kFilterTile), dim3(256), 0,
+                     e->stream, v->raw_src, v->depth, W, H, v->affine_a, v->affine_b);
   DSLAM_HIP(hipGetLastError());
-  // the result sits in filter_tmp; make it the view's depth image by swapping the two buffers.  The new scratch
-  // buffer must look like upstream's floatImage again (zero border, interior rewritten before it is read)
-  float *t = v->depth; v->depth = v->filter_tmp; v->filter_tmp = t;
-  DSLAM_HIP(hipMemsetAsync(v->filter_tmp, 0, (size_t)n * sizeof(float), e->stream));
   v->depth_dirty = false;
   return DSLAM_OK;
 }

@@ -7,6 +7,7 @@ gpurun_out/final_bench_sync.json    <- python bench.py --sync --steps 100 --warm
 gpurun_out/final_stats/             <- rocprofv3 --kernel-trace --stats ... bench.py --steps 100 --warmup 10 --no-cpu-baseline --reint 0
 gpurun_out/final_fetch|final_write/ <- rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --kernel-trace ... bench.py --steps 30 --warmup 5
 gpurun_out/final_stress.json        <- python denseslam-global-consistency-h_amd/harness/stress.py 64
+gpurun_out/final_side_bench.json    <- python denseslam-global-consistency-h_amd/harness/side_bench.py 50
 """
 import csv
 import glob
@@ -51,6 +52,9 @@ def main():
     shutil.copy(newest("final_stats/*/*kernel_stats.csv"), os.path.join(HERE, f"{tag}_bench_steps100_kernel_stats.csv"))
     json.dump(last_json_line(os.path.join(OUT, "final_stress.json")),
               open(os.path.join(HERE, f"{tag}_stress_integrate.json"), "w"), indent=1)
+    side = os.path.join(OUT, "final_side_bench.json")
+    if os.path.exists(side):
+        json.dump(last_json_line(side), open(os.path.join(HERE, f"{tag}_side_bench.json"), "w"), indent=1)
 
     # HBM traffic of k_integrate from the two PMC passes (MI355X_MICROARCH.md, "HBM / rocprofv3"): counters are in KiB;
     # on gfx950 FETCH_SIZE counts wide (16 B per lane) streaming reads at half their size -> doubled; WRITE_SIZE is exact.
