@@ -130,7 +130,6 @@ int dslam_engine_create(int device_index, dslam_engine **out) {
   dslam_engine *e = new dslam_engine();
   e->device = device_index;
   DSLAM_HIP(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
-  DSLAM_HIP(hipStreamCreateWithFlags(&e->copy_stream, hipStreamNonBlocking));
   e->pinned_bytes = 64 * 1024;
   DSLAM_HIP(hipHostMalloc(&e->pinned, e->pinned_bytes, hipHostMallocDefault));
   memset(e->pinned, 0, e->pinned_bytes);
@@ -156,7 +155,6 @@ int dslam_engine_destroy(dslam_engine *e) {
   if (e->icp_partials_host) (void)hipHostFree(e->icp_partials_host);
   for (auto ev : e->ev_pool) (void)hipEventDestroy(ev);
   (void)hipStreamDestroy(e->stream);
-  (void)hipStreamDestroy(e->copy_stream);
   delete e;
   return DSLAM_OK;
 }

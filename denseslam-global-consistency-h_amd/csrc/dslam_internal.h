@@ -37,7 +37,6 @@ bool invert_matrix(const float *m, float *dst);
 struct dslam_engine {
   int device = 0;
   hipStream_t stream = nullptr;
-  hipStream_t copy_stream = nullptr;
   bool async_mode = false;
   dslam_weight_params wp{0, 1, 1.0f};
   // scratch shared by all scenes of this engine (sized for the largest scene seen)
