@@ -14,6 +14,8 @@
 //   Only 16-byte chunks that changed are written back.
 //   Grid = fixed 2048 workgroups of 4 waves (one full residency wave of the 256 CUs), grid-stride over the
 //   visible list whose length is read from device memory (no host round trip after allocation).
+#include <hip/hip_ext.h>
+
 #include "dslam_internal.h"
 
 #pragma clang fp contract(off)
@@ -299,21 +301,24 @@ int launch_integrate(dslam_engine *e, dslam_scene *s, const dslam_view *v, const
     ip.push_words = s->history_words; ip.push_ring = push_ring;
   }
   ip.timer_slot = nullptr;
+  // Timed launches (bench roofline) attach their two events to the dispatch packet itself (hipExtLaunchKernelGGL), so
+  // the elapsed time is the kernel's own start-to-end interval -- what rocprofv3 reports -- not the interval between
+  // two separately recorded stream events, which also contains ~3 us of packet processing.
   const bool timed = e->timer_enabled && e->ev_used + 2 <= e->ev_pool.size();
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
   if (timed) {
     ip.timer_slot = e->timer_counts_dev + (e->ev_used / 2);
-    DSLAM_HIP(hipEventRecord(e->ev_pool[e->ev_used], e->stream));
-  }
-  if (deintegrate) {
-    if (ip.same_cam) hipLaunchKernelGGL((k_integrate<true, true>), dim3(kIntegrateGrid), dim3(256), 0, e->stream, ip);
-    else hipLaunchKernelGGL((k_integrate<true, false>), dim3(kIntegrateGrid), dim3(256), 0, e->stream, ip);
-  } else {
-    if (ip.same_cam) hipLaunchKernelGGL((k_integrate<false, true>), dim3(kIntegrateGrid), dim3(256), 0, e->stream, ip);
-    else hipLaunchKernelGGL((k_integrate<false, false>), dim3(kIntegrateGrid), dim3(256), 0, e->stream, ip);
-  }
-  if (timed) {
-    DSLAM_HIP(hipEventRecord(e->ev_pool[e->ev_used + 1], e->stream));
+    ev0 = e->ev_pool[e->ev_used];
+    ev1 = e->ev_pool[e->ev_used + 1];
     e->ev_used += 2;
+  }
+  const dim3 grid(kIntegrateGrid), block(256);
+  if (deintegrate) {
+    if (ip.same_cam) hipExtLaunchKernelGGL((k_integrate<true, true>), grid, block, 0, e->stream, ev0, ev1, 0, ip);
+    else hipExtLaunchKernelGGL((k_integrate<true, false>), grid, block, 0, e->stream, ev0, ev1, 0, ip);
+  } else {
+    if (ip.same_cam) hipExtLaunchKernelGGL((k_integrate<false, true>), grid, block, 0, e->stream, ev0, ev1, 0, ip);
+    else hipExtLaunchKernelGGL((k_integrate<false, false>), grid, block, 0, e->stream, ev0, ev1, 0, ip);
   }
   DSLAM_HIP(hipGetLastError());
   return DSLAM_OK;
