@@ -170,3 +170,42 @@ def test_render_tile_budget_rule(pkg, synth, gpu, oracle, budget):
     assert n_vis > 300  # budgets 40 and 300 bite, 1500 does not
     if budget == 40:
         assert (imgs["gpu"] > 0).sum() < (full > 0).sum(), "a budget far below the visible count must lose surface"
+
+
+def test_full_size_parity_with_oracle(pkg, synth, gpu, oracle):
+    """BASELINE configs[1]/[2] geometry at full size: 640x480 S-street frames, the upstream default pools
+    (0x40000 voxel blocks, 0x100000 + 0x20000 hash entries), fusion + decay + sliding window, then the raycast --
+    the whole map state byte-for-byte against the CPU oracle, not just the down-sized scenes of the other tests."""
+    oracle.set_threads(16)
+    wl = synth.s_street()
+    p = pkg.SceneParams(**wl.scene_kwargs)
+    n_frames, max_age = 8, 5
+    objs = {}
+    for name, api in (("gpu", gpu), ("oracle", oracle)):
+        s = api.create_scene(p)
+        objs[name] = (api, s, api.create_render_state(s, wl.W, wl.H), api.create_view(wl.W, wl.H))
+    for i in range(n_frames):
+        rgba, mm, M = wl.frame(i)
+        for name, (api, s, rs, v) in objs.items():
+            api.view_update(v, rgba, mm, timestamp=float(i))
+            api.process_frame(s, v, rs, M, wl.intr)
+            if api.stats(s, rs)["fusion_fifo_len"] > max_age:
+                api.slide_window(s, rs, max_age)
+            api.decay(s, rs, 1, 3, True)
+        if i in (0, n_frames - 1):  # (a full snapshot moves 2 x 1 GiB of voxel blocks per engine)
+            snaps = {name: util.snapshot(api, s, rs) for name, (api, s, rs, v) in objs.items()}
+            util.assert_same_state(snaps["gpu"], snaps["oracle"], f"full size, frame {i}")
+    st = snaps["gpu"]["stats"]
+    assert st["no_visible_entries"] > 5000 and st["slid_block_count"] + st["decayed_block_count"] > 0
+    util.check_invariants(snaps["gpu"], objs["gpu"][1].params)
+    del snaps
+    imgs = {}
+    for name, (api, s, rs, v) in objs.items():
+        free = api.create_render_state(s, wl.W, wl.H)
+        imgs[name] = (api.get_image(s, free, M, wl.intr, pkg.IMAGE_DEPTH),
+                      api.get_image(s, free, M, wl.intr, pkg.IMAGE_COLOUR_FROM_VOLUME),
+                      api.download_range_image(free)[:(wl.H + 7) // 8, :(wl.W + 7) // 8])
+    assert np.array_equal(imgs["gpu"][2], imgs["oracle"][2]), "range image"
+    assert np.array_equal(imgs["gpu"][0] > 0, imgs["oracle"][0] > 0) and (imgs["gpu"][0] > 0).mean() > 0.5
+    assert np.abs(imgs["gpu"][0] - imgs["oracle"][0]).max() <= 1e-4  # metres (float; bit-identical in practice)
+    assert np.abs(imgs["gpu"][1].astype(int) - imgs["oracle"][1].astype(int)).max() <= 1
