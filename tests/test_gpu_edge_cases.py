@@ -172,14 +172,15 @@ def test_render_tile_budget_rule(pkg, synth, gpu, oracle, budget):
         assert (imgs["gpu"] > 0).sum() < (full > 0).sum(), "a budget far below the visible count must lose surface"
 
 
-def test_full_size_parity_with_oracle(pkg, synth, gpu, oracle):
+@pytest.mark.parametrize("swapping", [False, True])
+def test_full_size_parity_with_oracle(pkg, synth, gpu, oracle, swapping):
     """BASELINE configs[1]/[2] geometry at full size: 640x480 S-street frames, the upstream default pools
     (0x40000 voxel blocks, 0x100000 + 0x20000 hash entries), fusion + decay + sliding window, then the raycast --
     the whole map state byte-for-byte against the CPU oracle, not just the down-sized scenes of the other tests."""
     oracle.set_threads(16)
     wl = synth.s_street()
-    p = pkg.SceneParams(**wl.scene_kwargs)
-    n_frames, max_age = 8, 5
+    p = pkg.SceneParams(use_swapping=int(swapping), **wl.scene_kwargs)
+    n_frames, max_age = (14, 5) if swapping else (8, 5)
     objs = {}
     for name, api in (("gpu", gpu), ("oracle", oracle)):
         s = api.create_scene(p)
@@ -195,8 +196,20 @@ def test_full_size_parity_with_oracle(pkg, synth, gpu, oracle):
         if i in (0, n_frames - 1):  # (a full snapshot moves 2 x 1 GiB of voxel blocks per engine)
             snaps = {name: util.snapshot(api, s, rs) for name, (api, s, rs, v) in objs.items()}
             util.assert_same_state(snaps["gpu"], snaps["oracle"], f"full size, frame {i}")
+            if swapping:  # ITMGlobalCache bookkeeping and the blocks parked on the host
+                sw = {name: api.download_swap_states(s) for name, (api, s, rs, v) in objs.items()}
+                assert np.array_equal(sw["gpu"], sw["oracle"]), f"swap states, frame {i}"
+                out = np.nonzero(snaps["gpu"]["hash"]["ptr"] == -1)[0]
+                for t in out[:: max(1, len(out) // 40)]:
+                    a, ba = gpu.download_stored_block(objs["gpu"][1], int(t))
+                    b, bb = oracle.download_stored_block(objs["oracle"][1], int(t))
+                    assert a == b and (not a or np.array_equal(ba.view(np.uint64), bb.view(np.uint64)))
     st = snaps["gpu"]["stats"]
-    assert st["no_visible_entries"] > 5000 and st["slid_block_count"] + st["decayed_block_count"] > 0
+    assert st["no_visible_entries"] > 5000
+    if not swapping:
+        assert st["slid_block_count"] + st["decayed_block_count"] > 0
+    if swapping:  # (blocks that leave the view are parked on the host before the window or the decay reaches them)
+        assert (snaps["gpu"]["hash"]["ptr"] == -1).sum() > 0, "something must have been swapped out"
     util.check_invariants(snaps["gpu"], objs["gpu"][1].params)
     del snaps
     imgs = {}
