@@ -52,6 +52,9 @@ def main():
     shutil.copy(newest("final_stats/*/*kernel_stats.csv"), os.path.join(HERE, f"{tag}_bench_steps100_kernel_stats.csv"))
     json.dump(last_json_line(os.path.join(OUT, "final_stress.json")),
               open(os.path.join(HERE, f"{tag}_stress_integrate.json"), "w"), indent=1)
+    hostio = os.path.join(OUT, "final_bench_hostio.json")
+    if os.path.exists(hostio):
+        json.dump(last_json_line(hostio), open(os.path.join(HERE, f"{tag}_bench_hostio.json"), "w"), indent=1)
     side = os.path.join(OUT, "final_side_bench.json")
     if os.path.exists(side):
         json.dump(last_json_line(side), open(os.path.join(HERE, f"{tag}_side_bench.json"), "w"), indent=1)
