@@ -172,3 +172,42 @@ def test_gpu_is_deterministic(pkg, synth, gpu):
         snaps.append(sn)
     util.assert_same_state(snaps[0], snaps[1], "two GPU runs")
     assert np.array_equal(snaps[0]["img"], snaps[1]["img"])
+
+
+def test_separate_visualisation_calls_equal_get_image(pkg, synth, gpu, oracle):
+    """ITMVisualisationEngine's steps called one by one (FindVisibleBlocks, CreateExpectedDepths, RenderImage,
+    CountVisibleBlocks: InfiniTamDriver.cpp:229-277, DenseSlam.cpp:555-556) give what GetImage's fused launches give,
+    on the HIP engine and against the oracle, for every image type and from a pose other than the fused ones."""
+    wl = synth.s_tiny()
+    p = util.small_params(pkg, wl)
+    M_free = synth.world_to_camera(wl.pose(2) @ synth.pose_matrix(synth.look_rotation(0.05, -0.03), [0.03, 0.01, -0.02]))
+    out = {}
+    for name, api in (("gpu", gpu), ("oracle", oracle)):
+        s = api.create_scene(p)
+        rs, v = api.create_render_state(s, wl.W, wl.H), api.create_view(wl.W, wl.H)
+        for i in range(4):
+            rgba, mm, M = wl.frame(i)
+            api.view_update(v, rgba, mm, timestamp=float(i))
+            api.process_frame(s, v, rs, M, wl.intr)
+        fused, stepwise = api.create_render_state(s, wl.W, wl.H), api.create_render_state(s, wl.W, wl.H)
+        res = {}
+        for t in (pkg.IMAGE_DEPTH, pkg.IMAGE_SHADED, pkg.IMAGE_COLOUR_FROM_VOLUME, pkg.IMAGE_COLOUR_FROM_NORMAL):
+            a = api.get_image(s, fused, M_free, wl.intr, t)
+            api.find_visible_blocks(s, stepwise, M_free, wl.intr)
+            api.create_expected_depths(s, stepwise, M_free, wl.intr)
+            b = api.render_image(s, stepwise, M_free, wl.intr, t)
+            assert np.array_equal(a, b), f"{name}: image type {t}: stepwise != GetImage"
+            res[t] = a
+        assert np.array_equal(api.download_visible_ids(fused), api.download_visible_ids(stepwise))
+        n_vis = api.stats(s, stepwise)["no_visible_entries"]
+        nl = s.params.num_local_blocks
+        res["counts"] = (n_vis, api.count_visible_blocks(s, stepwise, 0, nl), api.count_visible_blocks(s, stepwise, nl - 100, nl))  # slots are dealt top-down
+        res["ids"] = api.download_visible_ids(stepwise)
+        res["range"] = api.download_range_image(stepwise)[:(wl.H + 7) // 8, :(wl.W + 7) // 8]
+        out[name] = res
+    g, o = out["gpu"], out["oracle"]
+    assert g["counts"] == o["counts"] and g["counts"][0] == g["counts"][1] > g["counts"][2] > 0
+    assert np.array_equal(g["ids"], o["ids"]) and np.array_equal(g["range"], o["range"])
+    assert np.abs(g[pkg.IMAGE_DEPTH] - o[pkg.IMAGE_DEPTH]).max() <= 1e-4
+    for t in (pkg.IMAGE_SHADED, pkg.IMAGE_COLOUR_FROM_VOLUME, pkg.IMAGE_COLOUR_FROM_NORMAL):
+        assert np.abs(g[t].astype(int) - o[t].astype(int)).max() <= 1
