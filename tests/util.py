@@ -18,11 +18,13 @@ def snapshot(api, scene, rs=None):
     return out
 
 
-def assert_same_state(a, b, what=""):
+def assert_same_state(a, b, what="", ignore_stats=()):
     """Bit-exact comparison of two snapshots (integer/byte work: no tolerance)."""
     sa, sb = a["stats"], b["stats"]
     for k in ("last_free_block_id", "last_free_excess_id", "no_visible_entries", "decayed_block_count",
               "slid_block_count", "frame_counter", "fusion_fifo_len", "defusion_fifo_len", "alloc_failures"):
+        if k in ignore_stats:
+            continue
         assert sa[k] == sb[k], f"{what}: stats[{k}] {sa[k]} != {sb[k]}"
     assert np.array_equal(a["hash"], b["hash"]), f"{what}: hash table differs"
     lf, lx = sa["last_free_block_id"], sa["last_free_excess_id"]
