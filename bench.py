@@ -195,7 +195,7 @@ def main():
             batch = reint.Batch([("dev", rgba_d.data_ptr() + i * rgba_stride, depth_d.data_ptr() + i * depth_stride) for i in ids],
                                 [Ms[i] for i in ids], new_poses, wl.intr)
             chunk = 64
-            ag = reint.make_torch_all_gather(vox_t, dist, chunk, eng.synchronize) if use_dist else None
+            ag = reint.make_torch_all_gather(vox_t, dist, chunk, eng.synchronize, api=eng, scene=scene) if use_dist else None
             timers = {}
             barrier()
             reint.reintegrate(eng, scene, view, rs, batch, rank=rank, world=world, chunk_blocks=chunk, all_gather=ag,

@@ -510,6 +510,14 @@ class CApi:
         self._call("upload_voxel_blocks", self._engine, scene.ptr, C.c_int(first), C.c_int(b.size // BLOCK_SIZE3),
                    _vptr(b))
 
+    def shard_pack(self, scene, first_block, groups, shard, num_shards, chunk_blocks, send_dev_ptr):
+        self._call("shard_pack", self._engine, scene.ptr, C.c_int(first_block), C.c_int(groups), C.c_int(shard),
+                   C.c_int(num_shards), C.c_int(chunk_blocks), C.c_void_p(send_dev_ptr))
+
+    def shard_unpack(self, scene, first_block, groups, num_shards, chunk_blocks, recv_dev_ptr):
+        self._call("shard_unpack", self._engine, scene.ptr, C.c_int(first_block), C.c_int(groups), C.c_int(num_shards),
+                   C.c_int(chunk_blocks), C.c_void_p(recv_dev_ptr))
+
     def upload_visible_ids(self, rs, ids):
         ids = np.ascontiguousarray(ids, dtype=np.int32)
         self._call("upload_visible_ids", self._engine, rs.ptr, _vptr(ids), C.c_int(ids.size))

@@ -273,6 +273,38 @@ int dslam_scene_set_shard_range(dslam_scene *s, int first_block, int num_blocks)
   return DSLAM_OK;
 }
 
+static int shard_region_ok(const dslam_scene *s, int first_block, int groups, int num_shards, int chunk_blocks) {
+  DSLAM_REQUIRE(s && first_block >= 0 && groups >= 0 && num_shards >= 1 && chunk_blocks >= 1, "bad shard region");
+  DSLAM_REQUIRE((long long)first_block + (long long)groups * num_shards * chunk_blocks <= s->p.num_local_blocks,
+                "shard region exceeds the voxel-block pool");
+  return DSLAM_OK;
+}
+
+int dslam_shard_pack(dslam_engine *e, const dslam_scene *s, int first_block, int groups, int shard, int num_shards,
+                     int chunk_blocks, void *send_dev) {
+  DSLAM_REQUIRE(e && send_dev && shard >= 0 && shard < num_shards, "bad argument");
+  int rc = shard_region_ok(s, first_block, groups, num_shards, chunk_blocks);
+  if (rc || groups == 0) return rc;
+  const size_t chunk_bytes = (size_t)chunk_blocks * kBlock3 * sizeof(uint2);
+  const char *src = reinterpret_cast<const char *>(s->voxels) + (size_t)first_block * kBlock3 * sizeof(uint2) + (size_t)shard * chunk_bytes;
+  DSLAM_HIP(hipMemcpy2DAsync(send_dev, chunk_bytes, src, chunk_bytes * num_shards, chunk_bytes, groups, hipMemcpyDeviceToDevice, e->stream));
+  return finish_call(e);
+}
+
+int dslam_shard_unpack(dslam_engine *e, dslam_scene *s, int first_block, int groups, int num_shards, int chunk_blocks,
+                       const void *recv_dev) {
+  DSLAM_REQUIRE(e && recv_dev, "bad argument");
+  int rc = shard_region_ok(s, first_block, groups, num_shards, chunk_blocks);
+  if (rc || groups == 0) return rc;
+  const size_t chunk_bytes = (size_t)chunk_blocks * kBlock3 * sizeof(uint2);
+  char *dst = reinterpret_cast<char *>(s->voxels) + (size_t)first_block * kBlock3 * sizeof(uint2);
+  for (int r = 0; r < num_shards; r++)
+    DSLAM_HIP(hipMemcpy2DAsync(dst + (size_t)r * chunk_bytes, chunk_bytes * num_shards,
+                               reinterpret_cast<const char *>(recv_dev) + (size_t)r * groups * chunk_bytes, chunk_bytes, chunk_bytes, groups,
+                               hipMemcpyDeviceToDevice, e->stream));
+  return finish_call(e);
+}
+
 // ---- render state / view --------------------------------------------------------------------------------------
 int dslam_render_state_create(dslam_engine *e, const dslam_scene *s, int w, int h, dslam_render_state **out) {
   DSLAM_REQUIRE(e && s && out && w > 0 && h > 0, "bad argument");

@@ -83,17 +83,28 @@ def reintegrate(api, scene, view, rs, batch, rank=0, world=1, chunk_blocks=64, a
     return lo, groups
 
 
-def make_torch_all_gather(voxel_tensor, dist, chunk_blocks, engine_sync):
-    """Collective over a torch uint8 CUDA tensor that IS the scene's voxel-block array (HIP engine)."""
+def make_torch_all_gather(voxel_tensor, dist, chunk_blocks, engine_sync, api=None, scene=None):
+    """Collective over a torch uint8 CUDA tensor that IS the scene's voxel-block array (HIP engine).  With `api` and
+    `scene` the strided pack / unpack runs through the C ABI (dslam_shard_pack / dslam_shard_unpack, the calls a C++
+    caller of RCCL uses); otherwise through torch strided views."""
     import torch
 
     def run(lo, groups):
         world, rank = dist.get_world_size(), dist.get_rank()
         chunk_bytes = chunk_blocks * BLOCK_BYTES
+        recv = torch.empty((world, groups, chunk_bytes), dtype=torch.uint8, device=voxel_tensor.device)
+        if api is not None:
+            send = torch.empty((groups, chunk_bytes), dtype=torch.uint8, device=voxel_tensor.device)
+            api.shard_pack(scene, lo, groups, rank, world, chunk_blocks, send.data_ptr())
+            engine_sync()  # the engine's copies run on its own stream
+            dist.all_gather_into_tensor(recv.view(-1), send.view(-1))
+            torch.cuda.synchronize()
+            api.shard_unpack(scene, lo, groups, world, chunk_blocks, recv.data_ptr())
+            engine_sync()
+            return
         region = voxel_tensor[lo * BLOCK_BYTES:].view(groups, world, chunk_bytes)
         engine_sync()  # the engine's kernels run on its own stream
         send = region[:, rank, :].contiguous()
-        recv = torch.empty((world, groups, chunk_bytes), dtype=torch.uint8, device=voxel_tensor.device)
         dist.all_gather_into_tensor(recv.view(-1), send.view(-1))
         region.copy_(recv.permute(1, 0, 2))
         torch.cuda.synchronize()

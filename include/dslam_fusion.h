@@ -372,6 +372,16 @@ int dslam_scene_set_shard(dslam_scene *s, int shard, int num_shards, int chunk_b
 /* Same, with a contiguous slot range [first_block, first_block + num_blocks): the layout an in-place RCCL
  * all-gather over the voxel-block array needs.  num_blocks < 0 disables. */
 int dslam_scene_set_shard_range(dslam_scene *s, int first_block, int num_blocks);
+/* The exchange step of the chunk-interleaved scheme, for callers that drive RCCL themselves.
+ * The slot range [first_block, first_block + groups * num_shards * chunk_blocks) is `groups` groups of `num_shards`
+ * chunks.  pack: this shard's chunks, in group order, into one contiguous device buffer of
+ * groups * chunk_blocks * 4096 bytes (the all-gather send buffer).  unpack: the all-gather result
+ * [num_shards][groups][chunk_blocks * 4096] back into the voxel-block array.  Both are strided device-to-device
+ * copies on the engine stream. */
+int dslam_shard_pack(dslam_engine *e, const dslam_scene *s, int first_block, int groups, int shard, int num_shards,
+                     int chunk_blocks, void *send_dev);
+int dslam_shard_unpack(dslam_engine *e, dslam_scene *s, int first_block, int groups, int num_shards, int chunk_blocks,
+                       const void *recv_dev);
 
 /* ---- instrumentation ---------------------------------------------------------------------------- */
 /* Time `iterations` back-to-back launches of the integrate kernel alone on the engine stream with HIP
