@@ -1415,7 +1415,7 @@ extern "C" int oracle_create_expected_depths(oracle_engine *eng, const oracle_sc
 namespace {
 // debug counters (oracle_raycast_stats): ray-march steps, interpolated reads, rays
 static long long g_dbg_steps = 0, g_dbg_interp = 0, g_dbg_rays = 0, g_dbg_maxsteps = 0;
-static int *g_dbg_pixel_steps = nullptr;  // optional [2 * W * H]: per ray (steps, steps that found no block)
+static int *g_dbg_pixel_steps = nullptr;  // optional [3 * W * H]: per ray (steps, steps that found no block, runs of such steps)
 
 // castRay
 static inline bool cast_ray(const oracle_scene *s, V4f &out, int x, int y, const float *invM, const float *intr,
@@ -1448,14 +1448,18 @@ static inline bool cast_ray(const oracle_scene *s, V4f &out, int x, int y, const
   dir.x *= dn; dir.y *= dn; dir.z *= dn;
   res = ps;
   IndexCache cache;
-  long long nsteps = 0, ninterp = 0, nmiss = 0;
+  long long nsteps = 0, ninterp = 0, nmiss = 0, nruns = 0;
+  bool prev_miss = false;
   while (total < total_max) {
     nsteps++;
     sdf = read_sdf_uninterp(s, res, hash_found, cache);
     if (!hash_found) {
       nmiss++;
+      if (!prev_miss) nruns++;
+      prev_miss = true;
       step = (float)DSLAM_BLOCK_SIZE;
     } else {
+      prev_miss = false;
       if ((sdf <= 0.1f) && (sdf >= -0.5f)) { sdf = read_sdf_interp(s, res, hash_found, cache); ninterp++; }
       if (sdf <= 0.0f) break;
       step = std::max(sdf * step_scale, 1.0f);
@@ -1471,7 +1475,7 @@ static inline bool cast_ray(const oracle_scene *s, V4f &out, int x, int y, const
 #pragma omp atomic
   g_dbg_rays += 1;
   if (nsteps > g_dbg_maxsteps) g_dbg_maxsteps = nsteps;
-  if (g_dbg_pixel_steps) { g_dbg_pixel_steps[2 * dbg_loc] = nsteps; g_dbg_pixel_steps[2 * dbg_loc + 1] = nmiss; }
+  if (g_dbg_pixel_steps) { g_dbg_pixel_steps[3 * dbg_loc] = nsteps; g_dbg_pixel_steps[3 * dbg_loc + 1] = nmiss; g_dbg_pixel_steps[3 * dbg_loc + 2] = nruns; }
   if (sdf <= 0.0f) {
     step = sdf * step_scale;
     res.x += step * dir.x; res.y += step * dir.y; res.z += step * dir.z;
