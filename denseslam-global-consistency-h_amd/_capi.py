@@ -290,6 +290,30 @@ class CApi:
         self._call("view_update_from_store", self._engine, view.ptr, fs.ptr, C.c_int(slot), C.c_float(affine_a),
                    C.c_float(affine_b), C.c_double(timestamp), C.c_int(int(bilateral)))
 
+    def view_update_dataset(self, view, colour, depth_raw, depth_format, max_depth_m, affine_a=1.0 / 1000.0, affine_b=0.0,
+                            timestamp=0.0, bilateral=False):
+        """Colour image (H, W, 4) RGBA or (H, W, 3) BGR plus the dataset's raw 16-bit depth image; depth_format:
+        0 millimetres, 1 KITTI-style depth * 256, 2 TUM / ICL-NUIM (divide by 5)."""
+        colour = np.ascontiguousarray(colour, dtype=np.uint8)
+        ch = colour.shape[-1]
+        raw = np.ascontiguousarray(depth_raw, dtype=np.int16)
+        assert colour.size == view.width * view.height * ch and raw.size == view.width_d * view.height_d
+        self._call("view_update_dataset", self._engine, view.ptr, _vptr(colour), C.c_int(ch), _vptr(raw),
+                   C.c_int(depth_format), C.c_float(max_depth_m), C.c_float(affine_a), C.c_float(affine_b),
+                   C.c_double(timestamp), C.c_int(int(bilateral)))
+
+    def download_view_raw_depth(self, view):
+        out = np.empty((view.height_d, view.width_d), dtype=np.int16)
+        self._call("download_view_raw_depth", self._engine, view.ptr, _vptr(out))
+        return out
+
+    def get_depth_image_int16(self, scene, rs, M, intr, scale):
+        """GetImage(FREECAMERA_DEPTH) as int16 = (int16)(metres * scale): scale 1000 -> mm, 256 -> the PNG format."""
+        m, k = self._mi(M, intr)
+        out = np.empty((rs.height, rs.width), dtype=np.int16)
+        self._call("get_depth_image_int16", self._engine, scene.ptr, rs.ptr, _fptr(m), _fptr(k), C.c_int(scale), _vptr(out))
+        return out
+
     def download_view_rgba(self, view):
         out = np.empty((view.height, view.width, 4), dtype=np.uint8)
         self._call("download_view_rgba", self._engine, view.ptr, _vptr(out))

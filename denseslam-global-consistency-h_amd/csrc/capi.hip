@@ -429,6 +429,25 @@ int dslam_view_update_bgr_device(dslam_engine *e, dslam_view *v, const void *bgr
   return finish_view_update(e, v, v->rgba, depth_dev, a, b, timestamp, use_bilateral);
 }
 
+int dslam_view_update_dataset(dslam_engine *e, dslam_view *v, const uint8_t *colour_host, int channels,
+                              const int16_t *depth_raw_host, int depth_format, float max_depth_m, float a, float b,
+                              double timestamp, int use_bilateral) {
+  DSLAM_REQUIRE(e && v && colour_host && depth_raw_host, "null argument");
+  DSLAM_REQUIRE(channels == 3 || channels == 4, "colour_channels must be 3 (BGR) or 4 (RGBA)");
+  DSLAM_REQUIRE(depth_format >= DSLAM_DEPTH_MM && depth_format <= DSLAM_DEPTH_RGBD_X5, "unknown depth format");
+  int rc = upload_view_host(e, v, colour_host, channels, depth_raw_host);
+  if (rc) return rc;
+  if (depth_format != DSLAM_DEPTH_MM && (rc = launch_dataset_depth(e, v->raw_depth, v->w_d * v->h_d, depth_format, max_depth_m))) return rc;
+  return finish_view_update(e, v, v->rgba, v->raw_depth, a, b, timestamp, use_bilateral);
+}
+
+int dslam_download_view_raw_depth(dslam_engine *e, const dslam_view *v, int16_t *out) {
+  DSLAM_REQUIRE(e && v && out, "null argument");
+  DSLAM_HIP(hipMemcpyAsync(out, v->raw_src, (size_t)v->w_d * v->h_d * 2, hipMemcpyDeviceToHost, e->stream));
+  DSLAM_HIP(hipStreamSynchronize(e->stream));
+  return DSLAM_OK;
+}
+
 int dslam_download_view_rgba(dslam_engine *e, const dslam_view *v, uint8_t *out) {
   DSLAM_REQUIRE(e && v && out, "null argument");
   DSLAM_HIP(hipMemcpyAsync(out, v->rgba_src, (size_t)v->w_rgb * v->h_rgb * 4, hipMemcpyDeviceToHost, e->stream));
@@ -750,6 +769,21 @@ int dslam_get_image(dslam_engine *e, const dslam_scene *s, dslam_render_state *r
   if ((rc = launch_find_visible_and_depths(e, s, r, M, intr))) return rc;
   if ((rc = launch_render(e, s, r, M, intr, type))) return rc;
   return image_out(e, r, type, out_rgba, out_float);
+}
+
+int dslam_get_depth_image_int16(dslam_engine *e, const dslam_scene *s, dslam_render_state *r, const float M[16],
+                                const float intr[4], int scale, int16_t *out_host) {
+  DSLAM_REQUIRE(e && s && r && M && intr && out_host && scale > 0, "bad argument");
+  int rc;
+  if ((rc = launch_find_visible_and_depths(e, s, r, M, intr))) return rc;
+  if ((rc = launch_render(e, s, r, M, intr, DSLAM_IMAGE_DEPTH))) return rc;
+  // the RGBA image buffer of the render state is idle in this mode: it takes the int16 image (2 of its 4 bytes per pixel)
+  const int n = r->w * r->h;
+  short *tmp = reinterpret_cast<short *>(r->image_rgba);
+  if ((rc = launch_depth_to_int16(e, r->image_float, tmp, n, scale))) return rc;
+  DSLAM_HIP(hipMemcpyAsync(out_host, tmp, (size_t)n * 2, hipMemcpyDeviceToHost, e->stream));
+  DSLAM_HIP(hipStreamSynchronize(e->stream));
+  return DSLAM_OK;
 }
 
 int dslam_create_icp_maps(dslam_engine *e, const dslam_scene *s, dslam_render_state *r, const float M[16],

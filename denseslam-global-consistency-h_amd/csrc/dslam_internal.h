@@ -149,6 +149,8 @@ int launch_scene_reset(dslam_engine *e, dslam_scene *s);
 int launch_view_convert(dslam_engine *e, dslam_view *v, const void *rgba_dev, const void *depth_dev, float a, float b);
 int launch_bgr_to_rgba(dslam_engine *e, const void *bgr_dev, uchar4 *rgba_dev, int npix);
 int launch_bilateral(dslam_engine *e, dslam_view *v);
+int launch_dataset_depth(dslam_engine *e, short *depth_dev, int n, int format, float max_depth_m);
+int launch_depth_to_int16(dslam_engine *e, const float *depth_dev, short *out_dev, int n, int scale);
 int launch_depth_post(dslam_engine *e, short *curr_dev, const unsigned short *prev_dev, int cols, int rows,
                       const float *Tpc, const float *intr, float threshold, float area, int *count_dev);
 int launch_allocate(dslam_engine *e, dslam_scene *s, const dslam_view *v, dslam_render_state *r, const float *M_d,

@@ -146,6 +146,46 @@ int launch_bilateral(dslam_engine *e, dslam_view *v) {
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// dataset wire formats (PrecomputedDepthProvider::ReadPrecomputed's loop; FloatDepthmapToShort / ...ToInt16)
+// ---------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ short wrap_i16(float f) { return (short)(int)f; }  // float -> int32 (truncate) -> low 16 bits
+
+__global__ __launch_bounds__(256) void k_dataset_depth(short *__restrict__ depth, int n, int format, float max_x256,
+                                                       short max_mm_s) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  short d = depth[i];
+  if (format == DSLAM_DEPTH_KITTI_X256) {
+    if ((float)d > max_x256) d = 0;
+    d = wrap_i16((float)d * 3.90625f);  // kitti_factor = 1000.0 / 256.0
+  } else {
+    d = (short)(int)((double)(float)d / 5.0);
+    if (d > max_mm_s) d = 0;
+  }
+  depth[i] = d;
+}
+
+int launch_dataset_depth(dslam_engine *e, short *depth_dev, int n, int format, float max_depth_m) {
+  const float max_mm_f = max_depth_m * 1000.0f;  // GetMaxDepthMeters() * kMetersToMillimeters
+  const short max_mm_s = (short)(int)roundf(max_mm_f);
+  hipLaunchKernelGGL(k_dataset_depth, dim3((n + 255) / 256), dim3(256), 0, e->stream, depth_dev, n, format,
+                     max_depth_m * 256.0f, max_mm_s);
+  DSLAM_HIP(hipGetLastError());
+  return DSLAM_OK;
+}
+
+__global__ __launch_bounds__(256) void k_depth_to_int16(const float *__restrict__ depth, short *__restrict__ out, int n, float scale) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = wrap_i16(depth[i] * scale);
+}
+
+int launch_depth_to_int16(dslam_engine *e, const float *depth_dev, short *out_dev, int n, int scale) {
+  hipLaunchKernelGGL(k_depth_to_int16, dim3((n + 255) / 256), dim3(256), 0, e->stream, depth_dev, out_dev, n, (float)scale);
+  DSLAM_HIP(hipGetLastError());
+  return DSLAM_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // depthPostProcessing
 // ---------------------------------------------------------------------------------------------------------
 struct PostParams {

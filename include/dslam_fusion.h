@@ -175,6 +175,25 @@ int dslam_view_update_bgr(dslam_engine *e, dslam_view *v, const uint8_t *bgr_hos
                           float affine_a, float affine_b, double timestamp, int use_bilateral_filter);
 int dslam_view_update_bgr_device(dslam_engine *e, dslam_view *v, const void *bgr_dev, const void *depth_mm_dev,
                                  float affine_a, float affine_b, double timestamp, int use_bilateral_filter);
+/* Dataset wire formats either side of the path, converted on the device.
+ * Input: the per-pixel loop of PrecomputedDepthProvider::ReadPrecomputed on the 16-bit depth image as stored by the
+ * datasets (PrecomputedDepthProvider.cpp:30-64): KITTI-style maps hold depth * 256 (values above max_depth_m * 256
+ * are dropped, then int16 mm = (int16)((float)v * (1000 / 256))), TUM / ICL-NUIM maps are divided by 5.0 and
+ * dropped above (int16)round(max_depth_m * 1000).  The converted millimetre image then takes UpdateView's path.
+ * colour_channels: 4 = RGBA as dslam_view_update, 3 = OpenCV BGR as dslam_view_update_bgr.  (A float -> int16
+ * conversion that overflows is undefined in C; here it wraps like the x86 code the reference compiles to.) */
+enum { DSLAM_DEPTH_MM = 0, DSLAM_DEPTH_KITTI_X256 = 1, DSLAM_DEPTH_RGBD_X5 = 2 };
+int dslam_view_update_dataset(dslam_engine *e, dslam_view *v, const uint8_t *colour_host, int colour_channels,
+                              const int16_t *depth_raw_host, int depth_format, float max_depth_m, float affine_a,
+                              float affine_b, double timestamp, int use_bilateral_filter);
+/* read-back of the view's raw millimetre image as the kernels see it (after the dataset conversion) */
+int dslam_download_view_raw_depth(dslam_engine *e, const dslam_view *v, int16_t *out_mm);
+/* Output: GetImage(FREECAMERA_DEPTH) followed by FloatDepthmapToShort (scale 1000, InfiniTamDriver.cpp:167-180) or
+ * FloatDepthmapToInt16 (scale 256, the raycast-depth PNGs of DenseSlam::SaveRaycastDepth, InfiniTamDriver.cpp:188-
+ * 200, DenseSlam.cpp:573-592): int16 = (int16)(depth_m * scale) per pixel, converted on the device, so half the
+ * bytes cross PCIe and the host loop disappears. */
+int dslam_get_depth_image_int16(dslam_engine *e, const dslam_scene *s, dslam_render_state *r, const float M[16],
+                                const float intrinsics[4], int scale, int16_t *out_host);
 /* test / debug read-back of the view's RGBA image (what IntegrateIntoScene will read). */
 int dslam_download_view_rgba(dslam_engine *e, const dslam_view *v, uint8_t *out_rgba);
 

@@ -653,6 +653,36 @@ extern "C" int oracle_view_update_bgr(oracle_engine *, oracle_view *v, const uin
   return view_finish(v, depth_mm, a, b, timestamp, use_bilateral);
 }
 
+// PrecomputedDepthProvider::ReadPrecomputed's per-pixel loop on the int16 image (PrecomputedDepthProvider.cpp:30-64)
+static int16_t wrap_i16(float f) { return (int16_t)(int32_t)f; }  // the x86 behaviour of the (undefined) overflow
+extern "C" int oracle_view_update_dataset(oracle_engine *e, oracle_view *v, const uint8_t *colour, int channels,
+                               const int16_t *raw, int format, float max_depth_m, float a, float b, double timestamp,
+                               int use_bilateral) {
+  if ((channels != 3 && channels != 4) || format < DSLAM_DEPTH_MM || format > DSLAM_DEPTH_RGBD_X5) return DSLAM_ERR_INVALID;
+  const size_t n = (size_t)v->w_d * v->h_d;
+  std::vector<int16_t> mm(raw, raw + n);
+  const float kitti_factor = 1000.0 / 256.0;
+  const float max_depth_mm_f = max_depth_m * 1000.0f;
+  const int16_t max_depth_mm_s = static_cast<int16_t>(round(max_depth_mm_f));
+  if (format == DSLAM_DEPTH_KITTI_X256) {
+    for (size_t i = 0; i < n; i++) {
+      if (mm[i] > max_depth_m * 256) mm[i] = 0;
+      mm[i] = wrap_i16((float)mm[i] * kitti_factor);
+    }
+  } else if (format == DSLAM_DEPTH_RGBD_X5) {
+    for (size_t i = 0; i < n; i++) {
+      mm[i] = static_cast<int16_t>(((float)mm[i]) / 5.0);
+      if (mm[i] > max_depth_mm_s) mm[i] = 0;
+    }
+  }
+  if (channels == 3) return oracle_view_update_bgr(e, v, colour, mm.data(), a, b, timestamp, use_bilateral);
+  return oracle_view_update(e, v, colour, mm.data(), a, b, timestamp, use_bilateral);
+}
+extern "C" int oracle_download_view_raw_depth(oracle_engine *, const oracle_view *v, int16_t *out) {
+  memcpy(out, v->raw_depth.data(), v->raw_depth.size() * 2);
+  return 0;
+}
+
 extern "C" int oracle_download_view_rgba(oracle_engine *, const oracle_view *v, uint8_t *out) {
   memcpy(out, v->rgba.data(), v->rgba.size());
   return 0;
@@ -1563,6 +1593,18 @@ extern "C" int oracle_get_image(oracle_engine *e, const oracle_scene *s, oracle_
   oracle_find_visible_blocks(e, s, r, M, intr);
   oracle_create_expected_depths(e, s, r, M, intr);
   return oracle_render_image(e, s, r, M, intr, type, out_rgba, out_float);
+}
+
+// GetImage(FREECAMERA_DEPTH) + FloatDepthmapToShort / FloatDepthmapToInt16 (InfiniTamDriver.cpp:167-200)
+extern "C" int oracle_get_image(oracle_engine *e, const oracle_scene *s, oracle_render_state *r, const float *M, const float *intr,
+                     int type, uint8_t *out_rgba, float *out_float);
+extern "C" int oracle_get_depth_image_int16(oracle_engine *e, const oracle_scene *s, oracle_render_state *r, const float *M,
+                                 const float *intr, int scale, int16_t *out) {
+  std::vector<float> d((size_t)r->w * r->h);
+  int rc = oracle_get_image(e, s, r, M, intr, DSLAM_IMAGE_DEPTH, nullptr, d.data());
+  if (rc) return rc;
+  for (size_t i = 0; i < d.size(); i++) out[i] = wrap_i16(d[i] * (float)scale);
+  return 0;
 }
 
 // trackingController->Prepare -> CreateICPMaps (InfiniTamDriver.h:208-220): processPixelICP<true,false>

@@ -126,3 +126,49 @@ def test_depth_post_processing_device_resident(gpu, oracle, synth):
     gpu.synchronize()
     assert gc == oc and np.array_equal(tc.cpu().numpy(), o)
     assert (o != curr).sum() > 0, "the case should blank something"
+
+
+@pytest.mark.parametrize("fmt,max_m", [(1, 40.0), (1, 20.0), (2, 10.0), (2, 4.0), (0, 0.0)])
+def test_dataset_depth_formats_bit_exact(gpu, oracle, synth, fmt, max_m):
+    """PrecomputedDepthProvider::ReadPrecomputed's loop (PrecomputedDepthProvider.cpp:30-64) on the device: raw 16-bit
+    dataset depth -> millimetres, incl. the values the reference's int16 casts wrap."""
+    wl = synth.s_street(320, 96)
+    rgba, _, _ = wl.frame(0)
+    rng = np.random.default_rng(fmt * 10 + int(max_m))
+    raw = rng.integers(-300, 32768, (wl.H, wl.W)).astype(np.int16)  # every positive int16 and a few negatives
+    raw[0, :8] = [0, 1, 255, 256, 5119, 5120, 10240, 10241]
+    out = {}
+    for name, api in (("gpu", gpu), ("oracle", oracle)):
+        v = api.create_view(wl.W, wl.H)
+        api.view_update_dataset(v, rgba, raw, fmt, max_m)
+        out[name] = (api.download_view_raw_depth(v), api.download_view_depth(v), api.download_view_rgba(v))
+        api.view_update_dataset(v, np.ascontiguousarray(rgba[..., 2::-1]), raw, fmt, max_m)  # BGR input, same depth
+        assert np.array_equal(api.download_view_raw_depth(v), out[name][0])
+    for a, b in zip(out["gpu"], out["oracle"]):
+        assert np.array_equal(a, b)
+    if fmt == 0:
+        assert np.array_equal(out["gpu"][0], raw)
+    if fmt == 2:
+        assert out["gpu"][0].max() <= max_m * 1000
+
+
+def test_depth_image_int16_output(pkg, synth, gpu, oracle):
+    """FloatDepthmapToShort (x1000) and FloatDepthmapToInt16 (x256, the raycast-depth PNGs): InfiniTamDriver.cpp:167-200."""
+    wl = synth.s_tiny()
+    p = util.small_params(pkg, wl)
+    res = {}
+    for name, api in (("gpu", gpu), ("oracle", oracle)):
+        s = api.create_scene(p)
+        rs, v = api.create_render_state(s, wl.W, wl.H), api.create_view(wl.W, wl.H)
+        for i in range(3):
+            rgba, mm, M = wl.frame(i)
+            api.view_update(v, rgba, mm, timestamp=float(i))
+            api.process_frame(s, v, rs, M, wl.intr)
+        free = api.create_render_state(s, wl.W, wl.H)
+        d = api.get_image(s, free, M, wl.intr, pkg.IMAGE_DEPTH)
+        res[name] = (d, api.get_depth_image_int16(s, free, M, wl.intr, 1000), api.get_depth_image_int16(s, free, M, wl.intr, 256))
+        for k, scale in ((1, 1000), (2, 256)):  # the int16 image is exactly the cast of the engine's own float image
+            assert np.array_equal(res[name][k], (d * np.float32(scale)).astype(np.int32).astype(np.int16))
+    assert np.abs(res["gpu"][0] - res["oracle"][0]).max() <= 1e-4
+    assert np.abs(res["gpu"][1].astype(int) - res["oracle"][1].astype(int)).max() <= 1  # 1 mm
+    assert (res["gpu"][2] > 0).sum() > 500
