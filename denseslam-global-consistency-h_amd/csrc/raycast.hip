@@ -31,13 +31,16 @@ __global__ __launch_bounds__(256) void k_frustum_flags(const HashEntry *__restri
                                                        int *__restrict__ tile_counts) {
   __shared__ int red[4];
   __shared__ TileVisScratch vis_scratch;
-  const int t0 = blockIdx.x * kTileEntries + threadIdx.x * 4;
+  // entry k of a lane is tile_base + k * 256 + lane: each of the four loads of a wavefront covers one contiguous KiB
+  // (only the tile's total is needed here, so the order in which lanes see entries is free)
+  const int tile_base = blockIdx.x * kTileEntries;
   bool cand[4] = {false, false, false, false};
   short4 pos[4];
-  if (t0 < n_entries) {
 #pragma unroll
-    for (int k = 0; k < 4; k++) {
-      const HashEntry e = load_entry(hash, t0 + k);
+  for (int k = 0; k < 4; k++) {
+    const int t = tile_base + k * 256 + threadIdx.x;
+    if (t < n_entries) {
+      const HashEntry e = load_entry(hash, t);
       cand[k] = e.ptr >= 0;
       pos[k] = make_short4(e.pos[0], e.pos[1], e.pos[2], 0);
     }
@@ -45,10 +48,10 @@ __global__ __launch_bounds__(256) void k_frustum_flags(const HashEntry *__restri
   unsigned char f[4];
   tile_block_vis<false>(vis_scratch, cand, pos, p.M, p.fx, p.fy, p.cx, p.cy, p.voxel_size, p.W, p.H, f);
   int c = 0;
-  if (t0 < n_entries) {
 #pragma unroll
-    for (int k = 0; k < 4; k++) { f[k] &= 1; c += f[k]; }
-    *reinterpret_cast<uchar4 *>(flags + t0) = make_uchar4(f[0], f[1], f[2], f[3]);
+  for (int k = 0; k < 4; k++) {
+    const int t = tile_base + k * 256 + threadIdx.x;
+    if (t < n_entries) { f[k] &= 1; c += f[k]; flags[t] = f[k]; }
   }
   int tot;
   block_excl_scan<4>(c, red, tot);
