@@ -251,9 +251,18 @@ constexpr int kRangeSlices = 32;  // workgroups per tile; each strides over the 
 __global__ __launch_bounds__(256) void k_fill_range_tiles(const RenderCounters *rc, const int4 *__restrict__ boxes,
                                                           const float2 *__restrict__ zr, const int *__restrict__ req,
                                                           float2 *range, int W, int tiles_x,
-                                                          const int *__restrict__ wg_tiles, int n_wg_tiles, int budget) {
+                                                          const int *__restrict__ wg_tiles, int n_wg_tiles, int budget,
+                                                          int capacity) {
   __shared__ int s_min[kRangeTile * kRangeTile], s_max[kRangeTile * kRangeTile];
   __shared__ int red[4];
+  // The visible count, the per-workgroup tile totals and this lane's first list entry are all fetched before anything
+  // waits: four dependent round trips become one (the entry is read speculatively -- the index is inside the
+  // buffers whatever the count turns out to be).
+  const int i0 = blockIdx.y * 256 + threadIdx.x;
+  int r0 = 0;
+  int4 b0 = make_int4(0, 0, 0, 0);
+  float2 z0 = make_float2(0.0f, 0.0f);
+  if (i0 < capacity) { r0 = req[i0]; b0 = boxes[i0]; z0 = zr[i0]; }
   const int n = rc->no_visible;
   // The render-tile budget (MAX_RENDERING_BLOCKS) is applied in visible-list order; only when the total (the sum of
   // the projection pass' per-workgroup counts) exceeds it does the order matter.  That case (> 262144 tiles) is
@@ -265,12 +274,10 @@ __global__ __launch_bounds__(256) void k_fill_range_tiles(const RenderCounters *
   s_min[threadIdx.x] = far_i;
   s_max[threadIdx.x] = close_i;
   __syncthreads();
-  auto splat = [&](int i) {
-    const int4 b = boxes[i];
+  auto splat_box = [&](const int4 &b, const float2 &z) {
     const int x0 = b.x > tx0 ? b.x : tx0, x1 = b.z < tx0 + kRangeTile - 1 ? b.z : tx0 + kRangeTile - 1;
     const int y0 = b.y > ty0 ? b.y : ty0, y1 = b.w < ty0 + kRangeTile - 1 ? b.w : ty0 + kRangeTile - 1;
     if (x0 > x1 || y0 > y1) return;
-    const float2 z = zr[i];
     const int zmin_i = __float_as_int(z.x), zmax_i = __float_as_int(z.y);
     for (int y = y0; y <= y1; y++)
       for (int x = x0; x <= x1; x++) {
@@ -279,8 +286,10 @@ __global__ __launch_bounds__(256) void k_fill_range_tiles(const RenderCounters *
         atomicMax(&s_max[c], zmax_i);
       }
   };
+  auto splat = [&](int i) { splat_box(boxes[i], zr[i]); };
   if (!over_budget) {
-    for (int i = blockIdx.y * 256 + threadIdx.x; i < n; i += gridDim.y * 256)
+    if (i0 < n && r0 != 0) splat_box(b0, z0);
+    for (int i = i0 + gridDim.y * 256; i < n; i += gridDim.y * 256)
       if (req[i] != 0) splat(i);
   } else {
     // sequential rule of the reference's tile list: entry i is dropped when the tiles accepted so far plus its own
@@ -335,10 +344,9 @@ static int launch_fill_range(dslam_engine *e, dslam_render_state *r, int n_wg_ti
   // corner = the tiles covering ceil(W/8) x ceil(H/8) cells (clamped to the image); chunks sized for the pool
   const int cw = (r->w + 7) / 8, ch = (r->h + 7) / 8;
   const int tiles_x = (cw + kRangeTile - 1) / kRangeTile, tiles_y = (ch + kRangeTile - 1) / kRangeTile;
-  static const int slices = getenv("DSLAM_DBG_SLICES") ? atoi(getenv("DSLAM_DBG_SLICES")) : kRangeSlices;
-  hipLaunchKernelGGL(k_fill_range_tiles, dim3(tiles_x * tiles_y, slices), dim3(256), 0, e->stream, r->counters,
+  hipLaunchKernelGGL(k_fill_range_tiles, dim3(tiles_x * tiles_y, kRangeSlices), dim3(256), 0, e->stream, r->counters,
                      r->proj_boxes, r->proj_z, r->proj_req, r->range, r->w, tiles_x, r->proj_wg_tiles, n_wg_tiles,
-                     e->render_tile_budget);
+                     e->render_tile_budget, r->n_local);
   DSLAM_HIP(hipGetLastError());
   return DSLAM_OK;
 }
