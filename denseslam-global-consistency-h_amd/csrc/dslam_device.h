@@ -280,6 +280,22 @@ __device__ __forceinline__ int block_sum_strided(const int *__restrict__ v, int 
   return tot;
 }
 
+// The same sums in two halves, so that the loads can be issued before an unrelated dependent chain (a scan with
+// barriers) and reduced after it: partial_* only loads and adds per thread, reduce_* needs the whole workgroup.
+__device__ __forceinline__ int partial_sum_strided(const int *__restrict__ v, int n, int stride) {
+  int s = 0;
+  for (int i = threadIdx.x; i < n; i += 256) s += v[i * stride];
+  return s;
+}
+__device__ __forceinline__ int reduce_sum(int s, int *lds4) {
+  for (int d = 32; d > 0; d >>= 1) s += __shfl_xor(s, d, 64);
+  if ((threadIdx.x & 63) == 0) lds4[threadIdx.x >> 6] = s;
+  __syncthreads();
+  const int tot = lds4[0] + lds4[1] + lds4[2] + lds4[3];
+  __syncthreads();
+  return tot;
+}
+
 // both the sum over [0, n_prefix) and over [0, n_total) of a strided int array (n_prefix <= n_total), one pass
 __device__ __forceinline__ void block_prefix_and_total(const int *__restrict__ v, int n_prefix, int n_total, int stride,
                                                        int *lds8, int &prefix, int &total) {

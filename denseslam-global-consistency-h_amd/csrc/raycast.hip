@@ -204,6 +204,8 @@ __global__ __launch_bounds__(256) void k_compact_project(const unsigned char *__
     f[0] = v.x; f[1] = v.y; f[2] = v.z; f[3] = v.w;
   }
   const int c = (f[0] > 0) + (f[1] > 0) + (f[2] > 0) + (f[3] > 0);
+  // (the loads of the preceding tiles' counts are in flight while the scan runs its barriers)
+  const int offset_part = partial_sum_strided(tile_counts, blockIdx.x, 1);
   int tot;
   int r = block_excl_scan<4>(c, red, tot);
   const bool last = blockIdx.x == gridDim.x - 1;
@@ -212,7 +214,7 @@ __global__ __launch_bounds__(256) void k_compact_project(const unsigned char *__
     return;
   }
   {
-    const int offset = block_sum_strided(tile_counts, blockIdx.x, 1, red);
+    const int offset = reduce_sum(offset_part, red);
     if (last && threadIdx.x == 0) rc->no_visible = (offset + tot) < capacity ? (offset + tot) : capacity;
 #pragma unroll
     for (int k = 0; k < 4; k++)
