@@ -124,7 +124,7 @@ struct dslam_view {
   uchar4 *rgba = nullptr;       // own buffers (host uploads land here)
   float *depth = nullptr;
   short *raw_depth = nullptr;
-  float *pyramid = nullptr;     // depth tracker: levels 1.. of the depth pyramid, allocated on first use
+  mutable float *pyramid = nullptr;  // depth tracker: levels 1.. of the depth pyramid (scratch, allocated on first use)
   // what the kernels read: own buffers, or the caller's resident frame (dslam_view_update_device: no copy)
   const uchar4 *rgba_src = nullptr;
   const short *raw_src = nullptr;

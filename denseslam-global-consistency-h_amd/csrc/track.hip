@@ -187,8 +187,7 @@ int launch_track_camera(dslam_engine *e, const dslam_view *v, dslam_render_state
   int rc = ensure_view_depth(e, v);
   if (rc) return rc;
   // depth pyramid (levels 1.. live in one buffer of the view) and the partial-sum buffers
-  dslam_view *vm = const_cast<dslam_view *>(v);
-  if (!vm->pyramid) DSLAM_HIP(hipMalloc(&vm->pyramid, (size_t)v->w_d * v->h_d * sizeof(float)));  // sum of levels 1.. < 1/3
+  if (!v->pyramid) DSLAM_HIP(hipMalloc(&v->pyramid, (size_t)v->w_d * v->h_d * sizeof(float)));  // sum of levels 1.. < 1/3
   if (!e->icp_partials) {
     DSLAM_HIP(hipMalloc(&e->icp_partials, (size_t)kIcpGrid * kIcpSums * sizeof(double)));
     DSLAM_HIP(hipHostMalloc((void **)&e->icp_partials_host, (size_t)kIcpGrid * kIcpSums * sizeof(double), hipHostMallocDefault));
@@ -198,7 +197,7 @@ int launch_track_camera(dslam_engine *e, const dslam_view *v, dslam_render_state
   float lintr[DSLAM_TRACKER_MAX_LEVELS][4];
   ldepth[0] = v->depth; lw[0] = v->w_d; lh[0] = v->h_d;
   for (int k = 0; k < 4; k++) lintr[0][k] = intr[k];
-  float *next = vm->pyramid;
+  float *next = v->pyramid;
   for (int i = 1; i < levels; i++) {
     lw[i] = lw[i - 1] / 2; lh[i] = lh[i - 1] / 2;
     DSLAM_REQUIRE(lw[i] > 0 && lh[i] > 0, "too many hierarchy levels for this image size");
