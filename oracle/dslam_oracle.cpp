@@ -183,6 +183,14 @@ struct oracle_view {
   double timestamp;
 };
 
+// The visible list has room for num_local_blocks entries (visibleEntryIDs is sized SDF_LOCAL_BLOCK_NUM upstream).
+// With swapping, entries parked on the host are visible too, so on a tiny pool the list can fill up: entries past
+// the capacity are dropped, in ascending entry order -- the same clipping the HIP engine's compaction applies.
+static inline void push_visible(oracle_render_state *r, int &n, int t) {
+  if (n < r->n_local) r->visible_ids[n] = t;
+  n++;
+}
+
 namespace {
 
 // ------------------------------------------------------------------------------------------------
@@ -441,8 +449,8 @@ static void remove_entries(oracle_scene *s, oracle_render_state *r, const std::v
   for (int x : freed) s->excess_list[++s->last_free_ex] = x;
   if (r) {
     int n = 0;
-    for (int t = 0; t < r->n_entries; t++) if (r->visible_type[t] > 0) r->visible_ids[n++] = t;
-    r->no_visible = n;
+    for (int t = 0; t < r->n_entries; t++) if (r->visible_type[t] > 0) push_visible(r, n, t);
+    r->no_visible = std::min(n, r->n_local);
   }
 }
 
@@ -911,9 +919,9 @@ extern "C" int oracle_allocate_scene_from_depth(oracle_engine *, oracle_scene *s
       r->visible_type[t] = vt;
     }
     if (use_swapping) { if (vt > 0 && s->swap_state[t] != 2) s->swap_state[t] = 1; }
-    if (vt > 0) r->visible_ids[n++] = t;
+    if (vt > 0) push_visible(r, n, t);
   }
-  r->no_visible = n;
+  r->no_visible = std::min(n, r->n_local);
 
   // REALLOC swapped-out blocks that came back into view
   if (use_swapping) {
@@ -1246,8 +1254,8 @@ static void slide_pop(oracle_scene *s, oracle_render_state *r, int q) {
   }
   if (r && !rem.empty()) {
     int n = 0;
-    for (int t = 0; t < r->n_entries; t++) if (r->visible_type[t] > 0) r->visible_ids[n++] = t;
-    r->no_visible = n;
+    for (int t = 0; t < r->n_entries; t++) if (r->visible_type[t] > 0) push_visible(r, n, t);
+    r->no_visible = std::min(n, r->n_local);
   }
 }
 
@@ -1353,9 +1361,9 @@ extern "C" int oracle_find_visible_blocks(oracle_engine *, const oracle_scene *s
     const dslam_hash_entry &e = s->hash[t];
     bool vis = false, vis_enl = false;
     if (e.ptr >= 0) check_block_vis(vis, vis_enl, e.pos, M, intr, s->p.voxel_size, r->w, r->h, false);
-    if (vis) r->visible_ids[n++] = t;
+    if (vis) push_visible(r, n, t);
   }
-  r->no_visible = n;
+  r->no_visible = std::min(n, r->n_local);
   return 0;
 }
 

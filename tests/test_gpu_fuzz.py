@@ -1,0 +1,113 @@
+"""Seeded random sequences of engine calls, HIP engine vs CPU oracle, compared byte for byte after every few calls.
+Each trial draws its own scene parameters (voxel size, truncation band, weight cap, pool sizes small enough to run
+out, history depth), camera jitter, depth noise and holes, and a random interleaving of ProcessFrame, DeProcessFrame
++ re-fusion, Decay (both modes), SlideWindow, the defusion-ring calls, AllocateSceneFromDepth alone, and raycasts
+from free poses.  It exists to catch divergences that the scripted scenarios do not reach."""
+import numpy as np
+import pytest
+
+import util
+
+pytestmark = pytest.mark.gpu
+
+
+def _trial(pkg, synth, gpu, oracle, seed):
+    rng = np.random.default_rng(seed)
+    W, H = int(rng.choice([48, 64, 80])), int(rng.choice([36, 48]))
+    wl = synth.s_room(W, H, scale=float(rng.choice([3.0, 4.0, 6.0])))
+    kw = dict(wl.scene_kwargs)
+    vs = kw["voxel_size"]
+    kw["mu"] = float(vs * rng.choice([2.0, 4.0, 5.0]))
+    kw["max_w"] = int(rng.choice([3, 20, 100]))
+    kw["stop_integrating_at_max_w"] = int(rng.integers(0, 2))
+    kw["num_local_blocks"] = int(rng.choice([0x400, 0x800, 0x2000]))
+    kw["num_buckets"] = int(rng.choice([0x200, 0x1000, 0x4000]))
+    kw["num_excess"] = int(rng.choice([0x100, 0x800]))
+    kw["history_words"] = int(rng.choice([1, 2, 4]))
+    kw["use_swapping"] = int(rng.random() < 0.25)
+    p = pkg.SceneParams(**kw)
+    objs = {}
+    for name, api in (("gpu", gpu), ("oracle", oracle)):
+        s = api.create_scene(p)
+        objs[name] = (api, s, api.create_render_state(s, W, H), api.create_view(W, H), api.create_render_state(s, W, H))
+    if rng.random() < 0.3:
+        max_new_w = int(rng.integers(2, 6))
+        for api, *_ in objs.values():
+            api.set_fusion_weight_params(depth_weighting=True, max_new_w=max_new_w, max_distance=3.0)
+    log = []
+    try:
+        fused = []
+        for step in range(int(rng.integers(10, 26))):
+            op = rng.choice(["fuse", "fuse", "fuse", "refuse", "decay", "slide", "alloc_only", "raycast", "defusion_ring", "flush"])
+            i = int(rng.integers(0, 12))
+            rgba, mm, M = wl.frame(i)
+            jitter = synth.pose_matrix(synth.look_rotation(rng.normal(0, 0.01), rng.normal(0, 0.01)), rng.normal(0, 0.01, 3))
+            M = (np.asarray(M, np.float64) @ jitter).astype(np.float32)
+            mm = mm.astype(np.int32) + rng.integers(-3, 4, mm.shape)
+            mm[rng.random(mm.shape) < 0.03] = 0
+            mm = np.clip(mm, 0, 32000).astype(np.int16)
+            args = ()
+            if op == "decay":
+                args = (int(rng.integers(1, 6)), int(rng.integers(0, 4)), bool(rng.integers(0, 2)))
+            elif op == "slide":
+                args = (int(rng.integers(1, 5)),)
+            elif op == "defusion_ring":
+                args = (int(rng.integers(1, 5)), int(rng.integers(1, 4)))
+            elif op == "raycast":
+                args = (int(rng.choice([pkg.IMAGE_DEPTH, pkg.IMAGE_SHADED, pkg.IMAGE_COLOUR_FROM_VOLUME, pkg.IMAGE_COLOUR_FROM_NORMAL])),)
+            elif op == "alloc_only":
+                args = (bool(rng.integers(0, 2)),)
+            log.append((op, i, args))
+            imgs = {}
+            for name, (api, s, rs, v, free) in objs.items():
+                if op == "fuse":
+                    api.view_update(v, rgba, mm, timestamp=float(step))
+                    api.process_frame(s, v, rs, M, wl.intr)
+                elif op == "refuse" and fused:
+                    rgba_o, mm_o, M_o = fused[-1]
+                    api.view_update(v, rgba_o, mm_o, timestamp=float(step))
+                    api.deprocess_frame(s, v, rs, M_o, wl.intr)
+                    api.process_frame(s, v, rs, M, wl.intr, is_defusion=True)
+                elif op == "decay":
+                    api.decay(s, rs, *args)
+                elif op == "slide":
+                    if api.stats(s, rs)["fusion_fifo_len"] > args[0]:
+                        api.slide_window(s, rs, args[0])
+                elif op == "defusion_ring":
+                    api.slide_window_defusion_part(s, rs, args[0], args[1])
+                    api.decay(s, rs, 2, 1, True, defusion_part=True)
+                elif op == "alloc_only":
+                    api.view_update(v, rgba, mm, timestamp=float(step))
+                    api.allocate_scene_from_depth(s, v, rs, M, wl.intr, only_update_visible_list=args[0])
+                elif op == "raycast":
+                    imgs[name] = api.get_image(s, free, M, wl.intr, args[0])
+                elif op == "flush" and p.use_swapping:
+                    api.save_to_global_memory(s)
+            if op == "fuse":
+                fused.append((rgba, mm, M))
+            if op == "raycast":
+                if args[0] == pkg.IMAGE_DEPTH:
+                    assert np.abs(imgs["gpu"] - imgs["oracle"]).max() <= 1e-4, f"seed {seed} step {step}: depth image"
+                else:
+                    assert np.abs(imgs["gpu"].astype(int) - imgs["oracle"].astype(int)).max() <= 1, f"seed {seed} step {step}: image"
+            snaps = {name: util.snapshot(api, s, rs) for name, (api, s, rs, v, free) in objs.items()}
+            util.assert_same_state(snaps["gpu"], snaps["oracle"], f"seed {seed} step {step} after {log[-1]}")
+            if p.use_swapping:
+                sw = [api.download_swap_states(s) for api, s, *_ in objs.values()]
+                assert np.array_equal(sw[0], sw[1]), f"seed {seed} step {step} after {log[-1]}: swap states"
+        util.check_invariants(snaps["gpu"], objs["gpu"][1].params)
+    finally:
+        for api, *_ in objs.values():
+            api.set_fusion_weight_params()
+    return log
+
+
+import os
+
+# DSLAM_FUZZ_SEEDS="first:count" widens the hunt (e.g. 5000:500); the default 60 trials take a few seconds
+_FIRST, _COUNT = (int(x) for x in os.environ.get("DSLAM_FUZZ_SEEDS", "1000:60").split(":"))
+
+
+@pytest.mark.parametrize("seed", range(_FIRST, _FIRST + _COUNT))
+def test_random_call_sequences(pkg, synth, gpu, oracle, seed):
+    _trial(pkg, synth, gpu, oracle, seed)
