@@ -57,11 +57,16 @@ def _trial(pkg, synth, gpu, oracle, seed):
                 args = (int(rng.choice([pkg.IMAGE_DEPTH, pkg.IMAGE_SHADED, pkg.IMAGE_COLOUR_FROM_VOLUME, pkg.IMAGE_COLOUR_FROM_NORMAL])),)
             elif op == "alloc_only":
                 args = (bool(rng.integers(0, 2)),)
+            elif op == "fuse":
+                args = (bool(rng.random() < 0.2), bool(rng.random() < 0.2))  # bilateral filter, BGR input
             log.append((op, i, args))
             imgs = {}
             for name, (api, s, rs, v, free) in objs.items():
                 if op == "fuse":
-                    api.view_update(v, rgba, mm, timestamp=float(step))
+                    if args[1]:
+                        api.view_update_bgr(v, np.ascontiguousarray(rgba[..., 2::-1]), mm, timestamp=float(step), bilateral=args[0])
+                    else:
+                        api.view_update(v, rgba, mm, timestamp=float(step), bilateral=args[0])
                     api.process_frame(s, v, rs, M, wl.intr)
                 elif op == "refuse" and fused:
                     rgba_o, mm_o, M_o = fused[-1]
@@ -83,8 +88,10 @@ def _trial(pkg, synth, gpu, oracle, seed):
                     imgs[name] = api.get_image(s, free, M, wl.intr, args[0])
                 elif op == "flush" and p.use_swapping:
                     api.save_to_global_memory(s)
-            if op == "fuse":
-                fused.append((rgba, mm, M))
+            if op == "fuse" and not args[0]:
+                rgba_n = rgba.copy()
+                rgba_n[..., 3] = 255 if args[1] else rgba[..., 3]
+                fused.append((rgba_n, mm, M))
             if op == "raycast":
                 if args[0] == pkg.IMAGE_DEPTH:
                     assert np.abs(imgs["gpu"] - imgs["oracle"]).max() <= 1e-4, f"seed {seed} step {step}: depth image"
