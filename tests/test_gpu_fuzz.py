@@ -3,6 +3,8 @@ Each trial draws its own scene parameters (voxel size, truncation band, weight c
 out, history depth), camera jitter, depth noise and holes, and a random interleaving of ProcessFrame, DeProcessFrame
 + re-fusion, Decay (both modes), SlideWindow, the defusion-ring calls, AllocateSceneFromDepth alone, and raycasts
 from free poses.  It exists to catch divergences that the scripted scenarios do not reach."""
+import os
+
 import numpy as np
 import pytest
 
@@ -13,16 +15,17 @@ pytestmark = pytest.mark.gpu
 
 def _trial(pkg, synth, gpu, oracle, seed):
     rng = np.random.default_rng(seed)
-    W, H = int(rng.choice([48, 64, 80])), int(rng.choice([36, 48]))
+    big = os.environ.get("DSLAM_FUZZ_BIG") == "1"  # one-off hunts: larger images, pools and longer sequences
+    W, H = (int(rng.choice([160, 200])), int(rng.choice([120, 96]))) if big else (int(rng.choice([48, 64, 80])), int(rng.choice([36, 48])))
     wl = synth.s_room(W, H, scale=float(rng.choice([3.0, 4.0, 6.0])))
     kw = dict(wl.scene_kwargs)
     vs = kw["voxel_size"]
     kw["mu"] = float(vs * rng.choice([2.0, 4.0, 5.0]))
     kw["max_w"] = int(rng.choice([3, 20, 100]))
     kw["stop_integrating_at_max_w"] = int(rng.integers(0, 2))
-    kw["num_local_blocks"] = int(rng.choice([0x400, 0x800, 0x2000]))
-    kw["num_buckets"] = int(rng.choice([0x200, 0x1000, 0x4000]))
-    kw["num_excess"] = int(rng.choice([0x100, 0x800]))
+    kw["num_local_blocks"] = int(rng.choice([0x2000, 0x8000] if big else [0x400, 0x800, 0x2000]))
+    kw["num_buckets"] = int(rng.choice([0x1000, 0x10000] if big else [0x200, 0x1000, 0x4000]))
+    kw["num_excess"] = int(rng.choice([0x800, 0x4000] if big else [0x100, 0x800]))
     kw["history_words"] = int(rng.choice([1, 2, 4]))
     kw["use_swapping"] = int(rng.random() < 0.25)
     p = pkg.SceneParams(**kw)
@@ -37,7 +40,7 @@ def _trial(pkg, synth, gpu, oracle, seed):
     log = []
     try:
         fused = []
-        for step in range(int(rng.integers(10, 26))):
+        for step in range(int(rng.integers(25, 45)) if big else int(rng.integers(10, 26))):
             op = rng.choice(["fuse", "fuse", "fuse", "refuse", "decay", "slide", "alloc_only", "raycast", "defusion_ring", "flush"])
             i = int(rng.integers(0, 12))
             rgba, mm, M = wl.frame(i)
@@ -108,8 +111,6 @@ def _trial(pkg, synth, gpu, oracle, seed):
             api.set_fusion_weight_params()
     return log
 
-
-import os
 
 # DSLAM_FUZZ_SEEDS="first:count" widens the hunt (e.g. 5000:500); the default 60 trials take a few seconds
 _FIRST, _COUNT = (int(x) for x in os.environ.get("DSLAM_FUZZ_SEEDS", "1000:60").split(":"))
