@@ -151,8 +151,7 @@ int dslam_engine_destroy(dslam_engine *e) {
   if (e->pinned) (void)hipHostFree(e->pinned);
   if (e->timer_counts_dev) (void)hipFree(e->timer_counts_dev);
   free_dev(e->misc_counter);
-  free_dev(e->icp_partials);
-  if (e->icp_partials_host) (void)hipHostFree(e->icp_partials_host);
+  if (e->icp_partials_host) (void)hipHostFree(e->icp_partials_host);  // (icp_partials is its device alias)
   for (auto ev : e->ev_pool) (void)hipEventDestroy(ev);
   (void)hipStreamDestroy(e->stream);
   delete e;

@@ -67,8 +67,8 @@ struct dslam_engine {
   int *timer_counts_dev = nullptr;    // visible-block count of each timed launch (written by the kernel)
   int sm_count = 256;
   int render_tile_budget = DSLAM_MAX_RENDERING_BLOCKS;  // MAX_RENDERING_BLOCKS; lowered only by the budget test
-  double *icp_partials = nullptr;       // depth tracker: per-workgroup partial sums (device) and their pinned mirror
-  double *icp_partials_host = nullptr;
+  double *icp_partials_host = nullptr;  // depth tracker: per-workgroup partial sums in mapped pinned host memory
+  double *icp_partials = nullptr;       // ... and the device address of the same buffer
   int *misc_counter = nullptr;        // device: small result counters of one-off kernels (depthPostProcessing)
 };
 

@@ -188,9 +188,11 @@ int launch_track_camera(dslam_engine *e, const dslam_view *v, dslam_render_state
   if (rc) return rc;
   // depth pyramid (levels 1.. live in one buffer of the view) and the partial-sum buffers
   if (!v->pyramid) DSLAM_HIP(hipMalloc(&v->pyramid, (size_t)v->w_d * v->h_d * sizeof(float)));  // sum of levels 1.. < 1/3
-  if (!e->icp_partials) {
-    DSLAM_HIP(hipMalloc(&e->icp_partials, (size_t)kIcpGrid * kIcpSums * sizeof(double)));
-    DSLAM_HIP(hipHostMalloc((void **)&e->icp_partials_host, (size_t)kIcpGrid * kIcpSums * sizeof(double), hipHostMallocDefault));
+  if (!e->icp_partials_host) {
+    // the workgroup partials (240 x 29 doubles) are written straight into mapped pinned host memory: one stream
+    // synchronise per iteration instead of a copy launch plus a synchronise
+    DSLAM_HIP(hipHostMalloc((void **)&e->icp_partials_host, (size_t)kIcpGrid * kIcpSums * sizeof(double), hipHostMallocMapped));
+    DSLAM_HIP(hipHostGetDevicePointer((void **)&e->icp_partials, e->icp_partials_host, 0));
   }
   const float *ldepth[DSLAM_TRACKER_MAX_LEVELS];
   int lw[DSLAM_TRACKER_MAX_LEVELS], lh[DSLAM_TRACKER_MAX_LEVELS];
@@ -245,7 +247,6 @@ int launch_track_camera(dslam_engine *e, const dslam_view *v, dslam_render_state
       else if (type == DSLAM_TRACKER_ITERATION_TRANSLATION) hipLaunchKernelGGL((k_icp_gh<2>), dim3(grid), dim3(256), 0, e->stream, ip);
       else hipLaunchKernelGGL((k_icp_gh<3>), dim3(grid), dim3(256), 0, e->stream, ip);
       DSLAM_HIP(hipGetLastError());
-      DSLAM_HIP(hipMemcpyAsync(e->icp_partials_host, e->icp_partials, (size_t)grid * kIcpSums * sizeof(double), hipMemcpyDeviceToHost, e->stream));
       DSLAM_HIP(hipStreamSynchronize(e->stream));
       double sums[kIcpSums];
       for (int i = 0; i < kIcpSums; i++) sums[i] = 0.0;
