@@ -50,3 +50,32 @@ def test_engine_creation_fails_loudly_without_gpu(pkg):
         pytest.skip("a GPU is present")
     with pytest.raises(pkg.DslamError):
         pkg.open_engine(0)
+
+
+def test_no_kernel_uses_scratch(pkg, tmp_path):
+    """Every gfx950 kernel must keep its working set in registers: private (scratch) memory costs the occupancy the
+    latency-bound kernels live on, and a scratch-using build once hung a rocprofv3 counter pass.  Compiles each
+    translation unit to assembly (device side only) and reads the code-object metadata."""
+    import concurrent.futures
+    import glob
+    import re
+    import shutil
+    import subprocess
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not available")
+    srcs = sorted(glob.glob(os.path.join(pkg.CSRC_DIR, "*.hip")))
+    assert len(srcs) >= 6
+
+    def scan(src):
+        out = tmp_path / (os.path.basename(src) + ".s")
+        subprocess.run([hipcc, "-O3", "--offload-arch=gfx950", "-ffp-contract=off", "-fno-fast-math", "-std=c++17", "-S",
+                        "--cuda-device-only", "-o", str(out), src], check=True, capture_output=True)
+        text = out.read_text()
+        return [(m.group(1), int(m.group(2))) for m in re.finditer(r"\.set (\S+)\.private_seg_size, (\d+)", text)]
+
+    with concurrent.futures.ThreadPoolExecutor(max_workers=4) as pool:
+        results = [kv for res in pool.map(scan, srcs) for kv in res]
+    assert len(results) >= 40, "kernel metadata not found"
+    offenders = [(k, v) for k, v in results if v != 0]
+    assert not offenders, f"kernels with scratch: {offenders}"
