@@ -93,12 +93,26 @@ def main():
     ap.add_argument("--sync", action="store_true", help="synchronous calls (reference driver behaviour) instead of pipelined")
     args = ap.parse_args()
 
-    import torch
-    import torch.distributed as dist
-
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+
+    pkg = ge.load_package()
+    from dslam_amd.harness import synth
+    wl = getattr(synth, args.workload)(args.width, args.height)
+    K, Wm = args.steps, args.warmup
+    nframes = K + Wm
+    # Synthetic frames first, while this process has not touched the GPU: the worker pool forks, and a forked child
+    # of a GPU-initialised process is not safe.  Under a profiler that initialises the GPU before the program starts
+    # (rocprofv3 --pmc preloads its tool library) there is no such moment, so no pool is used there.
+    preloaded = os.environ.get("LD_PRELOAD", "") + os.environ.get("ROCP_TOOL_LIBRARIES", "")
+    workers = 1 if "rocprof" in preloaded.lower() else max(1, min(16, (os.cpu_count() or 2) // max(1, world)))
+    frames = generate_frames(args.workload, args.width, args.height, nframes, workers)
+    rgba_h, depth_h, Ms = frames
+
+    import torch
+    import torch.distributed as dist
+
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: libdslam_fusion has no CPU path")
     torch.cuda.set_device(local_rank)
@@ -108,11 +122,6 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
-    pkg = ge.load_package()
-    from dslam_amd.harness import synth
-    wl = getattr(synth, args.workload)(args.width, args.height)
-    K, Wm = args.steps, args.warmup
-    nframes = K + Wm
     # pools sized so the un-windowed map of the whole run fits (the reference's default 0x40000-block pool fills
     # after ~320 KITTI keyframes, memory.txt:320); 288 GB of HBM make a 4 GiB pool a non-issue
     need_blocks = 9000 + 600 * nframes
@@ -121,9 +130,6 @@ def main():
         nlb *= 2
     params = pkg.SceneParams(num_local_blocks=nlb, **wl.scene_kwargs)
 
-    workers = max(1, min(16, (os.cpu_count() or 2) // max(1, world)))
-    frames = generate_frames(args.workload, args.width, args.height, nframes, workers)
-    rgba_h, depth_h, Ms = frames
     dev = torch.device("cuda", local_rank)
     rgba_d = torch.from_numpy(rgba_h).to(dev)
     depth_d = torch.from_numpy(depth_h).to(dev)

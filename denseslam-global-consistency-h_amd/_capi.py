@@ -167,6 +167,11 @@ class CApi:
     def set_async(self, flag):
         self._call("engine_set_async", self._engine, C.c_int(int(flag)))
 
+    def selftest_division(self, samples):
+        out = C.c_longlong(-1)
+        self._call("selftest_division", self._engine, C.c_longlong(samples), C.byref(out))
+        return out.value
+
     def debug_set_render_tile_budget(self, budget):
         self._call("debug_set_render_tile_budget", self._engine, C.c_int(budget))
 

@@ -158,6 +158,17 @@ int dslam_engine_destroy(dslam_engine *e) {
   return DSLAM_OK;
 }
 
+int dslam_selftest_division(dslam_engine *e, long long samples, long long *mismatches_out) {
+  DSLAM_REQUIRE(e && mismatches_out && samples > 0, "bad argument");
+  unsigned long long *dev = reinterpret_cast<unsigned long long *>(e->misc_counter + 4);  // 8-byte aligned slot
+  int rc = launch_selftest_division(e, samples, dev);
+  if (rc) return rc;
+  DSLAM_HIP(hipMemcpyAsync(e->pinned, dev, sizeof(unsigned long long), hipMemcpyDeviceToHost, e->stream));
+  DSLAM_HIP(hipStreamSynchronize(e->stream));
+  *mismatches_out = (long long)*reinterpret_cast<unsigned long long *>(e->pinned);
+  return DSLAM_OK;
+}
+
 int dslam_debug_set_render_tile_budget(dslam_engine *e, int budget) {
   DSLAM_REQUIRE(e && budget > 0, "bad argument");
   e->render_tile_budget = budget;

@@ -160,6 +160,7 @@ int launch_integrate(dslam_engine *e, dslam_scene *s, const dslam_view *v, const
                      const float *M_d, const float *intr_d, const float *M_rgb, const float *intr_rgb,
                      bool deintegrate, int push_ring = -1);
 int ensure_view_depth(dslam_engine *e, const dslam_view *v);
+int launch_selftest_division(dslam_engine *e, long long samples, unsigned long long *mismatches_dev);
 int prepare_push_visible_list(dslam_engine *e, dslam_scene *s, int q, int *bit_out, int *frame_out);
 int launch_find_visible(dslam_engine *e, const dslam_scene *s, dslam_render_state *r, const float *M,
                         const float *intr);

@@ -20,6 +20,10 @@
 
 #pragma clang fp contract(off)
 
+#ifndef DSLAM_PACKED
+#define DSLAM_PACKED 1
+#endif
+
 namespace dslam {
 
 struct IntegrateParams {
@@ -57,6 +61,65 @@ __device__ __forceinline__ float div_exact(float a, float b, float y) {
   const float q = a * y;
   const float r = __fmaf_rn(-b, q, a);
   return __fmaf_rn(r, y, q);
+}
+
+// IEEE division without the scaling / fix-up instructions, two quotients at a time.  hipcc expands a float division
+// into  d' = div_scale(b), n' = div_scale(a), r = rcp(d'), two FMAs refining r, q = n' r, two residual corrections,
+// div_fmas, div_fixup  (10 VALU instructions).  div_scale / div_fmas / div_fixup only act when an exponent is near
+// the ends of the float range or an operand is 0, inf or NaN; for the operands of this kernel (depths of 0.1-100 m,
+// image coordinates, eta / mu) they pass their inputs through, so the remaining arithmetic -- the same instructions,
+// in the same order, with the same roundings -- gives the same bits.  Written on 2-vectors it compiles to v_rcp_f32
+// x 2 + 7 packed instructions for TWO quotients: 9 instead of 20.  dslam_selftest_division() compares it with the
+// native division over random operands of these ranges on the device (tests/test_gpu_parity.py).
+typedef float __attribute__((ext_vector_type(2))) f2;
+
+__device__ __forceinline__ f2 div_ieee2(f2 a, f2 b) {
+  f2 r;
+  r.x = __builtin_amdgcn_rcpf(b.x);
+  r.y = __builtin_amdgcn_rcpf(b.y);
+  const f2 nb = -b;
+  const f2 one = {1.0f, 1.0f};
+  const f2 e = __builtin_elementwise_fma(nb, r, one);
+  r = __builtin_elementwise_fma(e, r, r);
+  f2 q = a * r;
+  f2 t = __builtin_elementwise_fma(nb, q, a);
+  q = __builtin_elementwise_fma(t, r, q);
+  t = __builtin_elementwise_fma(nb, q, a);
+  return __builtin_elementwise_fma(t, r, q);
+}
+
+// random operands in the kernel's ranges: projection (|a| in 2^[-20,24], b in 2^[-10,10]) and eta / mu
+// (|a| in 2^[-30,8], b in [2^-10, 1])
+__global__ __launch_bounds__(256) void k_selftest_division(unsigned long long seed, int per_thread, unsigned long long *mismatches) {
+  unsigned long long x = seed + 0x9E3779B97F4A7C15ull * (blockIdx.x * 256ull + threadIdx.x + 1);
+  auto next = [&]() { x ^= x << 13; x ^= x >> 7; x ^= x << 17; return (unsigned)(x >> 16); };
+  auto make = [&](int e_lo, int e_hi, bool may_be_negative) {
+    const unsigned r = next();
+    const unsigned mant = r & 0x7fffffu;
+    const unsigned ex = (unsigned)(127 + e_lo + (int)((r >> 23) % (unsigned)(e_hi - e_lo + 1)));
+    const unsigned sign = may_be_negative ? (next() & 1u) << 31 : 0u;
+    return __uint_as_float(sign | (ex << 23) | mant);
+  };
+  unsigned bad = 0;
+  for (int i = 0; i < per_thread; i++) {
+    f2 a, b;
+    a.x = make(-20, 24, true); b.x = make(-10, 10, false);
+    a.y = make(-30, 8, true);  b.y = make(-10, 0, false);
+    const f2 q = div_ieee2(a, b);
+    const float n0 = a.x / b.x, n1 = a.y / b.y;
+    bad += (__float_as_uint(q.x) != __float_as_uint(n0)) + (__float_as_uint(q.y) != __float_as_uint(n1));
+  }
+  if (bad) atomicAdd(mismatches, (unsigned long long)bad);
+}
+
+int launch_selftest_division(dslam_engine *e, long long samples, unsigned long long *mismatches_dev) {
+  const int per_thread = 4096;
+  const long long threads = (samples / 2 + per_thread - 1) / per_thread;
+  const int blocks = (int)std::max(1LL, (threads + 255) / 256);
+  DSLAM_HIP(hipMemsetAsync(mismatches_dev, 0, sizeof(unsigned long long), e->stream));
+  hipLaunchKernelGGL(k_selftest_division, dim3(blocks), dim3(256), 0, e->stream, 0x243F6A8885A308D3ull, per_thread, mismatches_dev);
+  DSLAM_HIP(hipGetLastError());
+  return DSLAM_OK;
 }
 
 constexpr int kInvTab = 512;  // reciprocals of the integer weights 1..511 (w_depth <= 255, newW <= 255)
@@ -177,6 +240,117 @@ __device__ __forceinline__ bool update_voxel(unsigned &lo, unsigned &hi, const V
   return changed;
 }
 
+// ---- two voxels at a time (fusion only) --------------------------------------------------------------------------
+// SQ counters on MI355X: the kernel issues ~1060 VALU instructions per block-wave, i.e. 14 us of VALU issue per SIMD
+// in a 24 us launch at V = 7.9k and ~90 % of the S-stress launch: it is bound by arithmetic, not by HBM.  The two
+// voxels of a 16-byte chunk (x and x+1) run the same arithmetic on different data, and gfx950 has packed FP32
+// (v_pk_fma/mul/add_f32: two lanes' worth per instruction), so the depth update is written on 2-vectors: one
+// instruction stream for both voxels, every operation the same IEEE operation in the same order as the scalar code
+// -- bit-identical results -- and the three divisions per voxel share 9-instruction packed sequences (div_ieee2).
+// Per-voxel conditions become masks; the rare colour update and the de-integration keep the scalar path.
+__device__ __forceinline__ f2 div_exact2(f2 a, float b, f2 y) {
+  const f2 q = a * y;
+  const f2 nb = {-b, -b};
+  const f2 r = __builtin_elementwise_fma(nb, q, a);
+  return __builtin_elementwise_fma(r, y, q);
+}
+
+// computeUpdatedVoxelColorInfo for one voxel (fusion); u, w = its projection into the colour image
+template <bool SAME_CAM>
+__device__ __forceinline__ bool fuse_colour(unsigned &lo, unsigned &hi, float u, float w, const Vec4 &pm,
+                                            const IntegrateParams &p, const float *inv_tab) {
+  if (!SAME_CAM) {
+    const Vec4 pcr = mul(p.M_rgb, pm);
+    u = p.fx_r * pcr.x / pcr.z + p.cx_r;
+    w = p.fy_r * pcr.y / pcr.z + p.cy_r;
+    if ((u < 1) || (u > p.Wr - 2) || (w < 1) || (w > p.Hr - 2)) return false;
+  }
+  float m[3];
+  bilinear_rgb(p.rgba, u, w, p.Wr, m);
+  const unsigned oc[3] = {lo >> 24, hi & 0xffu, (hi >> 8) & 0xffu};
+  const unsigned wc = (hi >> 16) & 0xffu;
+  const float oldW = (float)wc;
+  unsigned nc[3];
+  float newW = oldW + 1.0f;
+  const float inv_new = inv_tab[wc + 1];
+#pragma unroll
+  for (int k = 0; k < 3; k++) {
+    const float oldC = div_exact((float)oc[k], 255.0f, p.inv_255);
+    const float c = div_exact(m[k], 255.0f, p.inv_255);
+    const float v = div_exact(oldC * oldW + c * 1.0f, newW, inv_new);
+    nc[k] = (unsigned)(unsigned char)(v * 255.0f);
+  }
+  newW = fminf(newW, (float)p.max_w);
+  const unsigned new_wc = (unsigned)(unsigned char)newW;
+  lo = (lo & 0x00ffffffu) | (nc[0] << 24);
+  hi = (hi & 0xff000000u) | nc[1] | (nc[2] << 8) | (new_wc << 16);
+  return true;
+}
+
+// ComputeUpdatedVoxelInfo<hasColor>::compute for the two voxels of one chunk: (vv.x, vv.y) at x, (vv.z, vv.w) at x + 1
+template <bool SAME_CAM>
+__device__ __forceinline__ bool fuse_pair(uint4 &vv, f2 pcx, f2 pcy, f2 pcz, const Vec4 &pm0, const Vec4 &pm1,
+                                          const IntegrateParams &p, const float *inv_tab) {
+  bool act0 = pcz.x > 0.0f, act1 = pcz.y > 0.0f;
+  if (p.stop_max) {
+    act0 = act0 && (int)((vv.x >> 16) & 0xffu) != p.max_w;
+    act1 = act1 && (int)((vv.z >> 16) & 0xffu) != p.max_w;
+  }
+  if (!(act0 || act1)) return false;
+  const f2 fx2 = {p.fx_d, p.fx_d}, fy2 = {p.fy_d, p.fy_d}, cx2 = {p.cx_d, p.cx_d}, cy2 = {p.cy_d, p.cy_d};
+  const f2 u = div_ieee2(fx2 * pcx, pcz) + cx2;  // projParams.x * pt.x / pt.z + projParams.z
+  const f2 w = div_ieee2(fy2 * pcy, pcz) + cy2;
+  const float wmax = (float)(p.Wd - 2), hmax = (float)(p.Hd - 2);
+  act0 = act0 && !((u.x < 1) || (u.x > wmax) || (w.x < 1) || (w.x > hmax));
+  act1 = act1 && !((u.y < 1) || (u.y > wmax) || (w.y < 1) || (w.y > hmax));
+  if (!(act0 || act1)) return false;
+  const f2 half = {0.5f, 0.5f};
+  const f2 ur = u + half, wr = w + half;
+  const int i0 = act0 ? (int)ur.x + (int)wr.x * p.Wd : 0, i1 = act1 ? (int)ur.y + (int)wr.y * p.Wd : 0;
+  f2 dm;
+  dm.x = p.depth[i0];
+  dm.y = p.depth[i1];
+  const f2 eta = dm - pcz;
+  act0 = act0 && !(dm.x <= 0.0f) && !(eta.x < -p.mu);
+  act1 = act1 && !(dm.y <= 0.0f) && !(eta.y < -p.mu);
+  if (!(act0 || act1)) return false;
+  const f2 mu2 = {p.mu, p.mu};
+  const f2 eta_mu = div_ieee2(eta, mu2);  // true IEEE division (the 3-instruction form is not exact for arbitrary mu)
+  f2 sd;
+  sd.x = (float)(short)(vv.x & 0xffffu);
+  sd.y = (float)(short)(vv.z & 0xffffu);
+  const f2 inv32767 = {p.inv_32767, p.inv_32767};
+  const f2 oldF = div_exact2(sd, 32767.0f, inv32767);
+  const int oldW0 = (int)((vv.x >> 16) & 0xffu), oldW1 = (int)((vv.z >> 16) & 0xffu);
+  f2 newF;
+  newF.x = fminf(1.0f, eta_mu.x);
+  newF.y = fminf(1.0f, eta_mu.y);
+  const int addW0 = new_weight(p, dm.x), addW1 = new_weight(p, dm.y);
+  f2 oW, aW;
+  oW.x = (float)oldW0; oW.y = (float)oldW1;
+  aW.x = (float)addW0; aW.y = (float)addW1;
+  f2 nf = oW * oldF + aW * newF;  // oldW * oldF + newW * newF: two products, one sum (no contraction)
+  int nW0 = oldW0 + addW0, nW1 = oldW1 + addW1;
+  f2 nWf, inv;
+  nWf.x = (float)nW0; nWf.y = (float)nW1;
+  inv.x = inv_tab[nW0]; inv.y = inv_tab[nW1];
+  {  // div_exact with per-component divisors
+    const f2 q = nf * inv;
+    const f2 r = __builtin_elementwise_fma(-nWf, q, nf);
+    nf = __builtin_elementwise_fma(r, inv, q);
+  }
+  nW0 = nW0 < p.max_w ? nW0 : p.max_w;
+  nW1 = nW1 < p.max_w ? nW1 : p.max_w;
+  const f2 scale = {32767.0f, 32767.0f};
+  const f2 sf = nf * scale;  // floatToValue: (short)(x * 32767)
+  if (act0) vv.x = (vv.x & 0xff000000u) | ((unsigned)nW0 << 16) | (unsigned)(unsigned short)(short)sf.x;
+  if (act1) vv.z = (vv.z & 0xff000000u) | ((unsigned)nW1 << 16) | (unsigned)(unsigned short)(short)sf.y;
+  // colour: only inside the narrow band around the surface
+  if (act0 && !((eta.x > p.mu) || (fabsf(eta_mu.x) > 0.25f))) fuse_colour<SAME_CAM>(vv.x, vv.y, u.x, w.x, pm0, p, inv_tab);
+  if (act1 && !((eta.y > p.mu) || (fabsf(eta_mu.y) > 0.25f))) fuse_colour<SAME_CAM>(vv.z, vv.w, u.y, w.y, pm1, p, inv_tab);
+  return true;
+}
+
 constexpr int kMaxGroup = 8;
 
 // SAME_CAM: the RGB camera is the depth camera (identity calib, as the reference sets it up): the colour update
@@ -244,18 +418,26 @@ __global__ __launch_bounds__(256, 8) void k_integrate(IntegrateParams p) {
         const float fz = (float)(gz + j * 2 + vz0) * p.voxel_size;
         const float az0 = p.M_d.m[8] * fz, az1 = p.M_d.m[9] * fz, az2 = p.M_d.m[10] * fz;
         bool ch = false;
+        if constexpr (!DEINT && DSLAM_PACKED) {
+          // both voxels of the chunk at once (packed FP32): pc = ((pxy + az) + m12..14), as in the scalar form
+          const f2 a0 = {az0, az0}, a1 = {az1, az1}, a2 = {az2, az2};
+          const f2 t0 = {p.M_d.m[12], p.M_d.m[12]}, t1 = {p.M_d.m[13], p.M_d.m[13]}, t2 = {p.M_d.m[14], p.M_d.m[14]};
+          const f2 px = {pxy[0][0], pxy[1][0]}, py = {pxy[0][1], pxy[1][1]}, pz = {pxy[0][2], pxy[1][2]};
+          const Vec4 pm0 = {fxv[0], fy, fz, 1.0f}, pm1 = {fxv[1], fy, fz, 1.0f};
+          ch = fuse_pair<SAME_CAM>(v[jj], (px + a0) + t0, (py + a1) + t1, (pz + a2) + t2, pm0, pm1, p, inv_tab);
+        } else {
 #pragma unroll
-        for (int h = 0; h < 2; h++) {
-          unsigned &lo = h ? v[jj].z : v[jj].x;
-          unsigned &hi = h ? v[jj].w : v[jj].y;
-          if (!DEINT && p.stop_max && (int)((lo >> 16) & 0xffu) == p.max_w) continue;
-          Vec4 pc, pm;
-          pc.x = (pxy[h][0] + az0) + p.M_d.m[12];
-          pc.y = (pxy[h][1] + az1) + p.M_d.m[13];
-          pc.z = (pxy[h][2] + az2) + p.M_d.m[14];
-          pc.w = 1.0f;
-          pm.x = fxv[h]; pm.y = fy; pm.z = fz; pm.w = 1.0f;
-          ch |= update_voxel<DEINT, SAME_CAM>(lo, hi, pc, pm, p, inv_tab);
+          for (int h = 0; h < 2; h++) {
+            unsigned &lo = h ? v[jj].z : v[jj].x;
+            unsigned &hi = h ? v[jj].w : v[jj].y;
+            Vec4 pc, pm;
+            pc.x = (pxy[h][0] + az0) + p.M_d.m[12];
+            pc.y = (pxy[h][1] + az1) + p.M_d.m[13];
+            pc.z = (pxy[h][2] + az2) + p.M_d.m[14];
+            pc.w = 1.0f;
+            pm.x = fxv[h]; pm.y = fy; pm.z = fz; pm.w = 1.0f;
+            ch |= update_voxel<DEINT, SAME_CAM>(lo, hi, pc, pm, p, inv_tab);
+          }
         }
         if (ch) blk[j * 64 + lane] = v[jj];
       }

@@ -131,6 +131,10 @@ int dslam_engine_set_async(dslam_engine *e, int async_mode);
 int dslam_engine_synchronize(dslam_engine *e);
 /* native hipStream_t of the engine, for callers that enqueue their own work (RCCL, torch). */
 void *dslam_engine_stream(dslam_engine *e);
+/* Self-test: the integration kernel divides with a 2-wide, scaling-free form of the hardware's IEEE division sequence
+ * (csrc/integrate.hip div_ieee2).  Compares it with the native float division on `samples` random operand pairs
+ * drawn from the kernel's operand ranges, on the device; *mismatches_out must come back 0. */
+int dslam_selftest_division(dslam_engine *e, long long samples, long long *mismatches_out);
 /* Test hook: CreateExpectedDepths' render-tile budget (MAX_RENDERING_BLOCKS, default DSLAM_MAX_RENDERING_BLOCKS).
  * Upstream drops, in visible-list order, every block whose tiles would reach the budget; real scenes never get
  * there (it takes > 262144 tiles), so the parity test of that rule lowers the budget instead. */

@@ -211,3 +211,9 @@ def test_separate_visualisation_calls_equal_get_image(pkg, synth, gpu, oracle):
     assert np.abs(g[pkg.IMAGE_DEPTH] - o[pkg.IMAGE_DEPTH]).max() <= 1e-4
     for t in (pkg.IMAGE_SHADED, pkg.IMAGE_COLOUR_FROM_VOLUME, pkg.IMAGE_COLOUR_FROM_NORMAL):
         assert np.abs(g[t].astype(int) - o[t].astype(int)).max() <= 1
+
+
+def test_packed_division_selftest(gpu):
+    """The integration kernel's 2-wide IEEE division (div_ieee2: the hardware sequence without its scaling / fix-up
+    instructions) against the native float division on 2^28 random operand pairs of the kernel's ranges."""
+    assert gpu.selftest_division(1 << 28) == 0
