@@ -6,7 +6,6 @@ far past the 256 MiB Infinity Cache).  Used for the steady-state HBM roofline po
 """
 import json
 import sys
-import time
 
 import numpy as np
 

@@ -5,7 +5,6 @@ import re
 
 import pytest
 
-import __graft_entry__ as ge
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 

@@ -1,6 +1,5 @@
 """Oracle-level behaviour and metamorphic tests (CPU only).  They pin the semantics the HIP engine is held to."""
 import numpy as np
-import pytest
 
 import util
 

@@ -3,7 +3,6 @@ InfiniTAM v2 formulas, not from running reference code (the reference ships none
 import ctypes as C
 
 import numpy as np
-import pytest
 
 
 def test_hash_index(oracle):
