@@ -20,6 +20,8 @@
 
 #pragma clang fp contract(off)
 
+// -DDSLAM_PACKED=0 builds the fusion path voxel by voxel (the scalar form the packed one must match bit for bit;
+// used for A/B timing)
 #ifndef DSLAM_PACKED
 #define DSLAM_PACKED 1
 #endif
