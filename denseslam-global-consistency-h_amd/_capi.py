@@ -131,6 +131,7 @@ class CApi:
         self.prefix = prefix
         self.path = path
         self._engine = C.c_void_p()
+        self._pinned = {}
         if has_engine_device:
             self._check(self._fn("engine_create")(C.c_int(device), C.byref(self._engine)), "engine_create")
         else:
@@ -451,6 +452,29 @@ class CApi:
         nrm = np.empty((rs.height, rs.width, 4), dtype=np.float32)
         self._call("create_icp_maps", self._engine, scene.ptr, rs.ptr, _fptr(m), _fptr(k), _fptr(pts), _fptr(nrm))
         return pts, nrm
+
+    def download_icp_maps(self, rs):
+        """The points / normals maps the last create_icp_maps left on the device."""
+        pts = np.empty((rs.height, rs.width, 4), dtype=np.float32)
+        nrm = np.empty((rs.height, rs.width, 4), dtype=np.float32)
+        self._call("download_icp_maps", self._engine, rs.ptr, _fptr(pts), _fptr(nrm))
+        return pts, nrm
+
+    # -- page-locked host images -----------------------------------------------------------------------
+    def host_alloc(self, shape, dtype):
+        """A zero-filled numpy array over page-locked memory (dslam_host_alloc): view_update* in synchronous mode
+        DMA straight out of such arrays.  Release with host_free(array) once nothing refers to it any more."""
+        dtype = np.dtype(dtype)
+        n = int(np.prod(shape)) * dtype.itemsize
+        p = C.c_void_p()
+        self._call("host_alloc", C.c_size_t(n), C.byref(p))
+        buf = (C.c_char * max(n, 1)).from_address(p.value)
+        arr = np.frombuffer(buf, dtype=dtype, count=int(np.prod(shape))).reshape(shape)
+        self._pinned[arr.ctypes.data] = p.value
+        return arr
+
+    def host_free(self, arr):
+        self._call("host_free", C.c_void_p(self._pinned.pop(arr.ctypes.data)))
 
     # -- read-back -------------------------------------------------------------------------------------
     def stats(self, scene, rs=None):

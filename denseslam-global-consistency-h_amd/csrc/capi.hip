@@ -5,6 +5,9 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
+#include <utility>
+#include <vector>
 
 #include "dslam_internal.h"
 
@@ -391,19 +394,65 @@ static int finish_view_update(dslam_engine *e, dslam_view *v, const void *rgba_d
   return finish_call(e);
 }
 
+// ---- page-locked host buffers for the caller's input images ---------------------------------------------------
+// Upstream ORUtils::MemoryBlock allocates its host side with cudaMallocHost whenever the block also has a device
+// side; dslam_host_alloc gives the ITMLib mirror the same thing without it having to link the HIP runtime.  The
+// engine remembers the ranges, so an upload from one of them can skip the staging copy.
+static std::mutex g_pinned_mu;
+static std::vector<std::pair<const char *, size_t>> g_pinned_ranges;
+
+int dslam_host_alloc(size_t bytes, void **out) {
+  DSLAM_REQUIRE(out, "null argument");
+  void *p = nullptr;
+  DSLAM_HIP(hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault));
+  memset(p, 0, bytes);
+  std::lock_guard<std::mutex> lock(g_pinned_mu);
+  g_pinned_ranges.emplace_back(static_cast<const char *>(p), bytes ? bytes : 1);
+  *out = p;
+  return DSLAM_OK;
+}
+
+int dslam_host_free(void *p) {
+  if (!p) return DSLAM_OK;
+  {
+    std::lock_guard<std::mutex> lock(g_pinned_mu);
+    size_t i = 0;
+    while (i < g_pinned_ranges.size() && g_pinned_ranges[i].first != p) i++;
+    DSLAM_REQUIRE(i < g_pinned_ranges.size(), "dslam_host_free: pointer was not returned by dslam_host_alloc");
+    g_pinned_ranges.erase(g_pinned_ranges.begin() + i);
+  }
+  DSLAM_HIP(hipHostFree(p));
+  return DSLAM_OK;
+}
+
+static bool in_pinned_range(const void *p, size_t bytes) {
+  const char *c = static_cast<const char *>(p);
+  std::lock_guard<std::mutex> lock(g_pinned_mu);
+  for (const auto &r : g_pinned_ranges)
+    if (c >= r.first && c + bytes <= r.first + r.second) return true;
+  return false;
+}
+
 static int upload_view_host(dslam_engine *e, dslam_view *v, const uint8_t *colour_host, int colour_channels,
                             const int16_t *depth_host) {
   const size_t c_bytes = (size_t)v->w_rgb * v->h_rgb * colour_channels, d_bytes = (size_t)v->w_d * v->h_d * 2;
   int rc = ensure_staging(e, (size_t)v->w_rgb * v->h_rgb * 4 + d_bytes);
   if (rc) return rc;
-  // the caller may reuse its buffers right after the call (CvToItm rewrites them every frame), so stage through
-  // pinned memory; in async mode the previous upload must have drained before the staging buffer is rewritten
-  DSLAM_HIP(hipStreamSynchronize(e->stream));
-  memcpy(e->staging_host, colour_host, c_bytes);
-  memcpy((char *)e->staging_host + c_bytes, depth_host, d_bytes);
+  const void *colour_src, *depth_src;
+  if (!e->async_mode && in_pinned_range(colour_host, c_bytes) && in_pinned_range(depth_host, d_bytes)) {
+    // page-locked caller buffers and a call that only returns once the stream has drained: DMA straight from them
+    colour_src = colour_host; depth_src = depth_host;
+  } else {
+    // the caller may reuse its buffers right after the call (CvToItm rewrites them every frame), so stage through
+    // pinned memory; in async mode the previous upload must have drained before the staging buffer is rewritten
+    DSLAM_HIP(hipStreamSynchronize(e->stream));
+    memcpy(e->staging_host, colour_host, c_bytes);
+    memcpy((char *)e->staging_host + c_bytes, depth_host, d_bytes);
+    colour_src = e->staging_host; depth_src = (char *)e->staging_host + c_bytes;
+  }
   void *colour_dst = colour_channels == 4 ? (void *)v->rgba : e->staging_dev;
-  DSLAM_HIP(hipMemcpyAsync(colour_dst, e->staging_host, c_bytes, hipMemcpyHostToDevice, e->stream));
-  DSLAM_HIP(hipMemcpyAsync(v->raw_depth, (char *)e->staging_host + c_bytes, d_bytes, hipMemcpyHostToDevice, e->stream));
+  DSLAM_HIP(hipMemcpyAsync(colour_dst, colour_src, c_bytes, hipMemcpyHostToDevice, e->stream));
+  DSLAM_HIP(hipMemcpyAsync(v->raw_depth, depth_src, d_bytes, hipMemcpyHostToDevice, e->stream));
   if (colour_channels == 3) return launch_bgr_to_rgba(e, e->staging_dev, v->rgba, v->w_rgb * v->h_rgb);
   return DSLAM_OK;
 }
@@ -807,6 +856,16 @@ int dslam_create_icp_maps(dslam_engine *e, const dslam_scene *s, dslam_render_st
   if (out_normals) DSLAM_HIP(hipMemcpyAsync(out_normals, r->icp_normals, bytes, hipMemcpyDeviceToHost, e->stream));
   if (out_points || out_normals) { DSLAM_HIP(hipStreamSynchronize(e->stream)); return DSLAM_OK; }
   return finish_call(e);
+}
+
+int dslam_download_icp_maps(dslam_engine *e, const dslam_render_state *r, float *out_points, float *out_normals) {
+  DSLAM_REQUIRE(e && r, "null argument");
+  DSLAM_REQUIRE(r->icp_points && r->icp_normals, "dslam_create_icp_maps has not run on this render state");
+  const size_t bytes = (size_t)r->w * r->h * sizeof(float4);
+  if (out_points) DSLAM_HIP(hipMemcpyAsync(out_points, r->icp_points, bytes, hipMemcpyDeviceToHost, e->stream));
+  if (out_normals) DSLAM_HIP(hipMemcpyAsync(out_normals, r->icp_normals, bytes, hipMemcpyDeviceToHost, e->stream));
+  DSLAM_HIP(hipStreamSynchronize(e->stream));
+  return DSLAM_OK;
 }
 
 // ---- read-back -----------------------------------------------------------------------------------------------

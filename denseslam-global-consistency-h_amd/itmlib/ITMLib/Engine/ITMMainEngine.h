@@ -122,19 +122,19 @@ class ITMViewBuilder {
     dslam_check(dslam_view_update(eng_, v->handle, &rgb->GetData(MEMORYDEVICE_CPU)->x, rawDepth->GetData(MEMORYDEVICE_CPU),
                                   ab.x, ab.y, timestamp, useBilateralFilter), "dslam_view_update");
     v->timestamp = timestamp;
-    // host mirrors: view->rgb / view->depth are read back by the driver (InfiniTamDriver.h:217-218)
-    memcpy(v->rgb->GetData(MEMORYDEVICE_CPU), rgb->GetData(MEMORYDEVICE_CPU), (size_t)rgb->noDims.x * rgb->noDims.y * 4);
-    dslam_check(dslam_download_view_depth(eng_, v->handle, v->depth->GetData(MEMORYDEVICE_CPU)), "dslam_download_view_depth");
+    // host mirrors: view->rgb / view->depth are read back by the driver (InfiniTamDriver.h:217-218) -- on demand
+    v->MarkHostStale();
   }
   /// UpdateView for a keyframe that already sits in the device-resident keyframe store (the UpdateView calls of
-  /// DenseSlam::OnlineCorrection, DenseSlam.cpp:392,421): no upload, and the host mirrors view->rgb / view->depth
-  /// are left alone -- nothing on that path reads them.
+  /// DenseSlam::OnlineCorrection, DenseSlam.cpp:392,421): no upload; the host mirrors view->rgb / view->depth are
+  /// refreshed only if somebody reads them (nothing on that path does).
   void UpdateViewFromStore(ITMView **view, const dslam_frame_store *store, int slot, double timestamp, bool useBilateralFilter) {
     if (*view == nullptr) throw std::runtime_error("UpdateViewFromStore: the view must have been created by UpdateView first");
     const Vector2f ab = calib_->disparityCalib.params;
     dslam_check(dslam_view_update_from_store(eng_, (*view)->handle, store, slot, ab.x, ab.y, timestamp, useBilateralFilter),
                 "dslam_view_update_from_store");
     (*view)->timestamp = timestamp;
+    (*view)->MarkHostStale();
   }
 };
 
@@ -156,8 +156,15 @@ class ITMTrackingController {
   void Prepare(ITMTrackingState *ts, const ITMScene<ITMVoxel, ITMVoxelIndex> *scene, const ITMView *view, ITMRenderState *rs) {
     const Matrix4f M = ts->pose_d->GetM();
     const Vector4f k = view->calib->intrinsics_d.projectionParamsSimple.all;
-    dslam_check(dslam_create_icp_maps(eng_, scene->handle, rs->handle, M.m, k.v, &ts->pointsMap->GetData(MEMORYDEVICE_CPU)->x,
-                                      &ts->normalsMap->GetData(MEMORYDEVICE_CPU)->x), "dslam_create_icp_maps");
+    // the maps stay on the device (Track reads them there); trackingState->pointsMap / normalsMap are host mirrors
+    // filled when somebody asks for them
+    dslam_check(dslam_create_icp_maps(eng_, scene->handle, rs->handle, M.m, k.v, nullptr, nullptr), "dslam_create_icp_maps");
+    dslam_engine *eng = eng_;
+    dslam_render_state *h = rs->handle;
+    ts->pointsMap->SetHostPull([eng, h](Vector4f *dst) { dslam_check(dslam_download_icp_maps(eng, h, &dst->x, nullptr), "dslam_download_icp_maps"); });
+    ts->normalsMap->SetHostPull([eng, h](Vector4f *dst) { dslam_check(dslam_download_icp_maps(eng, h, nullptr, &dst->x), "dslam_download_icp_maps"); });
+    ts->pointsMap->MarkHostStale();
+    ts->normalsMap->MarkHostStale();
     ts->pose_pointCloud->SetM(M);
     ts->preparedWith = rs;
     ts->age_pointCloud = 0;

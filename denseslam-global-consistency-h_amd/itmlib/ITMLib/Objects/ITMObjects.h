@@ -127,10 +127,15 @@ class ITMView {
   dslam_view *handle;
   double timestamp;
   ITMView(const ITMRGBDCalib *c, Vector2i sz_rgb, Vector2i sz_d, dslam_engine *eng) : calib(c), handle(nullptr), timestamp(0) {
-    rgb = new ITMUChar4Image(sz_rgb, true, false);
-    depth = new ITMFloatImage(sz_d, true, false);
+    rgb = new ITMUChar4Image(sz_rgb, true, true);
+    depth = new ITMFloatImage(sz_d, true, true);
     dslam_check(dslam_view_create(eng, sz_rgb.x, sz_rgb.y, sz_d.x, sz_d.y, &handle), "dslam_view_create");
+    // the device images are the master copies; the host mirrors are filled on the first GetData after an update
+    dslam_view *h = handle;
+    rgb->SetHostPull([eng, h](Vector4u *dst) { dslam_check(dslam_download_view_rgba(eng, h, &dst->x), "dslam_download_view_rgba"); });
+    depth->SetHostPull([eng, h](float *dst) { dslam_check(dslam_download_view_depth(eng, h, dst), "dslam_download_view_depth"); });
   }
+  void MarkHostStale() { rgb->MarkHostStale(); depth->MarkHostStale(); }
   ~ITMView() { dslam_view_destroy(handle); delete rgb; delete depth; }
 };
 
@@ -145,8 +150,8 @@ class ITMTrackingState {
   explicit ITMTrackingState(Vector2i sz) : preparedWith(nullptr), age_pointCloud(-1) {
     pose_d = new ITMPose();
     pose_pointCloud = new ITMPose();
-    pointsMap = new ITMFloat4Image(sz, true, false);
-    normalsMap = new ITMFloat4Image(sz, true, false);
+    pointsMap = new ITMFloat4Image(sz, true, true);
+    normalsMap = new ITMFloat4Image(sz, true, true);
   }
   ~ITMTrackingState() { delete pose_d; delete pose_pointCloud; delete pointsMap; delete normalsMap; }
 };
@@ -165,7 +170,7 @@ class ITMRenderState_VH : public ITMRenderState {
   int noVisibleEntries;  ///< InfiniTamDriver.h:209-210
   ITMRenderState_VH(dslam_engine *eng, const dslam_scene *scene, Vector2i sz) : noVisibleEntries(0) {
     dslam_check(dslam_render_state_create(eng, scene, sz.x, sz.y, &handle), "dslam_render_state_create");
-    raycastImage = new ITMUChar4Image(sz, true, false);
+    raycastImage = new ITMUChar4Image(sz, true, true);
   }
 };
 

@@ -9,7 +9,11 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
+#include <new>
 #include <stdexcept>
+
+#include "dslam_fusion.h"
 
 enum MemoryDeviceType { MEMORYDEVICE_CPU, MEMORYDEVICE_CUDA };
 
@@ -114,24 +118,47 @@ template <class T> struct Matrix4 {
 template <typename T> class MemoryBlock {
  public:
   size_t dataSize;
-  MemoryBlock(size_t n, bool allocate_CPU, bool /*allocate_CUDA*/) : dataSize(n), data_(nullptr) {
-    if (allocate_CPU || true) data_ = (T *)calloc(n ? n : 1, sizeof(T));
+  /// allocate_CUDA: upstream gives such a block a device side and a page-locked host side (ORUtils/MemoryBlock.h
+  /// Allocate).  Here the device side lives inside libdslam_fusion; the host side is page-locked all the same, so
+  /// dslam_view_update can DMA straight out of the caller's image.
+  MemoryBlock(size_t n, bool /*allocate_CPU*/, bool allocate_CUDA) : dataSize(n), data_(nullptr), pinned_(allocate_CUDA), stale_(false) {
+    data_ = allocate(n);
   }
-  virtual ~MemoryBlock() { free(data_); }
-  T *GetData(MemoryDeviceType t) { check(t); return data_; }
-  const T *GetData(MemoryDeviceType t) const { check(t); return data_; }
-  void Clear(unsigned char v = 0) { memset(data_, v, dataSize * sizeof(T)); }
+  virtual ~MemoryBlock() { release(data_); }
+  T *GetData(MemoryDeviceType t) { check(t); sync(); return data_; }
+  const T *GetData(MemoryDeviceType t) const { check(t); sync(); return data_; }
+  void Clear(unsigned char v = 0) { stale_ = false; memset(data_, v, dataSize * sizeof(T)); }
   void UpdateDeviceFromHost() const {}
-  void UpdateHostFromDevice() const {}
+  void UpdateHostFromDevice() const { sync(); }
+  /// Lazy host mirror: the device copy inside libdslam_fusion is the master; `pull` fills the host buffer from it
+  /// the next time somebody asks for the host pointer (most frames nobody does, which saves a D2H copy per frame).
+  void SetHostPull(std::function<void(T *)> pull) { pull_ = std::move(pull); }
+  void MarkHostStale() { stale_ = (bool)pull_; }
  protected:
   static void check(MemoryDeviceType t) {
     if (t != MEMORYDEVICE_CPU) throw std::runtime_error("device mirrors live inside libdslam_fusion; use MEMORYDEVICE_CPU");
   }
+  void sync() const {
+    if (stale_) { stale_ = false; pull_(data_); }
+  }
   void resize(size_t n) {
-    if (n > dataSize) { free(data_); data_ = (T *)calloc(n, sizeof(T)); }
+    if (n > dataSize) { release(data_); data_ = allocate(n); }
     dataSize = n;
   }
+  T *allocate(size_t n) const {
+    void *p = nullptr;
+    if (!pinned_) p = calloc(n ? n : 1, sizeof(T));
+    else if (dslam_host_alloc((n ? n : 1) * sizeof(T), &p) != DSLAM_OK) throw std::runtime_error(dslam_last_error());
+    if (p == nullptr) throw std::bad_alloc();
+    return (T *)p;
+  }
+  void release(T *p) const {
+    if (pinned_) dslam_host_free(p); else free(p);
+  }
   T *data_;
+  bool pinned_;
+  mutable bool stale_;
+  std::function<void(T *)> pull_;
   MemoryBlock(const MemoryBlock &) = delete;
   MemoryBlock &operator=(const MemoryBlock &) = delete;
 };

@@ -13,8 +13,12 @@
 //             float depth[W*H]; uint8 colour[W*H*4]; float trackedM[16] (TrackLocalMap of the last frame, started
 //             from the pose of the frame before it);
 //             with keyframes.bin, per frame: int32 nCorrected, double ts[nCorrected] (in re-fusion order),
-//             int32 nCulled, int32 databaseSize
+//             int32 nCulled, int32 databaseSize;
+//             trailer: uint64 fnv1a(view->rgb host mirror), uint64 fnv1a(view->depth host mirror),
+//             int32 valid points, int32 valid normals of the tracking state's host ICP maps
+#include <chrono>
 #include <cstdint>
+#include <cstdlib>
 #include <cstdio>
 #include <vector>
 
@@ -229,6 +233,7 @@ int main(int argc, char **argv) {
       }
     }
     int fused = 0;
+    const auto t_loop0 = std::chrono::steady_clock::now();
     for (int i = 0; i < N && !oc.enabled; i++) {
       currentLocalMap->trackingState->pose_d->SetM(poses[i]);                 // SetPoseLocalMap (InfiniTamDriver.h:173-178)
       drv.UpdateView(rgba[i].data(), depth[i].data(), (double)i);             // DenseSlam.cpp:212
@@ -236,7 +241,13 @@ int main(int argc, char **argv) {
       fused++;
       if (sw.enabled && fused > sw.max_age) drv.SlideWindow(currentLocalMap);  // DenseSlam.cpp:215-225
       drv.Decay(currentLocalMap);                                             // DenseSlam.cpp:227-232
+      if (getenv("DRIVER_HARNESS_RAYCAST_EACH_FRAME")) {                      // SaveRaycastDepth's per-keyframe raycast
+        free_pose.SetM(poses[i]);
+        drv.GetFloatImage(&out_float, free_pose, currentLocalMap);
+      }
     }
+    const double loop_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_loop0).count();
+    if (!oc.enabled && N > 0) printf("driver_harness loop: %d keyframes in %.3f ms (%.1f us per keyframe, host-synchronous calls)\n", N, loop_s * 1e3, loop_s * 1e6 / N);
     free_pose.SetM(poses[N - 1]);
     drv.GetFloatImage(&out_float, free_pose, currentLocalMap);                // DenseSlam.h:146-153
     drv.GetImage(&out_rgba, ITMMainEngine::InfiniTAM_IMAGE_FREECAMERA_COLOUR_FROM_VOLUME, free_pose, currentLocalMap);
@@ -274,6 +285,19 @@ int main(int argc, char **argv) {
       fwrite(&n, 4, 1, o);
       fwrite(oc_order[i].data(), 8, oc_order[i].size(), o);
       fwrite(&oc_counts[3 * i + 1], 4, 2, o);
+    }
+    // trailer: the lazily filled host mirrors (view->rgb / view->depth of the last UpdateView, and the tracking
+    // state's points map from the last Prepare), read through the same GetData calls the reference driver makes
+    {
+      const ITMView *v = drv.GetView();
+      const size_t npx = (size_t)W * H;
+      uint64_t mirror[2] = {fnv1a(v->rgb->GetData(MEMORYDEVICE_CPU), npx * 4), fnv1a(v->depth->GetData(MEMORYDEVICE_CPU), npx * 4)};
+      const Vector4f *pts = currentLocalMap->trackingState->pointsMap->GetData(MEMORYDEVICE_CPU);
+      const Vector4f *nrm = currentLocalMap->trackingState->normalsMap->GetData(MEMORYDEVICE_CPU);
+      int32_t valid[2] = {0, 0};
+      for (size_t i = 0; i < npx; i++) { valid[0] += pts[i].w > 0.0f; valid[1] += nrm[i].w == 0.0f; }
+      fwrite(mirror, 8, 2, o);
+      fwrite(valid, 4, 2, o);
     }
     fclose(o);
     printf("driver_harness ok: %d frames, lastFreeBlockId %d, visible %d, decayed %d\n", N, st[0], st[1], st[3]);

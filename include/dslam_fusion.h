@@ -131,6 +131,13 @@ int dslam_engine_set_async(dslam_engine *e, int async_mode);
 int dslam_engine_synchronize(dslam_engine *e);
 /* native hipStream_t of the engine, for callers that enqueue their own work (RCCL, torch). */
 void *dslam_engine_stream(dslam_engine *e);
+/* Page-locked host memory for the caller's image buffers: what ORUtils::MemoryBlock's host side is whenever the
+ * block also has a device side (upstream ORUtils/MemoryBlock.h Allocate: cudaMallocHost), i.e. the rgb / raw-depth
+ * images DenseSlam::ProcessFrame fills each frame (DenseSlam.cpp:66-74).  Zero-filled.  In the default synchronous
+ * mode dslam_view_update* DMA straight from such buffers; any other host pointer is staged through the engine's
+ * own pinned buffer first.  Needs no engine (the images are created before it). */
+int dslam_host_alloc(size_t bytes, void **out);
+int dslam_host_free(void *p);
 /* Self-test: the integration kernel divides with a 2-wide, scaling-free form of the hardware's IEEE division sequence
  * (csrc/integrate.hip div_ieee2).  Compares it with the native float division on `samples` random operand pairs
  * drawn from the kernel's operand ranges, on the device; *mismatches_out must come back 0. */
@@ -364,6 +371,9 @@ int dslam_download_visible_types(dslam_engine *e, const dslam_render_state *r, u
 int dslam_download_range_image(dslam_engine *e, const dslam_render_state *r, float *out_minmax_host);
 int dslam_download_raycast_result(dslam_engine *e, const dslam_render_state *r, float *out_xyzw_host);
 int dslam_download_view_depth(dslam_engine *e, const dslam_view *v, float *out_host);
+/* the points / normals maps dslam_create_icp_maps left on the device (either pointer may be NULL) */
+int dslam_download_icp_maps(dslam_engine *e, const dslam_render_state *r, float *out_points_host,
+                            float *out_normals_host);
 int dslam_download_swap_states(dslam_engine *e, const dslam_scene *s, uint8_t *out_host);
 /* per voxel-block slot: newest global list index that holds the block (-1 never, <= -2 swept by Decay) */
 int dslam_download_last_seen(dslam_engine *e, const dslam_scene *s, int32_t *out_host);

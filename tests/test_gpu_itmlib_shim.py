@@ -78,7 +78,14 @@ def test_driver_harness_matches_oracle(pkg, synth, oracle, tmp_path, decay, slid
     # TrackLocalMap (InfiniTamDriver.h:151-163): Prepare at the last pose, then ICP of the last frame started from
     # the pose before it; tolerance 1e-5 on the matrix entries (double-accumulated sums differ in summation order)
     g_tracked = np.frombuffer(raw, np.float32, 16, 32 + npx * 8).reshape(4, 4).T
-    oracle.create_icp_maps(s, rs, M_last, wl.intr)
+    o_pts, o_nrm = oracle.create_icp_maps(s, rs, M_last, wl.intr)
     t_pose, t_res = oracle.track_camera(v, rs, M_last, frames[-2][2], wl.intr)
     assert t_res.iterations > 0 and t_res.valid_points_last > 100
     assert np.abs(g_tracked - t_pose).max() <= 1e-5
+    # trailer: the shim's host mirrors are filled lazily (first GetData after an update); what a reader sees must be
+    # the last UpdateView's images and the last Prepare's maps
+    m_rgb, m_depth = struct.unpack_from("<2Q", raw, len(raw) - 24)
+    n_pts, n_nrm = struct.unpack_from("<2i", raw, len(raw) - 8)
+    assert m_rgb == fnv1a(frames[-1][0].tobytes())
+    assert m_depth == fnv1a(oracle.download_view_depth(v).tobytes())
+    assert n_pts == int((o_pts[..., 3] > 0).sum()) and n_nrm == int((o_nrm[..., 3] == 0).sum()) and n_pts > 500

@@ -106,6 +106,9 @@ def test_icp_maps(pkg, synth, gpu, oracle):
         s, rs, v = util.run_sequence(api, pkg, wl, p, 3)
         rgba, mm, M = wl.frame(2)
         out[name] = api.create_icp_maps(s, rs, M, wl.intr)
+        if name == "gpu":  # the maps stay on the device for the tracker; a later read-back sees the same thing
+            again = api.download_icp_maps(rs)
+            assert np.array_equal(again[0], out[name][0]) and np.array_equal(again[1], out[name][1])
     (p0, n0), (p1, n1) = out["gpu"], out["oracle"]
     assert np.array_equal(p0[..., 3], p1[..., 3]) and (p0[..., 3] > 0).mean() > 0.3
     assert np.abs(p0 - p1).max() <= 1e-5 and np.abs(n0 - n1).max() <= 1e-4

@@ -3,6 +3,8 @@ BGR->RGBA (reference InfiniTamDriver.cpp:84-103), the bilateral depth filter of 
 (call site InfiniTamDriver.cpp:280-288) and DenseSlam::depthPostProcessing (DenseSlam.cpp:434-552).
 Integer / byte results are bit-exact; the filtered float depth is bit-exact too because host and device share one
 fixed exp sequence (tolerance 0)."""
+import ctypes
+
 import numpy as np
 import pytest
 
@@ -172,3 +174,43 @@ def test_depth_image_int16_output(pkg, synth, gpu, oracle):
     assert np.abs(res["gpu"][0] - res["oracle"][0]).max() <= 1e-4
     assert np.abs(res["gpu"][1].astype(int) - res["oracle"][1].astype(int)).max() <= 1  # 1 mm
     assert (res["gpu"][2] > 0).sum() > 500
+
+
+def test_page_locked_caller_images_take_the_direct_path(gpu, oracle):
+    """dslam_host_alloc: the caller's image buffers page-locked (what upstream's MemoryBlock gives every image that
+    has a device side).  In synchronous mode the upload DMAs straight out of them; in async mode, and from ordinary
+    host memory, it is staged -- all three must leave the same view on the device, and the buffer may be rewritten
+    right after the call returns."""
+    W, H = 96, 64
+    rng = np.random.default_rng(21)
+    rgba_p = gpu.host_alloc((H, W, 4), np.uint8)
+    mm_p = gpu.host_alloc((H, W), np.int16)
+    assert not rgba_p.any() and not mm_p.any()  # zero-filled
+    v, vo = gpu.create_view(W, H), oracle.create_view(W, H)
+    try:
+        for mode in (False, True, False):
+            gpu.set_async(mode)
+            for i in range(3):
+                rgba = rng.integers(0, 256, (H, W, 4), dtype=np.uint8)
+                mm = rng.integers(0, 4000, (H, W)).astype(np.int16)
+                rgba_p[...] = rgba
+                mm_p[...] = mm
+                gpu.view_update(v, rgba_p, mm_p, timestamp=float(i))
+                if not mode:  # the call has returned, so the buffers are the caller's again
+                    rgba_p[...] = 0
+                    mm_p[...] = -1
+                oracle.view_update(vo, rgba, mm, timestamp=float(i))
+                assert np.array_equal(gpu.download_view_rgba(v), oracle.download_view_rgba(vo))
+                assert np.array_equal(gpu.download_view_depth(v), oracle.download_view_depth(vo))
+        # a slice of a page-locked buffer is still inside the registered range; one past its end is not
+        big = gpu.host_alloc((H * W * 4 + 64,), np.uint8)
+        big[64:] = rgba.reshape(-1)
+        gpu.view_update(v, big[64:], mm, timestamp=9.0)  # colour pinned, depth pageable -> staged
+        assert np.array_equal(gpu.download_view_rgba(v), rgba)
+        gpu.host_free(big)
+    finally:
+        gpu.set_async(False)
+        gpu.host_free(rgba_p)
+        gpu.host_free(mm_p)
+    with pytest.raises(Exception):
+        gpu._call("host_free", ctypes.c_void_p(12345))  # not one of ours
