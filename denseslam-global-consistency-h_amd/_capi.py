@@ -460,6 +460,17 @@ class CApi:
         self._call("download_icp_maps", self._engine, rs.ptr, _fptr(pts), _fptr(nrm))
         return pts, nrm
 
+    # -- meshing export --------------------------------------------------------------------------------
+    def mesh_scene(self, scene, max_triangles=0, colour=False):
+        """SaveCurrSceneToMesh's MeshScene: returns (positions [n, 3, 3] float32 in metres, colours [n, 3, 3] float32
+        in [0, 1] or None), triangles in upstream's CPU-engine order."""
+        n = C.c_int(0)
+        self._call("mesh_scene", self._engine, scene.ptr, C.c_int(int(max_triangles)), C.c_int(int(colour)), C.byref(n))
+        pos = np.empty((max(n.value, 1), 3, 3), dtype=np.float32)  # never a null pointer, even for an empty mesh
+        col = np.empty((max(n.value, 1), 3, 3), dtype=np.float32) if colour else None
+        self._call("mesh_download", self._engine, _fptr(pos), _fptr(col) if colour else None, C.c_int(n.value))
+        return pos[:n.value], (col[:n.value] if colour else None)
+
     # -- page-locked host images -----------------------------------------------------------------------
     def host_alloc(self, shape, dtype):
         """A zero-filled numpy array over page-locked memory (dslam_host_alloc): view_update* in synchronous mode

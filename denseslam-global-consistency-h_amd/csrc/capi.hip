@@ -154,6 +154,7 @@ int dslam_engine_destroy(dslam_engine *e) {
   if (e->pinned) (void)hipHostFree(e->pinned);
   if (e->timer_counts_dev) (void)hipFree(e->timer_counts_dev);
   free_dev(e->misc_counter);
+  free_dev(e->mesh_positions); free_dev(e->mesh_colours);
   if (e->icp_partials_host) (void)hipHostFree(e->icp_partials_host);  // (icp_partials is its device alias)
   for (auto ev : e->ev_pool) (void)hipEventDestroy(ev);
   (void)hipStreamDestroy(e->stream);
@@ -864,6 +865,28 @@ int dslam_download_icp_maps(dslam_engine *e, const dslam_render_state *r, float 
   const size_t bytes = (size_t)r->w * r->h * sizeof(float4);
   if (out_points) DSLAM_HIP(hipMemcpyAsync(out_points, r->icp_points, bytes, hipMemcpyDeviceToHost, e->stream));
   if (out_normals) DSLAM_HIP(hipMemcpyAsync(out_normals, r->icp_normals, bytes, hipMemcpyDeviceToHost, e->stream));
+  DSLAM_HIP(hipStreamSynchronize(e->stream));
+  return DSLAM_OK;
+}
+
+// ---- meshing export --------------------------------------------------------------------------------------------
+int dslam_mesh_scene(dslam_engine *e, const dslam_scene *s, int max_triangles, int with_colour, int *out_num_triangles) {
+  DSLAM_REQUIRE(e && s && out_num_triangles, "null argument");
+  if (max_triangles <= 0) max_triangles = s->p.num_local_blocks * 32;  // ITMMesh::noMaxTriangles
+  int rc = launch_mesh_scene(e, s, max_triangles, with_colour, out_num_triangles);
+  if (rc) return rc;
+  return finish_call(e);
+}
+
+int dslam_mesh_download(dslam_engine *e, float *out_positions, float *out_colours, int capacity_triangles) {
+  DSLAM_REQUIRE(e && out_positions && capacity_triangles >= 0, "bad argument");
+  DSLAM_REQUIRE(capacity_triangles >= e->mesh_triangles, "dslam_mesh_download: buffer smaller than the mesh");
+  DSLAM_REQUIRE(!out_colours || e->mesh_has_colour, "dslam_mesh_download: the mesh was made without colours");
+  const size_t bytes = (size_t)e->mesh_triangles * 9 * sizeof(float);
+  if (bytes) {
+    DSLAM_HIP(hipMemcpyAsync(out_positions, e->mesh_positions, bytes, hipMemcpyDeviceToHost, e->stream));
+    if (out_colours) DSLAM_HIP(hipMemcpyAsync(out_colours, e->mesh_colours, bytes, hipMemcpyDeviceToHost, e->stream));
+  }
   DSLAM_HIP(hipStreamSynchronize(e->stream));
   return DSLAM_OK;
 }

@@ -70,6 +70,12 @@ struct dslam_engine {
   double *icp_partials_host = nullptr;  // depth tracker: per-workgroup partial sums in mapped pinned host memory
   double *icp_partials = nullptr;       // ... and the device address of the same buffer
   int *misc_counter = nullptr;        // device: small result counters of one-off kernels (depthPostProcessing)
+  // the last mesh dslam_mesh_scene produced (ITMMesh: triangles as 3 x Vector3f, metres)
+  float *mesh_positions = nullptr;    // device [mesh_triangles][3][3]
+  float *mesh_colours = nullptr;      // device [mesh_triangles][3][3], only if asked for
+  size_t mesh_bytes = 0;              // capacity of each of the two buffers
+  int mesh_triangles = 0;
+  bool mesh_has_colour = false;
 };
 
 struct dslam_scene {
@@ -175,6 +181,7 @@ int launch_track_camera(dslam_engine *e, const dslam_view *v, dslam_render_state
 int launch_render(dslam_engine *e, const dslam_scene *s, dslam_render_state *r, const float *M, const float *intr,
                   int type);
 int launch_icp_maps(dslam_engine *e, const dslam_scene *s, dslam_render_state *r, const float *M, const float *intr);
+int launch_mesh_scene(dslam_engine *e, const dslam_scene *s, int max_triangles, int with_colour, int *out_num);
 int launch_decay(dslam_engine *e, dslam_scene *s, dslam_render_state *r, int max_weight, int min_age, int force_all,
                  int which);
 int launch_slide_pop(dslam_engine *e, dslam_scene *s, dslam_render_state *r, int which);

@@ -309,8 +309,25 @@ class ITMMainEngine {
                                 t == DSLAM_IMAGE_DEPTH ? outFloat->GetData(MEMORYDEVICE_CPU) : nullptr), "dslam_get_image");
   }
 
-  void SaveCurrSceneToMesh(const char *objFileName, const ITMScene<ITMVoxel, ITMVoxelIndex> *) {
-    fprintf(stderr, "SaveCurrSceneToMesh(%s): meshing is an offline export outside the fusion/raycast path (SURVEY 2.1)\n", objFileName);
+  /// SaveCurrSceneToMesh(objFileName, scene) (DenseSlam.cpp:641): meshingEngine->MeshScene(mesh, scene), then
+  /// mesh->WriteOBJ(objFileName).  The marching cubes run on the device; the triangle list comes back in the order
+  /// of upstream's CPU engine, so the file is the same from run to run.
+  void SaveCurrSceneToMesh(const char *objFileName, const ITMScene<ITMVoxel, ITMVoxelIndex> *scene) {
+    ITMMesh mesh((unsigned)settings->numLocalBlocks * 32u);
+    MeshScene(&mesh, scene);
+    mesh.WriteOBJ(objFileName);
+  }
+  /// ITMMeshingEngine::MeshScene(mesh, scene)
+  void MeshScene(ITMMesh *mesh, const ITMScene<ITMVoxel, ITMVoxelIndex> *scene) {
+    int n = 0;
+    dslam_check(dslam_mesh_scene(engine_, scene->handle, (int)mesh->noMaxTriangles, settings->meshWithColour, &n), "dslam_mesh_scene");
+    mesh->noTotalTriangles = (unsigned)n;
+    mesh->triangles.resize((size_t)n + 1);  // never a null data()
+    mesh->colours.resize(settings->meshWithColour ? (size_t)n + 1 : 0);
+    dslam_check(dslam_mesh_download(engine_, &mesh->triangles[0].p0.x, settings->meshWithColour ? &mesh->colours[0].p0.x : nullptr, n),
+                "dslam_mesh_download");
+    mesh->triangles.resize((size_t)n);
+    if (settings->meshWithColour) mesh->colours.resize((size_t)n);
   }
 
   dslam_engine *GetDslamEngine() const { return engine_; }

@@ -3,6 +3,7 @@
 // handle of its device-side counterpart.
 #pragma once
 #include <memory>
+#include <string>
 #include <vector>
 
 #include "ITMRGBDCalib.h"
@@ -104,13 +105,14 @@ class ITMLibSettings {
   TrackerIterationType trackingRegime[8];
   float depthTrackerICPThreshold, depthTrackerTerminationThreshold;
   int hipDeviceIndex;
+  bool meshWithColour;  ///< SaveCurrSceneToMesh writes `v x y z r g b` lines (see ITMMesh)
   // pool sizes (ITMLibDefines.h constants upstream; runtime here)
   int numLocalBlocks, numBuckets, numExcess;
   ITMLibSettings()
       : deviceType(DEVICE_HIP), useSwapping(false), useApproximateRaycast(false), useBilateralFilter(false),
         modelSensorNoise(false), skipPoints(true), sceneParams(0.02f, 100, 0.005f, 0.2f, 3.0f, false),
         noHierarchyLevels(5), noICPRunTillLevel(0), depthTrackerICPThreshold(0.1f * 0.1f),
-        depthTrackerTerminationThreshold(1e-3f), hipDeviceIndex(0),
+        depthTrackerTerminationThreshold(1e-3f), hipDeviceIndex(0), meshWithColour(true),
         numLocalBlocks(SDF_LOCAL_BLOCK_NUM), numBuckets(SDF_BUCKET_NUM), numExcess(SDF_EXCESS_LIST_SIZE) {
     trackingRegime[0] = TRACKER_ITERATION_BOTH; trackingRegime[1] = TRACKER_ITERATION_BOTH;
     trackingRegime[2] = TRACKER_ITERATION_ROTATION; trackingRegime[3] = TRACKER_ITERATION_ROTATION;
@@ -216,6 +218,56 @@ template <class TVoxel, class TIndex> class ITMScene {
     index.lastFreeExcessListId = st.last_free_excess_id;
     if (rs) static_cast<ITMRenderState_VH *>(rs)->noVisibleEntries = st.no_visible_entries;
     if (decayed) *decayed = st.decayed_block_count;
+  }
+};
+
+/// ITMMesh: the triangle list SaveCurrSceneToMesh writes (DenseSlam.cpp:638-643).  Host-side copy of the mesh the
+/// engine built on the device; WriteOBJ / WriteSTL keep upstream's file layout (three `v` lines per triangle, faces
+/// listed with the vertex order reversed).  With colours each `v` line carries r g b in [0, 1] after the position,
+/// the coloured-OBJ convention of the DynSLAM lineage this fork descends from (not knowable from the reference
+/// tree; ITMLibSettings::meshWithColour = false gives upstream v2's plain lines).
+class ITMMesh {
+ public:
+  struct Triangle { Vector3f p0, p1, p2; };
+  unsigned noTotalTriangles;
+  unsigned noMaxTriangles;
+  std::vector<Triangle> triangles, colours;
+  explicit ITMMesh(unsigned maxTriangles) : noTotalTriangles(0), noMaxTriangles(maxTriangles) {}
+  void WriteOBJ(const char *fileName) const {
+    FILE *f = fopen(fileName, "w+");
+    if (f == nullptr) throw std::runtime_error(std::string("ITMMesh::WriteOBJ: cannot open ") + fileName);
+    const bool col = colours.size() == triangles.size() && !colours.empty();
+    for (unsigned i = 0; i < noTotalTriangles; i++) {
+      const Vector3f *p = &triangles[i].p0;
+      for (int k = 0; k < 3; k++) {
+        if (col) {
+          const Vector3f &c = (&colours[i].p0)[k];
+          fprintf(f, "v %f %f %f %f %f %f\n", p[k].x, p[k].y, p[k].z, c.x, c.y, c.z);
+        } else {
+          fprintf(f, "v %f %f %f\n", p[k].x, p[k].y, p[k].z);
+        }
+      }
+    }
+    for (unsigned i = 0; i < noTotalTriangles; i++) fprintf(f, "f %u %u %u\n", i * 3 + 2 + 1, i * 3 + 1 + 1, i * 3 + 0 + 1);
+    fclose(f);
+  }
+  void WriteSTL(const char *fileName) const {
+    FILE *f = fopen(fileName, "wb+");
+    if (f == nullptr) throw std::runtime_error(std::string("ITMMesh::WriteSTL: cannot open ") + fileName);
+    char header[80];
+    memset(header, ' ', sizeof(header));
+    fwrite(header, 1, sizeof(header), f);
+    fwrite(&noTotalTriangles, sizeof(unsigned), 1, f);
+    const float zero[3] = {0.0f, 0.0f, 0.0f};
+    const short attribute = 0;
+    for (unsigned i = 0; i < noTotalTriangles; i++) {
+      fwrite(zero, sizeof(float), 3, f);  // facet normal left to the reader, as upstream does
+      fwrite(&triangles[i].p2, sizeof(float), 3, f);
+      fwrite(&triangles[i].p1, sizeof(float), 3, f);
+      fwrite(&triangles[i].p0, sizeof(float), 3, f);
+      fwrite(&attribute, sizeof(short), 1, f);
+    }
+    fclose(f);
   }
 };
 

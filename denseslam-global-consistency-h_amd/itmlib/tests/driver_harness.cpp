@@ -286,6 +286,8 @@ int main(int argc, char **argv) {
       fwrite(oc_order[i].data(), 8, oc_order[i].size(), o);
       fwrite(&oc_counts[3 * i + 1], 4, 2, o);
     }
+    // DenseSlam::SaveStaticMap (DenseSlam.cpp:638-643): the mesh of the map as an OBJ file
+    if (const char *obj = getenv("DRIVER_HARNESS_MESH_OBJ")) drv.SaveCurrSceneToMesh(obj, currentLocalMap->scene);
     // trailer: the lazily filled host mirrors (view->rgb / view->depth of the last UpdateView, and the tracking
     // state's points map from the last Prepare), read through the same GetData calls the reference driver makes
     {

@@ -328,6 +328,20 @@ int dslam_get_image(dslam_engine *e, const dslam_scene *s, dslam_render_state *r
 int dslam_create_icp_maps(dslam_engine *e, const dslam_scene *s, dslam_render_state *r, const float M[16],
                           const float intrinsics[4], float *out_points_host, float *out_normals_host);
 
+/* ---- meshing export ---------------------------------------------------------------------------- */
+/* ITMMainEngine::SaveCurrSceneToMesh(objFileName, scene) -> ITMMeshingEngine::MeshScene(mesh, scene) (DenseSlam.cpp:
+ * 638-643): marching cubes over every allocated voxel block, in upstream's CPU-engine order (hash
+ * entries ascending, voxels z/y/x, triangles in case-table order), so the output is deterministic.  A cube is
+ * skipped when one of its 8 corner voxels is missing or has sdf == 1 (findPointNeighbors).  max_triangles <= 0
+ * selects ITMMesh's noMaxTriangles = num_local_blocks * 32; like upstream the list saturates at max_triangles - 1.
+ * The mesh stays on the device until dslam_mesh_download: per triangle 3 vertices x (x, y, z) floats in metres
+ * (world frame), and with with_colour the voxel colours interpolated to the same crossings, as (r, g, b) floats
+ * in [0, 1] (the coloured-OBJ form of the DynSLAM lineage; upstream v2 writes positions only). */
+int dslam_mesh_scene(dslam_engine *e, const dslam_scene *s, int max_triangles, int with_colour,
+                     int *out_num_triangles);
+int dslam_mesh_download(dslam_engine *e, float *out_positions_host, float *out_colours_host,
+                        int capacity_triangles);
+
 /* ---- depth tracker (ICP) ---------------------------------------------------------------------- */
 /* trackingController->Track(trackingState, view) (InfiniTamDriver.h:151-163, reached through
  * DenseSlam.cpp:200-206 when the reference runs without ORB-SLAM2 odometry): upstream InfiniTAM v2's

@@ -6,6 +6,7 @@ reference's.  Inputs are the synthetic S-tiny frames; outputs are the map state 
 
     python tests/golden/make_golden.py
 """
+import hashlib
 import os
 import sys
 
@@ -48,6 +49,9 @@ def run(api, pkg, synth, inputs=None):
     colour = api.get_image(s, rs_free, M_last, wl.intr, pkg.IMAGE_COLOUR_FROM_VOLUME)
     shaded = api.get_image(s, rs_free, M_last, wl.intr, pkg.IMAGE_SHADED)
     rng = api.download_range_image(rs_free)[:(wl.H + 7) // 8, :(wl.W + 7) // 8]
+    # meshing export (SaveCurrSceneToMesh): triangle count, the first triangles, and a digest of the whole mesh
+    mesh_pos, mesh_col = api.mesh_scene(s, colour=True)
+    digest = hashlib.sha256(mesh_pos.tobytes() + mesh_col.tobytes()).digest()
     return dict(
         rgba=np.stack([f[0] for f in frames]), depth_mm=np.stack([f[1] for f in frames]),
         poses=np.stack([f[2] for f in frames]), intr=np.asarray(wl.intr, np.float32),
@@ -55,7 +59,9 @@ def run(api, pkg, synth, inputs=None):
                                params.num_local_blocks, params.num_buckets, params.num_excess], np.float64),
         stats=np.array(stats, np.int32), occupied_idx=occ, occupied_pos=h["pos"][occ], occupied_ptr=h["ptr"][occ],
         occupied_offset=h["offset"][occ], visible_ids=vis, voxels_top=vox.view(np.uint64).reshape(N_BLOCKS, 512),
-        raycast_depth=depth, raycast_colour=colour, raycast_shaded=shaded, range_corner=rng)
+        raycast_depth=depth, raycast_colour=colour, raycast_shaded=shaded, range_corner=rng,
+        mesh_count=np.array([len(mesh_pos)], np.int32), mesh_head=mesh_pos[:256].copy(), mesh_head_colour=mesh_col[:256].copy(),
+        mesh_sha256=np.frombuffer(digest, np.uint8).copy())
 
 
 if __name__ == "__main__":

@@ -106,6 +106,11 @@ def _trial(pkg, synth, gpu, oracle, seed):
                 sw = [api.download_swap_states(s) for api, s, *_ in objs.values()]
                 assert np.array_equal(sw[0], sw[1]), f"seed {seed} step {step} after {log[-1]}: swap states"
         util.check_invariants(snaps["gpu"], objs["gpu"][1].params)
+        # the meshing export of whatever map the sequence left behind (decayed holes, swapped-out blocks, clamped
+        # weights ...): same triangles, same order, same colours
+        meshes = {name: api.mesh_scene(s, colour=True) for name, (api, s, *_r) in objs.items()}
+        assert np.array_equal(meshes["gpu"][0], meshes["oracle"][0]), f"seed {seed}: mesh positions"
+        assert np.array_equal(meshes["gpu"][1], meshes["oracle"][1]), f"seed {seed}: mesh colours"
     finally:
         for api, *_ in objs.values():
             api.set_fusion_weight_params()

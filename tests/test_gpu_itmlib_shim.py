@@ -42,7 +42,9 @@ def test_driver_harness_matches_oracle(pkg, synth, oracle, tmp_path, decay, slid
         f.write(np.asarray(wl.intr, np.float32).tobytes())
         f.write(struct.pack("<4f", p.voxel_size, p.mu, p.frustum_min, p.frustum_max))
         f.write(struct.pack("<4i", p.max_w, p.num_local_blocks, p.num_buckets, p.num_excess))
-    res = subprocess.run([HARNESS, str(fin), str(fout), str(decay), str(slide)], capture_output=True, text=True, timeout=120)
+    fobj = tmp_path / "mesh.obj"
+    res = subprocess.run([HARNESS, str(fin), str(fout), str(decay), str(slide)], capture_output=True, text=True, timeout=120,
+                         env=dict(os.environ, DRIVER_HARNESS_MESH_OBJ=str(fobj)))
     assert res.returncode == 0, res.stdout + res.stderr
 
     # same call sequence on the oracle (DenseSlam.cpp:210-232; Decay passes forceAllVoxels=true, InfiniTamDriver.h:280)
@@ -82,6 +84,13 @@ def test_driver_harness_matches_oracle(pkg, synth, oracle, tmp_path, decay, slid
     t_pose, t_res = oracle.track_camera(v, rs, M_last, frames[-2][2], wl.intr)
     assert t_res.iterations > 0 and t_res.valid_points_last > 100
     assert np.abs(g_tracked - t_pose).max() <= 1e-5
+    # SaveCurrSceneToMesh (DenseSlam.cpp:641): upstream's OBJ layout -- three `v` lines per triangle (with the
+    # interpolated voxel colour), then the faces with the vertex order reversed -- of the oracle's mesh, line for line
+    o_pos, o_col = oracle.mesh_scene(s, colour=True)
+    want = ["v %f %f %f %f %f %f" % (*map(float, o_pos[i, k]), *map(float, o_col[i, k])) for i in range(len(o_pos)) for k in range(3)]
+    want += ["f %d %d %d" % (3 * i + 3, 3 * i + 2, 3 * i + 1) for i in range(len(o_pos))]
+    got = open(fobj).read().splitlines()
+    assert len(o_pos) > 1000 and got == want
     # trailer: the shim's host mirrors are filled lazily (first GetData after an update); what a reader sees must be
     # the last UpdateView's images and the last Prepare's maps
     m_rgb, m_depth = struct.unpack_from("<2Q", raw, len(raw) - 24)
