@@ -102,6 +102,14 @@ def main():
         res_holder["r"] = eng.track_camera(vr, rsr, M3, M3, wr.intr)[1]
     out["track_camera"] = timed(eng, track, max(3, reps // 5))
     out["track_camera_iterations"] = res_holder["r"].iterations
+    # meshing export (SaveCurrSceneToMesh) of the street map built above and of the room map
+    import ctypes as C
+    for tag, sc in (("street", scene), ("room", sr)):
+        n = C.c_int(0)
+        for colour in (0, 1):
+            out[f"mesh_scene_{tag}" + ("_colour" if colour else "")] = timed(
+                eng, lambda: eng._call("mesh_scene", eng._engine, sc.ptr, C.c_int(0), C.c_int(colour), C.byref(n)), max(3, reps // 10))
+        out[f"mesh_triangles_{tag}"] = n.value
     print(json.dumps({k: (round(v, 2) if isinstance(v, float) else v) for k, v in out.items()}))
 
 

@@ -12,3 +12,4 @@ python denseslam-global-consistency-h_amd/harness/stress.py 64 > gpurun_out/fina
 python bench.py --sync --steps 100 --warmup 10 --no-cpu-baseline --reint 0 > gpurun_out/final_bench_sync.json 2>/dev/null; grep -o '"value": [0-9.]*' gpurun_out/final_bench_sync.json
 python denseslam-global-consistency-h_amd/harness/side_bench.py 50 > gpurun_out/final_side_bench.json 2>gpurun_out/final_side_bench.err; cat gpurun_out/final_side_bench.json
 python bench.py --host-io --steps 100 --warmup 10 --no-cpu-baseline --reint 0 > gpurun_out/final_bench_hostio.json 2>/dev/null; grep -o "\"value\": [0-9.]*" gpurun_out/final_bench_hostio.json
+python denseslam-global-consistency-h_amd/harness/quality.py 40 > gpurun_out/final_quality.json 2>gpurun_out/final_quality.err; cat gpurun_out/final_quality.json

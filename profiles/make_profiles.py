@@ -8,6 +8,7 @@ gpurun_out/final_stats/             <- rocprofv3 --kernel-trace --stats ... benc
 gpurun_out/final_fetch|final_write/ <- rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --kernel-trace ... bench.py --steps 30 --warmup 5
 gpurun_out/final_stress.json        <- python denseslam-global-consistency-h_amd/harness/stress.py 64
 gpurun_out/final_side_bench.json    <- python denseslam-global-consistency-h_amd/harness/side_bench.py 50
+gpurun_out/final_quality.json       <- python denseslam-global-consistency-h_amd/harness/quality.py 40
 """
 import csv
 import glob
@@ -58,6 +59,9 @@ def main():
     side = os.path.join(OUT, "final_side_bench.json")
     if os.path.exists(side):
         json.dump(last_json_line(side), open(os.path.join(HERE, f"{tag}_side_bench.json"), "w"), indent=1)
+    quality = os.path.join(OUT, "final_quality.json")
+    if os.path.exists(quality):
+        json.dump(last_json_line(quality), open(os.path.join(HERE, f"{tag}_quality.json"), "w"), indent=1)
 
     # HBM traffic of k_integrate from the two PMC passes (MI355X_MICROARCH.md, "HBM / rocprofv3"): counters are in KiB;
     # on gfx950 FETCH_SIZE counts wide (16 B per lane) streaming reads at half their size -> doubled; WRITE_SIZE is exact.
