@@ -144,9 +144,18 @@ def main():
     # render state: the fusion visible list must survive from keyframe to keyframe
     rs_free = eng.create_render_state(scene, wl.W, wl.H)
     view = eng.create_view(wl.W, wl.H)
-    eng.set_async(not args.sync)
+    eng.set_async(not (args.sync or args.host_io))  # --host-io: every call returns with its result, as InfiniTamDriver's do
     rgba_stride = wl.W * wl.H * 4
     depth_stride = wl.W * wl.H * 2
+
+    if args.host_io:
+        # the caller's frames and the image it reads back live in page-locked memory, as upstream's MemoryBlock keeps
+        # every image that has a device side (dslam_host_alloc): uploads and the copy back are plain DMAs
+        rgba_p, depth_p = eng.host_alloc(rgba_h.shape, np.uint8), eng.host_alloc(depth_h.shape, np.int16)
+        rgba_p[...] = rgba_h
+        depth_p[...] = depth_h
+        rgba_h, depth_h = rgba_p, depth_p
+        image_p = eng.host_alloc((wl.H, wl.W), np.float32)
 
     def step(i):
         if args.host_io:
@@ -155,7 +164,7 @@ def main():
             eng.view_update_device(view, rgba_d.data_ptr() + i * rgba_stride, depth_d.data_ptr() + i * depth_stride,
                                    timestamp=float(i))
         eng.process_frame(scene, view, rs, Ms[i], wl.intr)
-        eng.get_image(scene, rs_free, Ms[i], wl.intr, pkg.IMAGE_DEPTH, download=args.host_io)
+        eng.get_image(scene, rs_free, Ms[i], wl.intr, pkg.IMAGE_DEPTH, download=False, out=image_p if args.host_io else None)
 
     for i in range(Wm):
         step(i)
@@ -247,7 +256,7 @@ def main():
                                    f"(BASELINE configs[1]), fusion+raycast only, poses precomputed, voxel "
                                    f"{wl.scene_kwargs['voxel_size']} m, mu {wl.scene_kwargs['mu']} m, frustum "
                                    f"{wl.scene_kwargs['frustum_min']}-{wl.scene_kwargs['frustum_max']} m",
-                       "calls": ("host buffers in, depth image out over PCIe every frame" if args.host_io else
+                       "calls": ("synchronous; page-locked host buffers in, depth image out over PCIe every frame" if args.host_io else
                                  "pipelined (async engine stream)" if not args.sync else "synchronous per call"),
                        "parallelism": "replicas" if world > 1 else "single GPU",
                        "voxel_block_pool": nlb,

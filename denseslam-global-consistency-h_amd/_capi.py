@@ -424,23 +424,27 @@ class CApi:
                    C.byref(res))
         return pose.reshape(4, 4).T.copy(), res
 
-    def _image_call(self, name, scene, rs, M, intr, image_type, download=True):
+    def _image_call(self, name, scene, rs, M, intr, image_type, download=True, out=None):
+        """`out`: an existing (H, W) float32 / (H, W, 4) uint8 array to fill instead of a fresh one (e.g. a page-locked
+        array from host_alloc, which the copy back DMAs into directly)."""
         m, k = self._mi(M, intr)
         out_rgba = out_f = None
-        if download:
+        if download or out is not None:
             if image_type == IMAGE_DEPTH:
-                out_f = np.empty((rs.height, rs.width), dtype=np.float32)
+                out_f = out if out is not None else np.empty((rs.height, rs.width), dtype=np.float32)
+                assert out_f.dtype == np.float32 and out_f.size == rs.height * rs.width and out_f.flags.c_contiguous
             else:
-                out_rgba = np.empty((rs.height, rs.width, 4), dtype=np.uint8)
+                out_rgba = out if out is not None else np.empty((rs.height, rs.width, 4), dtype=np.uint8)
+                assert out_rgba.dtype == np.uint8 and out_rgba.size == rs.height * rs.width * 4 and out_rgba.flags.c_contiguous
         self._call(name, self._engine, scene.ptr, rs.ptr, _fptr(m), _fptr(k), C.c_int(image_type), _vptr(out_rgba),
                    _fptr(out_f))
         return out_f if image_type == IMAGE_DEPTH else out_rgba
 
-    def render_image(self, scene, rs, M, intr, image_type, download=True):
-        return self._image_call("render_image", scene, rs, M, intr, image_type, download)
+    def render_image(self, scene, rs, M, intr, image_type, download=True, out=None):
+        return self._image_call("render_image", scene, rs, M, intr, image_type, download, out)
 
-    def get_image(self, scene, rs, M, intr, image_type, download=True):
-        return self._image_call("get_image", scene, rs, M, intr, image_type, download)
+    def get_image(self, scene, rs, M, intr, image_type, download=True, out=None):
+        return self._image_call("get_image", scene, rs, M, intr, image_type, download, out)
 
     def create_icp_maps(self, scene, rs, M, intr, download=True):
         """trackingController->Prepare.  download=False leaves the maps on the device (all the depth tracker needs)."""
