@@ -288,6 +288,11 @@ int main(int argc, char **argv) {
     }
     // DenseSlam::SaveStaticMap (DenseSlam.cpp:638-643): the mesh of the map as an OBJ file
     if (const char *obj = getenv("DRIVER_HARNESS_MESH_OBJ")) drv.SaveCurrSceneToMesh(obj, currentLocalMap->scene);
+    if (const char *stl = getenv("DRIVER_HARNESS_MESH_STL")) {  // upstream's other writer, same triangle list
+      ITMLib::Objects::ITMMesh mesh((unsigned)ip[1] * 32u);
+      drv.MeshScene(&mesh, currentLocalMap->scene);
+      mesh.WriteSTL(stl);
+    }
     // trailer: the lazily filled host mirrors (view->rgb / view->depth of the last UpdateView, and the tracking
     // state's points map from the last Prepare), read through the same GetData calls the reference driver makes
     {

@@ -44,7 +44,7 @@ def test_driver_harness_matches_oracle(pkg, synth, oracle, tmp_path, decay, slid
         f.write(struct.pack("<4i", p.max_w, p.num_local_blocks, p.num_buckets, p.num_excess))
     fobj = tmp_path / "mesh.obj"
     res = subprocess.run([HARNESS, str(fin), str(fout), str(decay), str(slide)], capture_output=True, text=True, timeout=120,
-                         env=dict(os.environ, DRIVER_HARNESS_MESH_OBJ=str(fobj)))
+                         env=dict(os.environ, DRIVER_HARNESS_MESH_OBJ=str(fobj), DRIVER_HARNESS_MESH_STL=str(tmp_path / "mesh.stl")))
     assert res.returncode == 0, res.stdout + res.stderr
 
     # same call sequence on the oracle (DenseSlam.cpp:210-232; Decay passes forceAllVoxels=true, InfiniTamDriver.h:280)
@@ -91,6 +91,12 @@ def test_driver_harness_matches_oracle(pkg, synth, oracle, tmp_path, decay, slid
     want += ["f %d %d %d" % (3 * i + 3, 3 * i + 2, 3 * i + 1) for i in range(len(o_pos))]
     got = open(fobj).read().splitlines()
     assert len(o_pos) > 1000 and got == want
+    # ITMMesh::WriteSTL: 80-byte header, uint32 count, per triangle a zero normal, p2 p1 p0, a zero attribute
+    stl = open(tmp_path / "mesh.stl", "rb").read()
+    assert struct.unpack_from("<I", stl, 80)[0] == len(o_pos) and len(stl) == 84 + 50 * len(o_pos)
+    rec = np.frombuffer(stl, np.uint8, offset=84).reshape(len(o_pos), 50)
+    assert not rec[:, :12].any() and not rec[:, 48:].any()
+    assert np.array_equal(rec[:, 12:48].copy().view(np.float32).reshape(-1, 3, 3), o_pos[:, ::-1, :])
     # trailer: the shim's host mirrors are filled lazily (first GetData after an update); what a reader sees must be
     # the last UpdateView's images and the last Prepare's maps
     m_rgb, m_depth = struct.unpack_from("<2Q", raw, len(raw) - 24)
