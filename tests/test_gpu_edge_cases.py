@@ -275,3 +275,53 @@ def test_sharded_reintegration_with_abi_pack_unpack(pkg, synth, gpu):
         util.assert_same_state(got, want, f"rank {r} after the exchange")
     # and the shards really were disjoint halves of the work: before the exchange the ranks differed
     assert groups >= 2
+
+
+@pytest.mark.parametrize("size", [(912, 228), (1226, 370), (70, 45)])
+def test_kitti_frame_sizes_and_partial_tiles(pkg, synth, gpu, oracle, size):
+    """The frame sizes of BASELINE configs 2, 3 and 5 (KITTI crop 912x228, full 1226x370; DenseSLAMGUI.cpp:504,
+    scripts/eval_raycast_depth.py:90-92) and a small odd one.  1226, 370, 228, 70 and 45 are not multiples of 8: the
+    last 8x8 ray tile of a row / column is partial and the range image keeps upstream's full-image stride.  Fusion
+    with decay and a sliding window, then every raycast product, against the oracle."""
+    W, H = size
+    oracle.set_threads(16)
+    big = W > 100
+    wl = synth.s_street(W, H) if big else synth.s_room(W, H, scale=4.0)
+    kw = dict(num_local_blocks=0x10000) if big else dict(num_local_blocks=0x800, num_buckets=0x1000, num_excess=0x400)
+    p = pkg.SceneParams(**kw, **wl.scene_kwargs)
+    objs = {}
+    for name, api in (("gpu", gpu), ("oracle", oracle)):
+        s = api.create_scene(p)
+        objs[name] = (api, s, api.create_render_state(s, W, H), api.create_view(W, H), api.create_render_state(s, W, H))
+    n_frames = 5
+    for i in range(n_frames):
+        rgba, mm, M = wl.frame(i)
+        for name, (api, s, rs, v, free) in objs.items():
+            api.view_update(v, rgba, mm, timestamp=float(i))
+            api.process_frame(s, v, rs, M, wl.intr)
+            if api.stats(s, rs)["fusion_fifo_len"] > 3:
+                api.slide_window(s, rs, 3)
+            api.decay(s, rs, 1, 2, True)
+    snaps = {name: util.snapshot(api, s, rs) for name, (api, s, rs, v, free) in objs.items()}
+    util.assert_same_state(snaps["gpu"], snaps["oracle"], f"{W}x{H}")
+    assert snaps["gpu"]["stats"]["no_visible_entries"] > (3000 if big else 50)
+    M = wl.frame(n_frames - 1)[2]
+    out = {}
+    for name, (api, s, rs, v, free) in objs.items():
+        out[name] = dict(depth=api.get_image(s, free, M, wl.intr, pkg.IMAGE_DEPTH),
+                         colour=api.get_image(s, free, M, wl.intr, pkg.IMAGE_COLOUR_FROM_VOLUME),
+                         shaded=api.get_image(s, free, M, wl.intr, pkg.IMAGE_SHADED),
+                         rng=api.download_range_image(free), icp=api.create_icp_maps(s, rs, M, wl.intr),
+                         mm=api.get_depth_image_int16(s, free, M, wl.intr, 256))
+    g, o = out["gpu"], out["oracle"]
+    assert np.array_equal(g["rng"][:(H + 7) // 8, :(W + 7) // 8], o["rng"][:(H + 7) // 8, :(W + 7) // 8])
+    assert np.array_equal(g["depth"] > 0, o["depth"] > 0) and (g["depth"] > 0).mean() > 0.3
+    assert np.abs(g["depth"] - o["depth"]).max() <= 1e-4
+    # the partial tiles at the right and bottom edges are rendered like any other
+    assert W % 8 == 0 or (g["depth"][:, (W // 8) * 8:] > 0).any()
+    assert H % 8 == 0 or (g["depth"][(H // 8) * 8:, :] > 0).any()
+    assert np.abs(g["mm"].astype(int) - o["mm"].astype(int)).max() <= 1
+    for k in ("colour", "shaded"):
+        assert np.abs(g[k].astype(int) - o[k].astype(int)).max() <= 1, k
+    assert np.array_equal(g["icp"][0][..., 3], o["icp"][0][..., 3])
+    assert np.abs(g["icp"][0] - o["icp"][0]).max() <= 1e-4 and np.abs(g["icp"][1] - o["icp"][1]).max() <= 1e-4
