@@ -16,7 +16,7 @@ pytestmark = pytest.mark.gpu
 def _trial(pkg, synth, gpu, oracle, seed):
     rng = np.random.default_rng(seed)
     big = os.environ.get("DSLAM_FUZZ_BIG") == "1"  # one-off hunts: larger images, pools and longer sequences
-    W, H = (int(rng.choice([160, 200])), int(rng.choice([120, 96]))) if big else (int(rng.choice([48, 64, 80])), int(rng.choice([36, 48])))
+    W, H = (int(rng.choice([160, 200])), int(rng.choice([120, 96]))) if big else (int(rng.choice([48, 52, 64, 70, 80])), int(rng.choice([36, 45, 48])))
     wl = synth.s_room(W, H, scale=float(rng.choice([3.0, 4.0, 6.0])))
     kw = dict(wl.scene_kwargs)
     vs = kw["voxel_size"]
