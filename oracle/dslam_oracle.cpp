@@ -1457,6 +1457,8 @@ extern "C" int oracle_create_expected_depths(oracle_engine *eng, const oracle_sc
 namespace {
 // debug counters (oracle_raycast_stats): ray-march steps, interpolated reads, rays
 static long long g_dbg_steps = 0, g_dbg_interp = 0, g_dbg_rays = 0, g_dbg_maxsteps = 0;
+static uint8_t *g_dbg_trace = nullptr;  // optional [W * H * g_dbg_trace_len]: kind of every march step of every ray (analysis)
+static int g_dbg_trace_len = 0;
 static int *g_dbg_pixel_steps = nullptr;  // optional [3 * W * H]: per ray (steps, steps that found no block, runs of such steps)
 
 // castRay
@@ -1492,17 +1494,43 @@ static inline bool cast_ray(const oracle_scene *s, V4f &out, int x, int y, const
   IndexCache cache;
   long long nsteps = 0, ninterp = 0, nmiss = 0, nruns = 0;
   bool prev_miss = false;
+  V3i trace_key = {INT_MAX, INT_MAX, INT_MAX};  // analysis only: block of the last straddling cell's lower corner
+  V3i trace_cache = {INT_MAX, INT_MAX, INT_MAX};
   while (total < total_max) {
     nsteps++;
+    V3i probe_block;
+    point_to_block(V3i{iround(res.x), iround(res.y), iround(res.z)}, probe_block);
+    // (the engine's per-ray block cache is refreshed by the nearest-voxel probe only)
+    const bool probe_cached = probe_block.x == trace_cache.x && probe_block.y == trace_cache.y && probe_block.z == trace_cache.z;
     sdf = read_sdf_uninterp(s, res, hash_found, cache);
+    if (hash_found) trace_cache = probe_block;
+    uint8_t kind = 0;
     if (!hash_found) {
       nmiss++;
       if (!prev_miss) nruns++;
       prev_miss = true;
       step = (float)DSLAM_BLOCK_SIZE;
+      kind = 1;
+      if (g_dbg_trace && nsteps <= g_dbg_trace_len) g_dbg_trace[(size_t)dbg_loc * g_dbg_trace_len + nsteps - 1] = kind;
     } else {
       prev_miss = false;
-      if ((sdf <= 0.1f) && (sdf >= -0.5f)) { sdf = read_sdf_interp(s, res, hash_found, cache); ninterp++; }
+      kind = probe_cached ? 2 : 3;
+      if ((sdf <= 0.1f) && (sdf >= -0.5f)) {
+        if (g_dbg_trace) {  // does the trilinear cell straddle blocks, and is it the neighbourhood of the last such cell?
+          const int x0 = (int)floorf(res.x), y0 = (int)floorf(res.y), z0 = (int)floorf(res.z);
+          V3i lo, hi;
+          point_to_block(V3i{x0, y0, z0}, lo);
+          point_to_block(V3i{x0 + 1, y0 + 1, z0 + 1}, hi);
+          if (lo.x != hi.x || lo.y != hi.y || lo.z != hi.z) {
+            const bool same = lo.x == trace_key.x && lo.y == trace_key.y && lo.z == trace_key.z;
+            kind = (probe_cached ? 4 : 6) + (same ? 1 : 0);  // 4/5: straddling (new / same neighbourhood), 6/7 with a probe
+            trace_key = lo;
+          }
+        }
+        sdf = read_sdf_interp(s, res, hash_found, cache);
+        ninterp++;
+      }
+      if (g_dbg_trace && nsteps <= g_dbg_trace_len) g_dbg_trace[(size_t)dbg_loc * g_dbg_trace_len + nsteps - 1] = kind;
       if (sdf <= 0.0f) break;
       step = std::max(sdf * step_scale, 1.0f);
     }
@@ -2079,6 +2107,10 @@ extern "C" int oracle_upload_visible_ids(oracle_engine *, oracle_render_state *r
 }
 
 extern "C" int oracle_raycast_debug_buffer(int *buf) { g_dbg_pixel_steps = buf; return 0; }
+// analysis aid: per ray and march step a kind byte -- 1 no block, 2 plain (block cached), 3 plain after a probe,
+// 4/5 near-surface cell straddling blocks (new / same 2x2x2 neighbourhood as the ray's previous such step), 6/7 the
+// same after a probe; buf = NULL switches it off
+extern "C" int oracle_raycast_trace_buffer(uint8_t *buf, int steps_per_ray) { g_dbg_trace = buf; g_dbg_trace_len = steps_per_ray; return 0; }
 extern "C" int oracle_raycast_stats(long long *out4, int reset) {
   out4[0] = g_dbg_steps; out4[1] = g_dbg_interp; out4[2] = g_dbg_rays; out4[3] = g_dbg_maxsteps;
   if (reset) { g_dbg_steps = g_dbg_interp = g_dbg_rays = g_dbg_maxsteps = 0; }
