@@ -1498,12 +1498,14 @@ static inline bool cast_ray(const oracle_scene *s, V4f &out, int x, int y, const
   V3i trace_cache = {INT_MAX, INT_MAX, INT_MAX};
   while (total < total_max) {
     nsteps++;
-    V3i probe_block;
-    point_to_block(V3i{iround(res.x), iround(res.y), iround(res.z)}, probe_block);
-    // (the engine's per-ray block cache is refreshed by the nearest-voxel probe only)
-    const bool probe_cached = probe_block.x == trace_cache.x && probe_block.y == trace_cache.y && probe_block.z == trace_cache.z;
+    V3i probe_block = {0, 0, 0};
+    bool probe_cached = false;
+    if (g_dbg_trace) {  // analysis only; (the engine's per-ray block cache is refreshed by the nearest-voxel probe only)
+      point_to_block(V3i{iround(res.x), iround(res.y), iround(res.z)}, probe_block);
+      probe_cached = probe_block.x == trace_cache.x && probe_block.y == trace_cache.y && probe_block.z == trace_cache.z;
+    }
     sdf = read_sdf_uninterp(s, res, hash_found, cache);
-    if (hash_found) trace_cache = probe_block;
+    if (g_dbg_trace && hash_found) trace_cache = probe_block;
     uint8_t kind = 0;
     if (!hash_found) {
       nmiss++;
