@@ -226,12 +226,10 @@ int dslam_scene_create(dslam_engine *e, const dslam_scene_params *p, void *ext_v
   DSLAM_HIP(hipMalloc(&s->counters, sizeof(SceneCounters)));
   if (s->p.use_swapping) {
     DSLAM_HIP(hipMalloc(&s->swap_state, s->n_entries));
-    s->has_stored = (unsigned char *)calloc(s->n_entries, 1);
-    s->stored = (dslam_voxel *)calloc((size_t)s->n_entries * kBlock3, sizeof(dslam_voxel));  // committed lazily
-    if (!s->has_stored || !s->stored) { set_last_error("host global cache allocation failed"); return DSLAM_ERR_INVALID; }
-    DSLAM_HIP(hipMalloc(&s->transfer_dev, (size_t)kTransferBlocks * kBlock3 * sizeof(uint2)));
-    DSLAM_HIP(hipHostMalloc((void **)&s->transfer_host, (size_t)kTransferBlocks * kBlock3 * sizeof(dslam_voxel),
-                            hipHostMallocDefault));
+    s->slot_host = (int *)malloc((size_t)s->n_entries * sizeof(int));
+    if (!s->slot_host) { set_last_error("host global cache allocation failed"); return DSLAM_ERR_INVALID; }
+    for (int i = 0; i < s->n_entries; i++) s->slot_host[i] = -1;
+    DSLAM_HIP(hipMalloc(&s->slab_ptrs_dev, (size_t)kMaxSlabs * sizeof(uint4 *)));
     DSLAM_HIP(hipHostMalloc((void **)&s->transfer_ids_host, (size_t)kTransferBlocks * sizeof(int) * 2, hipHostMallocDefault));
   }
   int rc = ensure_scratch(e, s->n_entries, s->p.num_local_blocks);
@@ -249,11 +247,10 @@ int dslam_scene_destroy(dslam_scene *s) {
   free_dev(s->hash);
   if (!s->voxels_external) free_dev(s->voxels);
   free_dev(s->alloc_list); free_dev(s->excess_list); free_dev(s->last_seen); free_dev(s->masks); free_dev(s->counters);
-  free_dev(s->swap_state); free_dev(s->transfer_dev);
-  if (s->transfer_host) (void)hipHostFree(s->transfer_host);
+  free_dev(s->swap_state); free_dev(s->slab_ptrs_dev);
+  for (uint4 *slab : s->slabs) (void)hipHostFree(slab);
   if (s->transfer_ids_host) (void)hipHostFree(s->transfer_ids_host);
-  free(s->has_stored);
-  free(s->stored);
+  free(s->slot_host);
   delete s;
   return DSLAM_OK;
 }
@@ -265,7 +262,11 @@ int dslam_scene_reset(dslam_engine *e, dslam_scene *s) {
   for (int q = 0; q < 2; q++) { s->ring_head[q] = 0; s->ring_next[q] = 0; s->decay_cursor[q] = 0; }
   s->frame_counter = 0;
   s->last_swapped_in = s->last_swapped_out = 0;
-  if (s->has_stored) memset(s->has_stored, 0, s->n_entries);
+  if (s->slot_host) {  // the slabs stay; their slots are dealt again from the start
+    DSLAM_HIP(hipStreamSynchronize(e->stream));
+    for (int i = 0; i < s->n_entries; i++) s->slot_host[i] = -1;
+    s->next_slot = 0;
+  }
   return finish_call(e);
 }
 
@@ -984,10 +985,14 @@ int dslam_download_last_seen(dslam_engine *e, const dslam_scene *s, int32_t *out
   return d2h(e, out, s->last_seen, (size_t)s->p.num_local_blocks * sizeof(int));
 }
 int dslam_download_stored_block(dslam_engine *e, const dslam_scene *s, int entry, dslam_voxel *out) {
-  DSLAM_REQUIRE(e && s && s->stored && entry >= 0 && entry < s->n_entries, "bad entry / no global cache");
-  DSLAM_HIP(hipStreamSynchronize(e->stream));
-  if (out) memcpy(out, s->stored + (size_t)entry * kBlock3, kBlock3 * sizeof(dslam_voxel));
-  return s->has_stored[entry] ? 1 : 0;
+  DSLAM_REQUIRE(e && s && s->slot_host && entry >= 0 && entry < s->n_entries, "bad entry / no global cache");
+  DSLAM_HIP(hipStreamSynchronize(e->stream));  // the swap kernels write the host slabs directly
+  const int slot = s->slot_host[entry];
+  if (out) {
+    if (slot >= 0) memcpy(out, s->slabs[slot >> kSlabShift] + (size_t)(slot & (kSlabBlocks - 1)) * (kBlock3 / 2), kBlock3 * sizeof(dslam_voxel));
+    else memset(out, 0, kBlock3 * sizeof(dslam_voxel));
+  }
+  return slot >= 0 ? 1 : 0;
 }
 int dslam_download_alloc_scratch(dslam_engine *e, const dslam_scene *s, uint8_t *types, int16_t *coords) {
   DSLAM_REQUIRE(e && s && e->scratch_entries >= s->n_entries, "no allocation pass has run");

@@ -21,6 +21,9 @@ constexpr float kFarAway = 999999.9f;
 constexpr float kVeryClose = 0.05f;
 constexpr int kMaxRenderingBlocks = 65536 * 4;
 constexpr int kTransferBlocks = 0x1000;
+constexpr int kSlabShift = 14;                 // host-store slab = 0x4000 blocks = 64 MiB of page-locked memory
+constexpr int kSlabBlocks = 1 << kSlabShift;
+constexpr int kMaxSlabs = 512;                 // 8.4 M blocks: more than any table has entries
 
 struct __attribute__((aligned(16))) HashEntry {
   short pos[3];

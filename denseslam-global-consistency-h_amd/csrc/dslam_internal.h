@@ -97,11 +97,13 @@ struct dslam_scene {
   int frame_counter = 0;
   // ITMGlobalCache
   unsigned char *swap_state = nullptr;  // device [entries]
-  unsigned char *has_stored = nullptr;  // host   [entries]
-  dslam_voxel *stored = nullptr;        // host   [entries * 512], lazily committed
-  uint2 *transfer_dev = nullptr;        // device [kTransferBlocks * 512]
-  dslam_voxel *transfer_host = nullptr; // pinned [kTransferBlocks * 512]
-  int *transfer_ids_host = nullptr;     // pinned [kTransferBlocks]
+  // host store of swapped-out blocks: page-locked slabs the kernels read and write directly over PCIe (no staging
+  // copy, no host memcpy); an entry's block lives in slot slot_host[entry], slots are dealt in swap-out order
+  std::vector<uint4 *> slabs;           // pinned, kSlabBlocks blocks each, allocated as the store grows
+  uint4 **slab_ptrs_dev = nullptr;      // device [kMaxSlabs]: the same pointers for the kernels
+  int *slot_host = nullptr;             // host   [entries]: slot of the entry's stored block, -1 = none
+  int next_slot = 0;
+  int *transfer_ids_host = nullptr;     // pinned [2 * kTransferBlocks]: entry ids of a batch, then their slots
   int last_swapped_in = 0, last_swapped_out = 0;
   int shard = 0, num_shards = 1, chunk_blocks = 256;
   int shard_first = 0, shard_count = -1;  // contiguous slot range (count < 0: off)

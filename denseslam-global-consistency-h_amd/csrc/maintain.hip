@@ -401,9 +401,16 @@ __device__ __forceinline__ void combine_voxel(unsigned slo, unsigned shi, unsign
   }
 }
 
-__global__ __launch_bounds__(256) void k_swap_merge(const int *__restrict__ ids, const int *__restrict__ has_synced,
+// address of a stored block in the page-locked host slabs
+__device__ __forceinline__ uint4 *stored_block(uint4 *const *slabs, int slot) {
+  return slabs[slot >> kSlabShift] + (size_t)(slot & (kSlabBlocks - 1)) * (kBlock3 / 2);
+}
+
+// merge the host copies of ids[0..n) into their (re-allocated) blocks; the stored blocks are read straight from the
+// host slabs over PCIe (slot < 0: the entry has no host copy)
+__global__ __launch_bounds__(256) void k_swap_merge(const int *__restrict__ ids, const int *__restrict__ slots,
                                                     int n, const HashEntry *__restrict__ hash, uint4 *voxels16,
-                                                    const uint4 *__restrict__ transfer16, unsigned char *swap_state,
+                                                    uint4 *const *__restrict__ slabs, unsigned char *swap_state,
                                                     int maxW) {
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane((int)((blockIdx.x * 256 + threadIdx.x) >> 6));
@@ -411,15 +418,18 @@ __global__ __launch_bounds__(256) void k_swap_merge(const int *__restrict__ ids,
   for (int i = wave; i < n; i += n_waves) {
     const int t = ids[i];
     const int ptr = hash[t].ptr;
-    if (has_synced[i] && ptr >= 0) {
+    const int slot = slots[i];
+    if (slot >= 0 && ptr >= 0) {
       uint4 *blk = voxels16 + (size_t)ptr * (kBlock3 / 2);
-      const uint4 *src = transfer16 + (size_t)i * (kBlock3 / 2);
+      const uint4 *src = stored_block(slabs, slot);
+      uint4 sv[4];
+#pragma unroll
+      for (int j = 0; j < 4; j++) sv[j] = src[j * 64 + lane];  // all four PCIe reads in flight
 #pragma unroll
       for (int j = 0; j < 4; j++) {
         uint4 d = blk[j * 64 + lane];
-        const uint4 sv = src[j * 64 + lane];
-        combine_voxel(sv.x, sv.y, d.x, d.y, maxW);
-        combine_voxel(sv.z, sv.w, d.z, d.w, maxW);
+        combine_voxel(sv[j].x, sv[j].y, d.x, d.y, maxW);
+        combine_voxel(sv[j].z, sv[j].w, d.z, d.w, maxW);
         blk[j * 64 + lane] = d;
       }
     }
@@ -427,9 +437,11 @@ __global__ __launch_bounds__(256) void k_swap_merge(const int *__restrict__ ids,
   }
 }
 
-// pack selected blocks into the transfer buffer, reset them, give their slots back, mark the entries swapped out
-__global__ __launch_bounds__(256) void k_swap_pack(const int *__restrict__ ids, int n, HashEntry *hash, uint4 *voxels16,
-                                                   uint4 *transfer16, int *alloc_list, unsigned long long *masks,
+// write selected blocks to their host slots (over PCIe, straight from the kernel), reset them, give their voxel-block
+// slots back, mark the entries swapped out
+__global__ __launch_bounds__(256) void k_swap_pack(const int *__restrict__ ids, const int *__restrict__ slots, int n,
+                                                   HashEntry *hash, uint4 *voxels16, uint4 *const *__restrict__ slabs,
+                                                   int *alloc_list, unsigned long long *masks,
                                                    int *last_seen, int words, unsigned char *swap_state,
                                                    unsigned char *vis_type, SceneCounters *cnt) {
   const int lane = threadIdx.x & 63;
@@ -441,7 +453,7 @@ __global__ __launch_bounds__(256) void k_swap_pack(const int *__restrict__ ids, 
     const int t = ids[i];
     const int ptr = hash[t].ptr;
     uint4 *blk = voxels16 + (size_t)ptr * (kBlock3 / 2);
-    uint4 *dst = transfer16 + (size_t)i * (kBlock3 / 2);
+    uint4 *dst = stored_block(slabs, slots[i]);
 #pragma unroll
     for (int j = 0; j < 4; j++) {
       dst[j * 64 + lane] = blk[j * 64 + lane];
@@ -489,46 +501,63 @@ static int swap_select_to_host(dslam_engine *e, dslam_scene *s, const unsigned c
   return DSLAM_OK;
 }
 
-// host: gather stored blocks for ids[0..n) into the pinned transfer buffer, upload, merge on the device
-static int merge_from_host(dslam_engine *e, dslam_scene *s, const MaintScratch &m, int n) {
-  int *ids = s->transfer_ids_host, *synced = s->transfer_ids_host + kTransferBlocks;
-  int any = 0;
-  for (int i = 0; i < n; i++) {
-    synced[i] = s->has_stored[ids[i]] ? 1 : 0;
-    if (synced[i]) {
-      memcpy(s->transfer_host + (size_t)i * kBlock3, s->stored + (size_t)ids[i] * kBlock3, kBlock3 * sizeof(dslam_voxel));
-      any = 1;
-    }
-  }
-  int *synced_dev = m.rem_list;  // free int scratch
-  DSLAM_HIP(hipMemcpyAsync(synced_dev, synced, (size_t)n * sizeof(int), hipMemcpyHostToDevice, e->stream));
-  if (any)
-    DSLAM_HIP(hipMemcpyAsync(s->transfer_dev, s->transfer_host, (size_t)n * kBlock3 * sizeof(uint2), hipMemcpyHostToDevice,
-                             e->stream));
-  hipLaunchKernelGGL(k_swap_merge, dim3(1024), dim3(256), 0, e->stream, m.cand_list, synced_dev, n, s->hash,
-                     reinterpret_cast<uint4 *>(s->voxels), reinterpret_cast<const uint4 *>(s->transfer_dev), s->swap_state,
-                     s->p.max_w);
-  DSLAM_HIP(hipGetLastError());
-  DSLAM_HIP(hipStreamSynchronize(e->stream));  // the pinned buffers are reused by the next batch
+// one more page-locked slab for the host store; its pointer goes to the device table the kernels index
+static int add_slab(dslam_engine *e, dslam_scene *s) {
+  if ((int)s->slabs.size() >= kMaxSlabs) { set_last_error("host global cache: slab table full"); return DSLAM_ERR_INVALID; }
+  uint4 *slab = nullptr;
+  DSLAM_HIP(hipHostMalloc((void **)&slab, (size_t)kSlabBlocks * kBlock3 * sizeof(uint2), hipHostMallocDefault));
+  s->slabs.push_back(slab);
+  DSLAM_HIP(hipMemcpyAsync(s->slab_ptrs_dev + (s->slabs.size() - 1), &s->slabs.back(), sizeof(uint4 *), hipMemcpyHostToDevice,
+                           e->stream));
+  DSLAM_HIP(hipStreamSynchronize(e->stream));  // (the source is a vector element)
   return DSLAM_OK;
 }
 
-// device: pack ids[0..n) (already in m.cand_list), download, store on the host
+// slots of ids[0..n) into the second half of the pinned id buffer and on to the device; `assign`: entries without a
+// host copy get the next free slot (swap-out), otherwise they keep -1 (swap-in of an entry that was never stored)
+static int batch_slots_to_device(dslam_engine *e, dslam_scene *s, int n, bool assign, int *slots_dev) {
+  const int *ids = s->transfer_ids_host;
+  int *slots = s->transfer_ids_host + kTransferBlocks;
+  for (int i = 0; i < n; i++) {
+    int slot = s->slot_host[ids[i]];
+    if (slot < 0 && assign) {
+      slot = s->next_slot++;
+      while ((slot >> kSlabShift) >= (int)s->slabs.size()) {
+        int rc = add_slab(e, s);
+        if (rc) return rc;
+      }
+      s->slot_host[ids[i]] = slot;
+    }
+    slots[i] = slot;
+  }
+  DSLAM_HIP(hipMemcpyAsync(slots_dev, slots, (size_t)n * sizeof(int), hipMemcpyHostToDevice, e->stream));
+  return DSLAM_OK;
+}
+
+// merge the host copies of ids[0..n) (ids in m.cand_list and in the pinned id buffer) into the map
+static int merge_from_host(dslam_engine *e, dslam_scene *s, const MaintScratch &m, int n) {
+  int *slots_dev = m.rem_list;  // free int scratch
+  int rc = batch_slots_to_device(e, s, n, false, slots_dev);
+  if (rc) return rc;
+  hipLaunchKernelGGL(k_swap_merge, dim3(1024), dim3(256), 0, e->stream, m.cand_list, slots_dev, n, s->hash,
+                     reinterpret_cast<uint4 *>(s->voxels), s->slab_ptrs_dev, s->swap_state, s->p.max_w);
+  DSLAM_HIP(hipGetLastError());
+  DSLAM_HIP(hipStreamSynchronize(e->stream));  // the pinned id / slot buffer is reused by the next batch
+  return DSLAM_OK;
+}
+
+// write ids[0..n) (in m.cand_list and in the pinned id buffer) to the host store and release their voxel blocks
 static int pack_to_host(dslam_engine *e, dslam_scene *s, unsigned char *vis_type, const MaintScratch &m, int n,
                         int add_slid) {
-  hipLaunchKernelGGL(k_swap_pack, dim3(1024), dim3(256), 0, e->stream, m.cand_list, n, s->hash,
-                     reinterpret_cast<uint4 *>(s->voxels), reinterpret_cast<uint4 *>(s->transfer_dev), s->alloc_list, s->masks,
+  int *slots_dev = m.rem_list;
+  int rc = batch_slots_to_device(e, s, n, true, slots_dev);
+  if (rc) return rc;
+  hipLaunchKernelGGL(k_swap_pack, dim3(1024), dim3(256), 0, e->stream, m.cand_list, slots_dev, n, s->hash,
+                     reinterpret_cast<uint4 *>(s->voxels), s->slab_ptrs_dev, s->alloc_list, s->masks,
                      s->last_seen, s->history_words, s->swap_state, vis_type, s->counters);
   hipLaunchKernelGGL(k_add_last_free, dim3(1), dim3(64), 0, e->stream, s->counters, n, add_slid);
   DSLAM_HIP(hipGetLastError());
-  DSLAM_HIP(hipMemcpyAsync(s->transfer_host, s->transfer_dev, (size_t)n * kBlock3 * sizeof(uint2), hipMemcpyDeviceToHost,
-                           e->stream));
-  DSLAM_HIP(hipStreamSynchronize(e->stream));
-  const int *ids = s->transfer_ids_host;
-  for (int i = 0; i < n; i++) {
-    memcpy(s->stored + (size_t)ids[i] * kBlock3, s->transfer_host + (size_t)i * kBlock3, kBlock3 * sizeof(dslam_voxel));
-    s->has_stored[ids[i]] = 1;
-  }
+  DSLAM_HIP(hipStreamSynchronize(e->stream));  // the pinned id / slot buffer is reused by the next batch
   return DSLAM_OK;
 }
 

@@ -1,0 +1,181 @@
+"""The other HBM-streaming rows of SURVEY.md 8(d) on the S-stress map (every one of 0x40000 voxel blocks allocated on
+a dense lattice, 1 GiB of voxels): de-integration, the decay sweeps, sliding-window release, scene reset, the swap
+transfers over PCIe -- wall clock around synchronous engine calls with their algorithmic bytes (a call is several
+kernels; the per-kernel split of the same run is the rocprofv3 summary next to this file's JSON in profiles/) -- and the
+latency-bound ones as rates: rays/s of the raycast and pixels/s of the allocation pass on the bench's S-street frames.
+
+    python denseslam-global-consistency-h_amd/harness/maint_bench.py        # one JSON line
+"""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+import __graft_entry__ as ge  # noqa: E402
+
+BLOCK_BYTES = 4096
+
+
+def timed(eng, fn):
+    eng.synchronize()
+    t0 = time.perf_counter()
+    fn()
+    eng.synchronize()
+    return (time.perf_counter() - t0) * 1e6
+
+
+def entry(us, nbytes, what):
+    return {"us": round(us, 1), "algorithmic_bytes": int(nbytes), "GBps": round(nbytes / us / 1e3, 1), "what": what}
+
+
+def lattice_scene(pkg, eng, stress, n_side, swapping, W, H):
+    n = n_side ** 3
+    # frustum_max lies in front of the 30 m depth plane the frames show: the allocation pass then marks nothing (no
+    # failed requests on the full pool, no unallocated entries on the visible list) while integration, which has no
+    # frustum test, still updates every voxel
+    params = pkg.SceneParams(voxel_size=0.01, mu=0.04, max_w=100, frustum_min=0.2, frustum_max=20.0,
+                             num_local_blocks=n, num_buckets=0x100000, num_excess=0x20000, use_swapping=int(swapping))
+    scene = eng.create_scene(params)
+    rs = eng.create_render_state(scene, W, H)
+    table, visible, excess_list, last_free_ex = stress.build_lattice_state(pkg, n_side, params.num_buckets, params.num_excess)
+    eng.upload_scene_state(scene, hash_table=table, allocation_list=np.arange(n, dtype=np.int32), last_free_block_id=-1,
+                           excess_list=excess_list, last_free_excess_id=last_free_ex)
+    eng.upload_visible_ids(rs, visible)
+    return scene, rs, n, visible
+
+
+def main():
+    pkg = ge.load_package()
+    from dslam_amd.harness import stress, synth
+    eng = pkg.open_engine(0)
+    W, H = 640, 480
+    n_side = int(sys.argv[1]) if len(sys.argv) > 1 else 64
+    out = {"map": f"S-stress lattice {n_side}^3 blocks ({n_side ** 3 * BLOCK_BYTES / 2 ** 30:.2f} GiB of voxels), 640x480 frames",
+           "unit": "us per synchronous call (wall clock); GBps = algorithmic bytes / that time"}
+    view = eng.create_view(W, H)
+    far = np.full((H, W), 30000, dtype=np.int16)   # every voxel lies in front of the surface: all are updated
+    none = np.zeros((H, W), dtype=np.int16)        # an empty depth image: nothing allocated, nothing visible
+    rgba = np.full((H, W, 4), 128, dtype=np.uint8)
+    M_see = np.eye(4, dtype=np.float32)
+    M_away = np.diag([-1.0, 1.0, -1.0, 1.0]).astype(np.float32)  # looking the other way
+    intr = np.array([100.0, 100.0, (W - 1) / 2.0, (H - 1) / 2.0], np.float32)
+
+    scene, rs, n, visible = lattice_scene(pkg, eng, stress, n_side, False, W, H)
+    vox_bytes = n * BLOCK_BYTES
+    frame_bytes = 8212.0 * n + 8.0 * W * H
+
+    def see(depth=far):
+        # the lattice is not next to the observed surface, so only "was visible last frame and is still in the frustum"
+        # keeps it on the visible list: after looking away the list is put back by hand
+        eng.upload_visible_ids(rs, visible)
+        eng.view_update(view, rgba, depth)
+        eng.process_frame(scene, view, rs, M_see, intr)
+        assert eng.stats(scene, rs)["no_visible_entries"] == n
+
+    def look_away():
+        eng.view_update(view, rgba, none)
+        eng.process_frame(scene, view, rs, M_away, intr)
+
+    see()  # warm-up, weights 1
+    eng.view_update(view, rgba, far)
+    out["process_frame_all_visible"] = entry(min(timed(eng, lambda: eng.process_frame(scene, view, rs, M_see, intr)) for _ in range(3)),
+                                             frame_bytes, "allocation sweeps + integration of all blocks (A6 + A7)")
+    out["deprocess_frame_all_visible"] = entry(min(timed(eng, lambda: eng.deprocess_frame(scene, view, rs, M_see, intr)) for _ in range(3)),
+                                               frame_bytes, "visible-list pass + de-integration of all blocks (A8)")
+    assert eng.stats(scene, rs)["no_visible_entries"] == n
+    w = eng.download_voxel_blocks(scene, n // 2, 64)["w_depth"]
+    assert (w == 1).all(), "1 + 3 fusions - 3 de-integrations must leave weight 1 everywhere"
+    # Decay, full sweep (the reference's per-keyframe call passes forceAllVoxels = true): blocks not seen for min_age
+    # keyframes are read once; with max_weight 0 no voxel qualifies, so this is the pure 1 GiB read sweep
+    reps = []
+    for _ in range(3):
+        see()
+        look_away(); look_away()
+        reps.append(timed(eng, lambda: eng.decay(scene, rs, 0, 2, True)))
+    out["decay_full_sweep_read_only"] = entry(min(reps), vox_bytes + 4.0 * n, "A10 full sweep, nothing to decay: 4 KiB read + age per block")
+    assert eng.stats(scene, rs)["decayed_block_count"] == 0
+    assert (eng.download_last_seen(scene) <= -2).all(), "the sweep must have visited every block"
+    # everything decays: weights are small, max_weight 100 zeroes every voxel and frees every block
+    see()
+    look_away(); look_away()
+    t = timed(eng, lambda: eng.decay(scene, rs, 100, 2, True))
+    st = eng.stats(scene, rs)
+    assert st["decayed_block_count"] == n
+    out["decay_full_sweep_everything_freed"] = entry(t, 2.0 * vox_bytes + 40.0 * n,
+                                                     f"A10: 4 KiB read + 4 KiB reset + unlink per block; {st['decayed_block_count']} blocks freed")
+    out["reset_scene"] = entry(min(timed(eng, lambda: eng.reset_scene(scene)) for _ in range(3)),
+                               n * BLOCK_BYTES + 16.0 * (0x100000 + 0x20000) + 4.0 * (n + 0x20000), "A13: voxels, hash table, both free lists")
+    del scene, rs
+
+    # Decay, aged-list mode (forceAllVoxels = false): the one visible list queued min_age keyframes ago holds every block
+    scene, rs, n, visible = lattice_scene(pkg, eng, stress, n_side, False, W, H)
+    see()
+    look_away(); look_away()
+    out["decay_aged_list_read_only"] = entry(timed(eng, lambda: eng.decay(scene, rs, 0, 2, False)), vox_bytes + 20.0 * n,
+                                             "A10 aged-list mode, one list of all blocks: 4 KiB read + list/entry words per block")
+    del scene, rs
+
+    # sliding window: a map whose blocks were last seen max_age + 1 keyframes ago is released in one call
+    scene, rs, n, visible = lattice_scene(pkg, eng, stress, n_side, False, W, H)
+    see()
+    for _ in range(3):
+        look_away()
+    t = timed(eng, lambda: eng.slide_window(scene, rs, 2))
+    st = eng.stats(scene, rs)
+    out["slide_window_release_all"] = entry(t, vox_bytes + 40.0 * n, f"A11: 4 KiB reset + unlink + free-list push per block; {st['slid_block_count']} blocks released")
+    del scene, rs
+
+    # swapping: 0x1000 blocks (16 MiB) per transfer and direction (ITMGlobalCache), PCIe
+    scene, rs, n, visible = lattice_scene(pkg, eng, stress, n_side, True, W, H)
+    see()
+    # every entry seen for the first time is queued for a merge with its (non-existent) host copy: drain that queue, so
+    # that the swap-in batches measured below are blocks that really come back from the host
+    while eng.stats(scene, rs)["last_swapped_in"] > 0:
+        eng.swap_in(scene, rs)
+    look_away()   # the lattice leaves the view: process_frame's swap-out moves the first batch already
+    def batches(fn, key):
+        res = []
+        for _ in range(5):
+            t = timed(eng, fn)
+            res.append((eng.stats(scene, rs)[key], t))
+        return [r for r in res if r[0] > 0]
+
+    moved = batches(lambda: eng.swap_out(scene, rs), "last_swapped_out")
+    if moved:
+        nb, t = moved[0][0], float(np.median([q[1] for q in moved if q[0] == moved[0][0]]))
+        out["swap_out_first_touch"] = entry(moved[0][1], nb * BLOCK_BYTES, "first batch (includes allocating the first 64 MiB page-locked slab)")
+        out["swap_out_batch"] = entry(t, nb * BLOCK_BYTES, f"A12 swap-out batch: {nb} blocks device -> host in one call (selection sweep + a kernel that writes the page-locked host store directly)")
+    eng.upload_visible_ids(rs, visible)
+    eng.view_update(view, rgba, far)
+    eng.process_frame(scene, view, rs, M_see, intr)   # looks back: blocks parked on the host are wanted again
+    back = batches(lambda: eng.swap_in(scene, rs), "last_swapped_in")
+    if back:
+        nb, t = back[0][0], float(np.median([q[1] for q in back if q[0] == back[0][0]]))
+        out["swap_in_batch"] = entry(t, nb * BLOCK_BYTES, f"A12 swap-in batch: {nb} blocks host -> device in one call (selection sweep + a merge kernel that reads the page-locked host store directly)")
+    del scene, rs
+
+    # latency-bound rows as rates, on the bench's S-street frames
+    wl = synth.s_street(W, H)
+    p = pkg.SceneParams(**wl.scene_kwargs)
+    scene = eng.create_scene(p)
+    rs, rsf = eng.create_render_state(scene, W, H), eng.create_render_state(scene, W, H)
+    frames = [wl.frame(i) for i in range(40)]
+    for i, (c, mm, M) in enumerate(frames):
+        eng.view_update(view, c, mm, timestamp=float(i))
+        eng.process_frame(scene, view, rs, M, wl.intr)
+    M = frames[-1][2]
+    t = min(timed(eng, lambda: eng.get_image(scene, rsf, M, wl.intr, pkg.IMAGE_DEPTH, download=False)) for _ in range(20))
+    out["get_image_depth"] = {"us": round(t, 1), "rays_per_s": round(W * H / t * 1e6), "what": "A14: FindVisibleBlocks + CreateExpectedDepths + march of 640x480 rays"}
+    eng.view_update(view, frames[-1][0], frames[-1][1])
+    t = min(timed(eng, lambda: eng.allocate_scene_from_depth(scene, view, rs, M, wl.intr)) for _ in range(20))
+    out["allocate_scene_from_depth"] = {"us": round(t, 1), "pixels_per_s": round(W * H / t * 1e6),
+                                        "table_bytes_swept": 2 * 16 * (0x100000 + 0x20000), "what": "A6: mark + commit + visible list (two sweeps of the 18.9 MB table)"}
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

@@ -13,3 +13,4 @@ python bench.py --sync --steps 100 --warmup 10 --no-cpu-baseline --reint 0 > gpu
 python denseslam-global-consistency-h_amd/harness/side_bench.py 50 > gpurun_out/final_side_bench.json 2>gpurun_out/final_side_bench.err; cat gpurun_out/final_side_bench.json
 python bench.py --host-io --steps 100 --warmup 10 --no-cpu-baseline --reint 0 > gpurun_out/final_bench_hostio.json 2>/dev/null; grep -o "\"value\": [0-9.]*" gpurun_out/final_bench_hostio.json
 python denseslam-global-consistency-h_amd/harness/quality.py 40 > gpurun_out/final_quality.json 2>gpurun_out/final_quality.err; cat gpurun_out/final_quality.json
+python denseslam-global-consistency-h_amd/harness/maint_bench.py > gpurun_out/final_maintenance.json 2>gpurun_out/final_maintenance.err; cat gpurun_out/final_maintenance.json

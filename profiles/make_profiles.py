@@ -59,6 +59,9 @@ def main():
     side = os.path.join(OUT, "final_side_bench.json")
     if os.path.exists(side):
         json.dump(last_json_line(side), open(os.path.join(HERE, f"{tag}_side_bench.json"), "w"), indent=1)
+    maint = os.path.join(OUT, "final_maintenance.json")
+    if os.path.exists(maint):
+        json.dump(last_json_line(maint), open(os.path.join(HERE, f"{tag}_maintenance.json"), "w"), indent=1)
     quality = os.path.join(OUT, "final_quality.json")
     if os.path.exists(quality):
         json.dump(last_json_line(quality), open(os.path.join(HERE, f"{tag}_quality.json"), "w"), indent=1)
