@@ -174,6 +174,38 @@ def main():
     t = min(timed(eng, lambda: eng.allocate_scene_from_depth(scene, view, rs, M, wl.intr)) for _ in range(20))
     out["allocate_scene_from_depth"] = {"us": round(t, 1), "pixels_per_s": round(W * H / t * 1e6),
                                         "table_bytes_swept": 2 * 16 * (0x100000 + 0x20000), "what": "A6: mark + commit + visible list (two sweeps of the 18.9 MB table)"}
+    # BASELINE configs[2]: the same keyframes with the sliding-window memory path switched on (SURVEY 8d's parameters:
+    # Decay(maxWeight 3, minAge 30, forceAll) after every keyframe, window of 50 keyframes), with and without host
+    # swapping; synchronous calls, one free-view depth raycast per keyframe, frames already on the device side of
+    # view_update's upload (the upload is part of the time)
+    del scene, rs, rsf
+    frames = frames + [wl.frame(i) for i in range(40, 120)]
+
+    def memory_path(swapping, window):
+        ps = pkg.SceneParams(use_swapping=int(swapping), **wl.scene_kwargs)
+        sc = eng.create_scene(ps)
+        r1, r2 = eng.create_render_state(sc, W, H), eng.create_render_state(sc, W, H)
+        t0 = None
+        for i, (c, mm, M_i) in enumerate(frames):
+            if i == 70:
+                eng.synchronize()
+                t0 = time.perf_counter()
+            eng.view_update(view, c, mm, timestamp=float(i))
+            eng.process_frame(sc, view, r1, M_i, wl.intr)
+            if window:
+                if eng.stats(sc, r1)["fusion_fifo_len"] > 50:
+                    eng.slide_window(sc, r1, 50)
+                eng.decay(sc, r1, 3, 30, True)
+            eng.get_image(sc, r2, M_i, wl.intr, pkg.IMAGE_DEPTH, download=False)
+        eng.synchronize()
+        st = eng.stats(sc, r1)
+        return {"us_per_keyframe": round((time.perf_counter() - t0) / (len(frames) - 70) * 1e6, 1),
+                "allocated_blocks_end": st["num_allocated_blocks"] - 1 - st["last_free_block_id"],
+                "decayed_blocks": st["decayed_block_count"], "slid_blocks": st["slid_block_count"]}
+
+    out["keyframe_loop_plain"] = memory_path(False, False)
+    out["keyframe_loop_decay_window"] = memory_path(False, True)
+    out["keyframe_loop_decay_window_swapping"] = memory_path(True, True)
     print(json.dumps(out))
 
 
