@@ -249,11 +249,10 @@ static MaintScratch carve(dslam_engine *e, int N) {
 
 static int rebuild_visible_list(dslam_engine *e, dslam_render_state *r) {
   const int N = r->n_entries, n_tiles = num_tiles(N);
+  // (each apply workgroup sums the preceding tile counts itself: no scan launch in between)
   hipLaunchKernelGGL(k_flag_count, dim3(n_tiles), dim3(256), 0, e->stream, r->visible_type, N, e->tile_counts);
-  hipLaunchKernelGGL(k_scan_count, dim3(1), dim3(1024), 0, e->stream, e->tile_counts, e->tile_offsets, n_tiles,
-                     &r->counters->no_visible, r->n_local);
-  hipLaunchKernelGGL(k_compact_apply, dim3(n_tiles), dim3(256), 0, e->stream, r->visible_type, N, e->tile_offsets,
-                     r->visible_ids, r->n_local);
+  hipLaunchKernelGGL(k_compact_apply_fused, dim3(n_tiles), dim3(256), 0, e->stream, r->visible_type, N, e->tile_counts,
+                     r->visible_ids, r->n_local, &r->counters->no_visible);
   DSLAM_HIP(hipGetLastError());
   return DSLAM_OK;
 }
@@ -264,10 +263,8 @@ static int release_flagged(dslam_engine *e, dslam_scene *s, dslam_render_state *
   const int N = s->n_entries, n_tiles = num_tiles(N);
   const int x_tiles = num_tiles(s->p.num_excess);
   hipLaunchKernelGGL(k_flag_count, dim3(n_tiles), dim3(256), 0, e->stream, rem_flags, N, e->tile_counts);
-  hipLaunchKernelGGL(k_scan_count, dim3(1), dim3(1024), 0, e->stream, e->tile_counts, e->tile_offsets, n_tiles,
-                     &s->counters->remove_count, s->p.num_local_blocks);
-  hipLaunchKernelGGL(k_compact_apply, dim3(n_tiles), dim3(256), 0, e->stream, rem_flags, N, e->tile_offsets, m.rem_list,
-                     s->p.num_local_blocks);
+  hipLaunchKernelGGL(k_compact_apply_fused, dim3(n_tiles), dim3(256), 0, e->stream, rem_flags, N, e->tile_counts, m.rem_list,
+                     s->p.num_local_blocks, &s->counters->remove_count);
   hipLaunchKernelGGL(k_release_blocks, dim3(1024), dim3(256), 0, e->stream, m.rem_list, s->counters, s->hash,
                      reinterpret_cast<uint4 *>(s->voxels), s->alloc_list, s->masks, s->last_seen, s->history_words);
   hipLaunchKernelGGL(k_find_leaders, dim3(256), dim3(256), 0, e->stream, m.rem_list, s->counters, s->hash,
@@ -291,10 +288,8 @@ static int decay_candidates(dslam_engine *e, dslam_scene *s, dslam_render_state 
                             int max_weight) {
   // cand_flags / tile_counts hold the selection; turn it into the candidate list, decay, release empties
   const int N = s->n_entries, n_tiles = num_tiles(N);
-  hipLaunchKernelGGL(k_scan_count, dim3(1), dim3(1024), 0, e->stream, e->tile_counts, e->tile_offsets, n_tiles,
-                     &s->counters->swap_count, s->p.num_local_blocks);  // swap_count doubles as candidate count
-  hipLaunchKernelGGL(k_compact_apply, dim3(n_tiles), dim3(256), 0, e->stream, m.cand_flags, N, e->tile_offsets,
-                     m.cand_list, s->p.num_local_blocks);
+  hipLaunchKernelGGL(k_compact_apply_fused, dim3(n_tiles), dim3(256), 0, e->stream, m.cand_flags, N, e->tile_counts,
+                     m.cand_list, s->p.num_local_blocks, &s->counters->swap_count);  // swap_count doubles as candidate count
   DSLAM_HIP(hipMemsetAsync(m.rem_flags, 0, N, e->stream));
   hipLaunchKernelGGL(k_decay_blocks, dim3(1024), dim3(256), 0, e->stream, m.cand_list, &s->counters->swap_count, s->hash,
                      reinterpret_cast<uint4 *>(s->voxels), max_weight, m.rem_flags, s->p.use_swapping ? 0 : 1);
