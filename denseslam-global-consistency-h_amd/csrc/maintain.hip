@@ -484,15 +484,13 @@ static int swap_select_to_host(dslam_engine *e, dslam_scene *s, const unsigned c
   hipLaunchKernelGGL(k_compact_apply, dim3(n_tiles), dim3(256), 0, e->stream, m.cand_flags, N, e->tile_offsets,
                      m.cand_list, kTransferBlocks);
   DSLAM_HIP(hipGetLastError());
+  // count and ids travel together (16 KiB at most): one wait instead of two
   int *host_count = reinterpret_cast<int *>(e->pinned) + 48;
   DSLAM_HIP(hipMemcpyAsync(host_count, &s->counters->swap_count, sizeof(int), hipMemcpyDeviceToHost, e->stream));
+  DSLAM_HIP(hipMemcpyAsync(s->transfer_ids_host, m.cand_list, (size_t)kTransferBlocks * sizeof(int), hipMemcpyDeviceToHost,
+                           e->stream));
   DSLAM_HIP(hipStreamSynchronize(e->stream));
-  const int n = *host_count;
-  if (n > 0) {
-    DSLAM_HIP(hipMemcpyAsync(s->transfer_ids_host, m.cand_list, (size_t)n * sizeof(int), hipMemcpyDeviceToHost, e->stream));
-    DSLAM_HIP(hipStreamSynchronize(e->stream));
-  }
-  *out_count = n;
+  *out_count = *host_count;
   return DSLAM_OK;
 }
 
@@ -537,7 +535,8 @@ static int merge_from_host(dslam_engine *e, dslam_scene *s, const MaintScratch &
   hipLaunchKernelGGL(k_swap_merge, dim3(1024), dim3(256), 0, e->stream, m.cand_list, slots_dev, n, s->hash,
                      reinterpret_cast<uint4 *>(s->voxels), s->slab_ptrs_dev, s->swap_state, s->p.max_w);
   DSLAM_HIP(hipGetLastError());
-  DSLAM_HIP(hipStreamSynchronize(e->stream));  // the pinned id / slot buffer is reused by the next batch
+  // no wait here: the pinned id / slot buffer is next written by the host only after the next selection's wait, and
+  // by the device only in stream order
   return DSLAM_OK;
 }
 
@@ -552,8 +551,7 @@ static int pack_to_host(dslam_engine *e, dslam_scene *s, unsigned char *vis_type
                      s->last_seen, s->history_words, s->swap_state, vis_type, s->counters);
   hipLaunchKernelGGL(k_add_last_free, dim3(1), dim3(64), 0, e->stream, s->counters, n, add_slid);
   DSLAM_HIP(hipGetLastError());
-  DSLAM_HIP(hipStreamSynchronize(e->stream));  // the pinned id / slot buffer is reused by the next batch
-  return DSLAM_OK;
+  return DSLAM_OK;  // (no wait: see merge_from_host; readers of the host store synchronise first)
 }
 
 int launch_swap_in(dslam_engine *e, dslam_scene *s, dslam_render_state *) {
