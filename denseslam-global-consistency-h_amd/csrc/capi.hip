@@ -257,6 +257,7 @@ int dslam_scene_destroy(dslam_scene *s) {
 
 int dslam_scene_reset(dslam_engine *e, dslam_scene *s) {
   DSLAM_REQUIRE(e && s, "null argument");
+  s->version++;  // the map may change: GetImage memos of this scene are stale
   int rc = launch_scene_reset(e, s);
   if (rc) return rc;
   for (int q = 0; q < 2; q++) { s->ring_head[q] = 0; s->ring_next[q] = 0; s->decay_cursor[q] = 0; }
@@ -309,6 +310,7 @@ int dslam_shard_pack(dslam_engine *e, const dslam_scene *s, int first_block, int
 int dslam_shard_unpack(dslam_engine *e, dslam_scene *s, int first_block, int groups, int num_shards, int chunk_blocks,
                        const void *recv_dev) {
   DSLAM_REQUIRE(e && recv_dev, "bad argument");
+  s->version++;  // the map may change: GetImage memos of this scene are stale
   int rc = shard_region_ok(s, first_block, groups, num_shards, chunk_blocks);
   if (rc || groups == 0) return rc;
   const size_t chunk_bytes = (size_t)chunk_blocks * kBlock3 * sizeof(uint2);
@@ -674,6 +676,8 @@ int dslam_allocate_scene_from_depth(dslam_engine *e, dslam_scene *s, const dslam
                                     const float M_d[16], const float intr[4], int only_visible) {
   int rc = check_frame_args(e, s, v, r, M_d, intr);
   if (rc) return rc;
+  s->version++;  // the map may change: GetImage memos of this scene are stale
+  if (r) r->memo_valid = false;
   rc = launch_allocate(e, s, v, r, M_d, intr, only_visible);
   if (rc) return rc;
   return finish_call(e);
@@ -684,6 +688,7 @@ int dslam_integrate_into_scene(dslam_engine *e, dslam_scene *s, const dslam_view
                                const float intr_rgb[4]) {
   int rc = check_frame_args(e, s, v, r, M_d, intr_d);
   if (rc) return rc;
+  s->version++;  // the map may change: GetImage memos of this scene are stale
   rc = launch_integrate(e, s, v, r, M_d, intr_d, M_rgb, intr_rgb, false);
   if (rc) return rc;
   return finish_call(e);
@@ -694,6 +699,8 @@ int dslam_process_frame(dslam_engine *e, dslam_scene *s, const dslam_view *v, ds
                         int only_visible, int is_defusion) {
   int rc = check_frame_args(e, s, v, r, M_d, intr_d);
   if (rc) return rc;
+  s->version++;  // the map may change: GetImage memos of this scene are stale
+  if (r) r->memo_valid = false;
   if ((rc = launch_allocate(e, s, v, r, M_d, intr_d, only_visible))) return rc;
   if ((rc = launch_integrate(e, s, v, r, M_d, intr_d, M_rgb, intr_rgb, false, is_defusion ? 1 : 0))) return rc;
   if (s->p.use_swapping) {
@@ -707,6 +714,8 @@ int dslam_deprocess_frame(dslam_engine *e, dslam_scene *s, const dslam_view *v, 
                           const float M_d[16], const float intr_d[4], const float M_rgb[16], const float intr_rgb[4]) {
   int rc = check_frame_args(e, s, v, r, M_d, intr_d);
   if (rc) return rc;
+  s->version++;  // the map may change: GetImage memos of this scene are stale
+  if (r) r->memo_valid = false;
   if ((rc = launch_allocate(e, s, v, r, M_d, intr_d, 1))) return rc;
   if ((rc = launch_integrate(e, s, v, r, M_d, intr_d, M_rgb, intr_rgb, true))) return rc;
   return finish_call(e);
@@ -724,6 +733,8 @@ int dslam_track_camera(dslam_engine *e, const dslam_view *v, dslam_render_state 
 // ---- decay / sliding window ----------------------------------------------------------------------------------
 int dslam_decay(dslam_engine *e, dslam_scene *s, dslam_render_state *r, int max_weight, int min_age, int force_all) {
   DSLAM_REQUIRE(e && s, "null argument");
+  s->version++;  // the map may change: GetImage memos of this scene are stale
+  if (r) r->memo_valid = false;
   int rc = launch_decay(e, s, r, max_weight, min_age, force_all, 0);
   if (rc) return rc;
   return finish_call(e);
@@ -731,12 +742,16 @@ int dslam_decay(dslam_engine *e, dslam_scene *s, dslam_render_state *r, int max_
 int dslam_decay_defusion_part(dslam_engine *e, dslam_scene *s, dslam_render_state *r, int max_weight, int min_age,
                               int force_all) {
   DSLAM_REQUIRE(e && s, "null argument");
+  s->version++;  // the map may change: GetImage memos of this scene are stale
+  if (r) r->memo_valid = false;
   int rc = launch_decay(e, s, r, max_weight, min_age, force_all, 1);
   if (rc) return rc;
   return finish_call(e);
 }
 int dslam_slide_window(dslam_engine *e, dslam_scene *s, dslam_render_state *r, int max_age) {
   DSLAM_REQUIRE(e && s, "null argument");
+  s->version++;  // the map may change: GetImage memos of this scene are stale
+  if (r) r->memo_valid = false;
   if (max_age < 0) max_age = 0;
   while (s->ring_next[0] - s->ring_head[0] > max_age) {
     int rc = launch_slide_pop(e, s, r, 0);
@@ -746,6 +761,8 @@ int dslam_slide_window(dslam_engine *e, dslam_scene *s, dslam_render_state *r, i
 }
 int dslam_slide_window_defusion_part(dslam_engine *e, dslam_scene *s, dslam_render_state *r, int max_age, int max_size) {
   DSLAM_REQUIRE(e && s, "null argument");
+  s->version++;  // the map may change: GetImage memos of this scene are stale
+  if (r) r->memo_valid = false;
   (void)max_age;
   if (max_size < 0) max_size = 0;
   while (s->ring_next[1] - s->ring_head[1] > max_size) {
@@ -758,18 +775,23 @@ int dslam_slide_window_defusion_part(dslam_engine *e, dslam_scene *s, dslam_rend
 // ---- swapping ------------------------------------------------------------------------------------------------
 int dslam_swap_in(dslam_engine *e, dslam_scene *s, dslam_render_state *r) {
   DSLAM_REQUIRE(e && s && s->p.use_swapping, "scene was created without swapping");
+  s->version++;  // the map may change: GetImage memos of this scene are stale
+  if (r) r->memo_valid = false;
   int rc = launch_swap_in(e, s, r);
   if (rc) return rc;
   return finish_call(e);
 }
 int dslam_swap_out(dslam_engine *e, dslam_scene *s, dslam_render_state *r) {
   DSLAM_REQUIRE(e && s && r && s->p.use_swapping, "scene was created without swapping");
+  s->version++;  // the map may change: GetImage memos of this scene are stale
+  if (r) r->memo_valid = false;
   int rc = launch_swap_out(e, s, r, false);
   if (rc) return rc;
   return finish_call(e);
 }
 int dslam_save_to_global_memory(dslam_engine *e, dslam_scene *s) {
   DSLAM_REQUIRE(e && s && s->p.use_swapping, "scene was created without swapping");
+  s->version++;  // the map may change: GetImage memos of this scene are stale
   int rc = launch_save_to_global(e, s);
   if (rc) return rc;
   return finish_call(e);
@@ -779,6 +801,7 @@ int dslam_save_to_global_memory(dslam_engine *e, dslam_scene *s) {
 int dslam_find_visible_blocks(dslam_engine *e, const dslam_scene *s, dslam_render_state *r, const float M[16],
                               const float intr[4]) {
   DSLAM_REQUIRE(e && s && r && M && intr, "null argument");
+  r->memo_valid = false;  // raycastResult / the lists behind it are about to be rewritten
   int rc = launch_find_visible(e, s, r, M, intr);
   if (rc) return rc;
   return finish_call(e);
@@ -791,6 +814,7 @@ int dslam_count_visible_blocks(dslam_engine *e, const dslam_scene *s, const dsla
 int dslam_create_expected_depths(dslam_engine *e, const dslam_scene *s, dslam_render_state *r, const float M[16],
                                  const float intr[4]) {
   DSLAM_REQUIRE(e && s && r && M && intr, "null argument");
+  r->memo_valid = false;  // raycastResult / the lists behind it are about to be rewritten
   int rc = launch_expected_depths(e, s, r, M, intr);
   if (rc) return rc;
   return finish_call(e);
@@ -816,19 +840,38 @@ static int image_out(dslam_engine *e, dslam_render_state *r, int type, uint8_t *
 int dslam_render_image(dslam_engine *e, const dslam_scene *s, dslam_render_state *r, const float M[16],
                        const float intr[4], int type, uint8_t *out_rgba, float *out_float) {
   DSLAM_REQUIRE(e && s && r && M && intr, "null argument");
+  r->memo_valid = false;  // raycastResult / the lists behind it are about to be rewritten
   DSLAM_REQUIRE(type >= 0 && type <= DSLAM_IMAGE_DEPTH, "unknown image type");
   int rc = launch_render(e, s, r, M, intr, type);
   if (rc) return rc;
   return image_out(e, r, type, out_rgba, out_float);
 }
 
+// FindVisibleBlocks + CreateExpectedDepths + march for (scene version, pose, intrinsics), unless the render state
+// still holds exactly that (see dslam_render_state::memo_*); then the image of the requested type.
+static int get_image_on_device(dslam_engine *e, const dslam_scene *s, dslam_render_state *r, const float *M,
+                               const float *intr, int type) {
+  // a map whose voxel blocks live in caller memory can change behind the engine's back: never memoised
+  const bool hit = r->memo_valid && !s->voxels_external && r->memo_scene == s && r->memo_version == s->version &&
+                   r->memo_budget == e->render_tile_budget && memcmp(r->memo_M, M, sizeof(r->memo_M)) == 0 &&
+                   memcmp(r->memo_intr, intr, sizeof(r->memo_intr)) == 0;
+  int rc;
+  if (hit) return launch_render(e, s, r, M, intr, type, true);
+  r->memo_valid = false;
+  if ((rc = launch_find_visible_and_depths(e, s, r, M, intr))) return rc;
+  if ((rc = launch_render(e, s, r, M, intr, type))) return rc;
+  r->memo_valid = true; r->memo_scene = s; r->memo_version = s->version; r->memo_budget = e->render_tile_budget;
+  memcpy(r->memo_M, M, sizeof(r->memo_M));
+  memcpy(r->memo_intr, intr, sizeof(r->memo_intr));
+  return DSLAM_OK;
+}
+
 int dslam_get_image(dslam_engine *e, const dslam_scene *s, dslam_render_state *r, const float M[16],
                     const float intr[4], int type, uint8_t *out_rgba, float *out_float) {
   DSLAM_REQUIRE(e && s && r && M && intr, "null argument");
   DSLAM_REQUIRE(type >= 0 && type <= DSLAM_IMAGE_DEPTH, "unknown image type");
-  int rc;
-  if ((rc = launch_find_visible_and_depths(e, s, r, M, intr))) return rc;
-  if ((rc = launch_render(e, s, r, M, intr, type))) return rc;
+  int rc = get_image_on_device(e, s, r, M, intr, type);
+  if (rc) return rc;
   return image_out(e, r, type, out_rgba, out_float);
 }
 
@@ -836,8 +879,7 @@ int dslam_get_depth_image_int16(dslam_engine *e, const dslam_scene *s, dslam_ren
                                 const float intr[4], int scale, int16_t *out_host) {
   DSLAM_REQUIRE(e && s && r && M && intr && out_host && scale > 0, "bad argument");
   int rc;
-  if ((rc = launch_find_visible_and_depths(e, s, r, M, intr))) return rc;
-  if ((rc = launch_render(e, s, r, M, intr, DSLAM_IMAGE_DEPTH))) return rc;
+  if ((rc = get_image_on_device(e, s, r, M, intr, DSLAM_IMAGE_DEPTH))) return rc;
   // the RGBA image buffer of the render state is idle in this mode: it takes the int16 image (2 of its 4 bytes per pixel)
   const int n = r->w * r->h;
   short *tmp = reinterpret_cast<short *>(r->image_rgba);
@@ -850,6 +892,7 @@ int dslam_get_depth_image_int16(dslam_engine *e, const dslam_scene *s, dslam_ren
 int dslam_create_icp_maps(dslam_engine *e, const dslam_scene *s, dslam_render_state *r, const float M[16],
                           const float intr[4], float *out_points, float *out_normals) {
   DSLAM_REQUIRE(e && s && r && M && intr, "null argument");
+  r->memo_valid = false;  // raycastResult / the lists behind it are about to be rewritten
   int rc;
   if ((rc = launch_expected_depths(e, s, r, M, intr))) return rc;
   if ((rc = launch_icp_maps(e, s, r, M, intr))) return rc;
@@ -1005,6 +1048,7 @@ int dslam_download_alloc_scratch(dslam_engine *e, const dslam_scene *s, uint8_t 
 int dslam_upload_scene_state(dslam_engine *e, dslam_scene *s, const dslam_hash_entry *hash, const int32_t *alloc_list,
                              int last_free, const int32_t *excess_list, int last_free_ex) {
   DSLAM_REQUIRE(e && s, "null argument");
+  s->version++;  // the map may change: GetImage memos of this scene are stale
   int rc = 0;
   if (hash) {
     rc = h2d(e, s->hash, hash, (size_t)s->n_entries * sizeof(HashEntry));
@@ -1027,10 +1071,12 @@ int dslam_upload_scene_state(dslam_engine *e, dslam_scene *s, const dslam_hash_e
 }
 int dslam_upload_voxel_blocks(dslam_engine *e, dslam_scene *s, int first, int n, const dslam_voxel *host) {
   DSLAM_REQUIRE(e && s && host && first >= 0 && n >= 0 && first + n <= s->p.num_local_blocks, "bad block range");
+  s->version++;  // the map may change: GetImage memos of this scene are stale
   return h2d(e, s->voxels + (size_t)first * kBlock3, host, (size_t)n * kBlock3 * sizeof(uint2));
 }
 int dslam_upload_visible_ids(dslam_engine *e, dslam_render_state *r, const int32_t *ids, int count) {
   DSLAM_REQUIRE(e && r && ids && count >= 0 && count <= r->n_local, "bad visible list");
+  r->memo_valid = false;  // raycastResult / the lists behind it are about to be rewritten
   int rc = h2d(e, r->visible_ids, ids, (size_t)count * sizeof(int));
   if (rc) return rc;
   RenderCounters *rcn = reinterpret_cast<RenderCounters *>(reinterpret_cast<char *>(e->pinned) + 128);
@@ -1052,6 +1098,7 @@ int dslam_time_integrate(dslam_engine *e, dslam_scene *s, const dslam_view *v, c
                          const float M_d[16], const float intr[4], int iterations, float *out_ms, int *out_blocks) {
   int rc = check_frame_args(e, s, v, r, M_d, intr);
   if (rc) return rc;
+  s->version++;  // the map may change: GetImage memos of this scene are stale
   DSLAM_REQUIRE(iterations > 0 && out_ms, "bad argument");
   hipEvent_t a, b;
   DSLAM_HIP(hipEventCreate(&a));

@@ -106,6 +106,7 @@ struct dslam_scene {
   int *transfer_ids_host = nullptr;     // pinned [2 * kTransferBlocks]: entry ids of a batch, then their slots
   int last_swapped_in = 0, last_swapped_out = 0;
   int shard = 0, num_shards = 1, chunk_blocks = 256;
+  unsigned long long version = 0;       // bumped by every call that can change the map (GetImage memo key)
   int shard_first = 0, shard_count = -1;  // contiguous slot range (count < 0: off)
 };
 
@@ -124,6 +125,14 @@ struct dslam_render_state {
   int *proj_req = nullptr;      // per visible block: render tiles required (0 = invalid projection)
   int *proj_wg_tiles = nullptr; // render tiles requested per workgroup of the projection pass (summed by the next kernel)
   dslam::RenderCounters *counters = nullptr;  // device
+  // GetImage memo: raycastResult (and the visible list / range image behind it) is still that of this scene version,
+  // pose and intrinsics, so another image type of the same view only has to be shaded (the reference's GUI asks for
+  // a depth and a colour image of the same free pose every tick, DenseSlam.h:146-164)
+  bool memo_valid = false;
+  const dslam_scene *memo_scene = nullptr;
+  unsigned long long memo_version = 0;
+  int memo_budget = 0;
+  float memo_M[16] = {0}, memo_intr[4] = {0};
 };
 
 struct dslam_view {
@@ -181,7 +190,7 @@ int launch_find_visible_and_depths(dslam_engine *e, const dslam_scene *s, dslam_
 int launch_track_camera(dslam_engine *e, const dslam_view *v, dslam_render_state *r, const float *scenePose, float *pose_M,
                         const float *intr, const dslam_tracker_params *tp, dslam_tracker_result *res);
 int launch_render(dslam_engine *e, const dslam_scene *s, dslam_render_state *r, const float *M, const float *intr,
-                  int type);
+                  int type, bool reuse_raycast = false);
 int launch_icp_maps(dslam_engine *e, const dslam_scene *s, dslam_render_state *r, const float *M, const float *intr);
 int launch_mesh_scene(dslam_engine *e, const dslam_scene *s, int max_triangles, int with_colour, int *out_num);
 int launch_decay(dslam_engine *e, dslam_scene *s, dslam_render_state *r, int max_weight, int min_age, int force_all,

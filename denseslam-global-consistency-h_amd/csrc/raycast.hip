@@ -692,6 +692,7 @@ struct RenderParams {
   int type;  // dslam_image_type, or -1: raycast only
   unsigned long long *dbg_waves;  // diagnostics only (env DSLAM_DBG_WAVETIME=<file>): per wave {cycles, max iterations, straddling iterations, their cycles, setup cycles, refinement cycles}
   int dbg_flags;  // diagnostics only (env DSLAM_DBG_FLAGS: 8 = 16x16 workgroups)
+  int reuse_raycast;  // 1: raycastResult already holds this view's march (GetImage memo): shade only
 };
 
 // DIAG instantiation only: wave-level split of the march (single-wave workgroups): iterations in which some lane took
@@ -840,7 +841,12 @@ __global__ __launch_bounds__(WAVES * 64, 5) void k_render(RenderParams p) {
   Vec4 pr;
   MarchDiag diag;
   const unsigned long long t_start = DIAG ? __builtin_amdgcn_s_memtime() : 0ull;
-  cast_ray<DIAG>(pr, x, y, p, p.range[loc2], diag);
+  if (p.reuse_raycast) {  // (uniform) the march of this very view is in raycastResult already
+    const float4 q = p.raycast[loc];
+    pr.x = q.x; pr.y = q.y; pr.z = q.z; pr.w = q.w;
+  } else {
+    cast_ray<DIAG>(pr, x, y, p, p.range[loc2], diag);
+  }
   if (DIAG) {  // diagnostic instantiation (DSLAM_DBG_WAVETIME): per-wave cycles and march length
     const unsigned long long dt = __builtin_amdgcn_s_memtime() - t_start;
     // the lane with the longest march saw every wave iteration
@@ -856,7 +862,7 @@ __global__ __launch_bounds__(WAVES * 64, 5) void k_render(RenderParams p) {
       p.dbg_waves[6 * wid + 5] = diag.tail_cycles;
     }
   }
-  p.raycast[loc] = make_float4(pr.x, pr.y, pr.z, pr.w);
+  if (!p.reuse_raycast) p.raycast[loc] = make_float4(pr.x, pr.y, pr.z, pr.w);
   if (p.type < 0) return;
 
   const Vec3 pt = {pr.x, pr.y, pr.z};
@@ -913,15 +919,16 @@ static int fill_render_params(RenderParams &rp, const dslam_scene *s, dslam_rend
   rp.range = r->range; rp.raycast = r->raycast; rp.out_rgba = r->image_rgba; rp.out_float = r->image_float;
   rp.type = type;
   static const int dbg_flags = getenv("DSLAM_DBG_FLAGS") ? atoi(getenv("DSLAM_DBG_FLAGS")) : 0;
-  rp.dbg_flags = dbg_flags; rp.dbg_waves = nullptr;
+  rp.dbg_flags = dbg_flags; rp.dbg_waves = nullptr; rp.reuse_raycast = 0;
   return DSLAM_OK;
 }
 
 int launch_render(dslam_engine *e, const dslam_scene *s, dslam_render_state *r, const float *M, const float *intr,
-                  int type) {
+                  int type, bool reuse_raycast) {
   RenderParams rp;
   int rc = fill_render_params(rp, s, r, M, intr, type);
   if (rc) return rc;
+  rp.reuse_raycast = reuse_raycast ? 1 : 0;
   static const char *dbg_file = getenv("DSLAM_DBG_WAVETIME");
   static int dbg_calls = 0;
   const int n_waves = ((r->w + 7) / 8) * ((r->h + 7) / 8);

@@ -325,3 +325,57 @@ def test_kitti_frame_sizes_and_partial_tiles(pkg, synth, gpu, oracle, size):
         assert np.abs(g[k].astype(int) - o[k].astype(int)).max() <= 1, k
     assert np.array_equal(g["icp"][0][..., 3], o["icp"][0][..., 3])
     assert np.abs(g["icp"][0] - o["icp"][0]).max() <= 1e-4 and np.abs(g["icp"][1] - o["icp"][1]).max() <= 1e-4
+
+
+def test_get_image_memo_same_view_is_shaded_only_and_invalidated_by_any_change(pkg, synth, gpu, oracle):
+    """The reference's GUI asks for a depth and a colour image of the same free pose every tick (DenseSlam.h:146-164).
+    The engine keeps the march of the last GetImage per render state and only shades when scene version, pose and
+    intrinsics are unchanged.  Every image type from the memo must equal a fresh render, and anything that can change
+    the result -- fusing a frame, decay, another pose, another user of the render state -- must drop the memo."""
+    wl = synth.s_tiny(96, 72)
+    p = util.small_params(pkg, wl)
+    objs = {}
+    for name, api in (("gpu", gpu), ("oracle", oracle)):
+        s, rs, v = util.run_sequence(api, pkg, wl, p, 3)
+        objs[name] = (api, s, rs, v, api.create_render_state(s, wl.W, wl.H), api.create_render_state(s, wl.W, wl.H))
+    M0, M1 = wl.frame(2)[2], wl.frame(1)[2]
+    types = (pkg.IMAGE_DEPTH, pkg.IMAGE_COLOUR_FROM_VOLUME, pkg.IMAGE_SHADED, pkg.IMAGE_COLOUR_FROM_NORMAL)
+
+    def same(a, b, what):
+        if a.dtype == np.float32:
+            assert np.abs(a - b).max() <= 1e-4, what
+        else:
+            assert np.abs(a.astype(int) - b.astype(int)).max() <= 1, what
+
+    g, s, rs, v, free, fresh = objs["gpu"]
+    o, so, rso, vo, freeo, _ = objs["oracle"]
+    # (1) four types of one view through one render state (memo) == each through a just-created render state == oracle
+    for t in types:
+        memo = g.get_image(s, free, M0, wl.intr, t)
+        cold = g.get_image(s, g.create_render_state(s, wl.W, wl.H), M0, wl.intr, t)
+        assert np.array_equal(memo, cold), f"type {t}: memo differs from a fresh render"
+        same(memo, o.get_image(so, freeo, M0, wl.intr, t), f"type {t} vs oracle")
+    assert np.array_equal(g.get_depth_image_int16(s, free, M0, wl.intr, 1000), o.get_depth_image_int16(so, freeo, M0, wl.intr, 1000))
+    # (2) another pose, then back: both rendered for what they are
+    same(g.get_image(s, free, M1, wl.intr, pkg.IMAGE_DEPTH), o.get_image(so, freeo, M1, wl.intr, pkg.IMAGE_DEPTH), "other pose")
+    same(g.get_image(s, free, M0, wl.intr, pkg.IMAGE_DEPTH), o.get_image(so, freeo, M0, wl.intr, pkg.IMAGE_DEPTH), "back")
+    # (3) the map changes between two requests for the same view
+    before = g.get_image(s, free, M0, wl.intr, pkg.IMAGE_DEPTH)
+    rgba, mm, M3 = wl.frame(3)
+    for api, sc, r, vw in ((g, s, rs, v), (o, so, rso, vo)):
+        api.view_update(vw, rgba, mm, timestamp=3.0)
+        api.process_frame(sc, vw, r, M3, wl.intr)
+    after = g.get_image(s, free, M0, wl.intr, pkg.IMAGE_DEPTH)
+    same(after, o.get_image(so, freeo, M0, wl.intr, pkg.IMAGE_DEPTH), "after fusing a frame")
+    assert not np.array_equal(before, after), "a fused frame must show in the next image of the same view"
+    for api, sc, r in ((g, s, rs), (o, so, rso)):
+        api.decay(sc, r, 2, 0, True)
+    same(g.get_image(s, free, M0, wl.intr, pkg.IMAGE_DEPTH), o.get_image(so, freeo, M0, wl.intr, pkg.IMAGE_DEPTH), "after decay")
+    # (4) another user of the render state in between (tracking raycast from a different pose)
+    g.get_image(s, free, M0, wl.intr, pkg.IMAGE_DEPTH)
+    g.create_icp_maps(s, free, M1, wl.intr)
+    o.create_icp_maps(so, freeo, M1, wl.intr)
+    same(g.get_image(s, free, M0, wl.intr, pkg.IMAGE_SHADED), o.get_image(so, freeo, M0, wl.intr, pkg.IMAGE_SHADED), "after ICP maps")
+    # (5) different intrinsics
+    intr2 = np.array(wl.intr, np.float32) * np.float32(0.9)
+    same(g.get_image(s, free, M0, intr2, pkg.IMAGE_DEPTH), o.get_image(so, freeo, M0, intr2, pkg.IMAGE_DEPTH), "other intrinsics")
