@@ -692,7 +692,6 @@ struct RenderParams {
   int type;  // dslam_image_type, or -1: raycast only
   unsigned long long *dbg_waves;  // diagnostics only (env DSLAM_DBG_WAVETIME=<file>): per wave {cycles, max iterations, straddling iterations, their cycles, setup cycles, refinement cycles}
   int dbg_flags;  // diagnostics only (env DSLAM_DBG_FLAGS: 8 = 16x16 workgroups)
-  int reuse_raycast;  // 1: raycastResult already holds this view's march (GetImage memo): shade only
 };
 
 // DIAG instantiation only: wave-level split of the march (single-wave workgroups): iterations in which some lane took
@@ -825,7 +824,8 @@ __device__ __forceinline__ bool cast_ray(Vec4 &out, int x, int y, const RenderPa
 // SHADE = false: raycast only / depth image -- the variant the fusion loop and the tracker use; it carries no
 // shading code, which keeps it at <= 64 VGPRs = 8 waves per SIMD (the march is latency-bound, occupancy is what
 // hides its load round trips).  SHADE = true adds the normal / colour modes.
-template <int WAVES, bool SHADE, bool DIAG = false>
+// REUSE = true: raycastResult already holds this very view's march (GetImage memo) -- shade only.
+template <int WAVES, bool SHADE, bool DIAG = false, bool REUSE = false>
 __global__ __launch_bounds__(WAVES * 64, 5) void k_render(RenderParams p) {
   // one wavefront = one workgroup = an 8x8 pixel tile = exactly one cell of the 1/8-resolution range image.
   // Single-wave workgroups let the dispatcher backfill a SIMD the moment a short tile finishes (ray lengths vary
@@ -841,7 +841,7 @@ __global__ __launch_bounds__(WAVES * 64, 5) void k_render(RenderParams p) {
   Vec4 pr;
   MarchDiag diag;
   const unsigned long long t_start = DIAG ? __builtin_amdgcn_s_memtime() : 0ull;
-  if (p.reuse_raycast) {  // (uniform) the march of this very view is in raycastResult already
+  if (REUSE) {
     const float4 q = p.raycast[loc];
     pr.x = q.x; pr.y = q.y; pr.z = q.z; pr.w = q.w;
   } else {
@@ -862,7 +862,7 @@ __global__ __launch_bounds__(WAVES * 64, 5) void k_render(RenderParams p) {
       p.dbg_waves[6 * wid + 5] = diag.tail_cycles;
     }
   }
-  if (!p.reuse_raycast) p.raycast[loc] = make_float4(pr.x, pr.y, pr.z, pr.w);
+  if (!REUSE) p.raycast[loc] = make_float4(pr.x, pr.y, pr.z, pr.w);
   if (p.type < 0) return;
 
   const Vec3 pt = {pr.x, pr.y, pr.z};
@@ -919,7 +919,7 @@ static int fill_render_params(RenderParams &rp, const dslam_scene *s, dslam_rend
   rp.range = r->range; rp.raycast = r->raycast; rp.out_rgba = r->image_rgba; rp.out_float = r->image_float;
   rp.type = type;
   static const int dbg_flags = getenv("DSLAM_DBG_FLAGS") ? atoi(getenv("DSLAM_DBG_FLAGS")) : 0;
-  rp.dbg_flags = dbg_flags; rp.dbg_waves = nullptr; rp.reuse_raycast = 0;
+  rp.dbg_flags = dbg_flags; rp.dbg_waves = nullptr;
   return DSLAM_OK;
 }
 
@@ -928,7 +928,6 @@ int launch_render(dslam_engine *e, const dslam_scene *s, dslam_render_state *r, 
   RenderParams rp;
   int rc = fill_render_params(rp, s, r, M, intr, type);
   if (rc) return rc;
-  rp.reuse_raycast = reuse_raycast ? 1 : 0;
   static const char *dbg_file = getenv("DSLAM_DBG_WAVETIME");
   static int dbg_calls = 0;
   const int n_waves = ((r->w + 7) / 8) * ((r->h + 7) / 8);
@@ -939,7 +938,10 @@ int launch_render(dslam_engine *e, const dslam_scene *s, dslam_render_state *r, 
     rp.dbg_waves = dbg_host;
   }
   const dim3 grid1((r->w + 7) / 8, (r->h + 7) / 8);
-  if (rp.dbg_flags & 8)
+  if (reuse_raycast) {
+    if (type == DSLAM_IMAGE_DEPTH || type < 0) hipLaunchKernelGGL((k_render<1, false, false, true>), grid1, dim3(64), 0, e->stream, rp);
+    else hipLaunchKernelGGL((k_render<1, true, false, true>), grid1, dim3(64), 0, e->stream, rp);
+  } else if (rp.dbg_flags & 8)
     hipLaunchKernelGGL((k_render<4, true>), dim3((r->w + 15) / 16, (r->h + 15) / 16), dim3(256), 0, e->stream, rp);
   else if (rp.dbg_waves)
     hipLaunchKernelGGL((k_render<1, false, true>), grid1, dim3(64), 0, e->stream, rp);
