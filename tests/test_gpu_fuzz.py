@@ -57,7 +57,9 @@ def _trial(pkg, synth, gpu, oracle, seed):
             elif op == "defusion_ring":
                 args = (int(rng.integers(1, 5)), int(rng.integers(1, 4)))
             elif op == "raycast":
-                args = (int(rng.choice([pkg.IMAGE_DEPTH, pkg.IMAGE_SHADED, pkg.IMAGE_COLOUR_FROM_VOLUME, pkg.IMAGE_COLOUR_FROM_NORMAL])),)
+                kinds = [pkg.IMAGE_DEPTH, pkg.IMAGE_SHADED, pkg.IMAGE_COLOUR_FROM_VOLUME, pkg.IMAGE_COLOUR_FROM_NORMAL]
+                # a second image type of the same view right after (the GUI's pair): served from the engine's GetImage memo
+                args = (int(rng.choice(kinds)), int(rng.choice(kinds)))
             elif op == "alloc_only":
                 args = (bool(rng.integers(0, 2)),)
             elif op == "fuse":
@@ -88,7 +90,7 @@ def _trial(pkg, synth, gpu, oracle, seed):
                     api.view_update(v, rgba, mm, timestamp=float(step))
                     api.allocate_scene_from_depth(s, v, rs, M, wl.intr, only_update_visible_list=args[0])
                 elif op == "raycast":
-                    imgs[name] = api.get_image(s, free, M, wl.intr, args[0])
+                    imgs[name] = [api.get_image(s, free, M, wl.intr, args[0]), api.get_image(s, free, M, wl.intr, args[1])]
                 elif op == "flush" and p.use_swapping:
                     api.save_to_global_memory(s)
             if op == "fuse" and not args[0]:
@@ -96,10 +98,11 @@ def _trial(pkg, synth, gpu, oracle, seed):
                 rgba_n[..., 3] = 255 if args[1] else rgba[..., 3]
                 fused.append((rgba_n, mm, M))
             if op == "raycast":
-                if args[0] == pkg.IMAGE_DEPTH:
-                    assert np.abs(imgs["gpu"] - imgs["oracle"]).max() <= 1e-4, f"seed {seed} step {step}: depth image"
-                else:
-                    assert np.abs(imgs["gpu"].astype(int) - imgs["oracle"].astype(int)).max() <= 1, f"seed {seed} step {step}: image"
+                for kind, a, b in zip(args, imgs["gpu"], imgs["oracle"]):
+                    if kind == pkg.IMAGE_DEPTH:
+                        assert np.abs(a - b).max() <= 1e-4, f"seed {seed} step {step}: depth image"
+                    else:
+                        assert np.abs(a.astype(int) - b.astype(int)).max() <= 1, f"seed {seed} step {step}: image"
             snaps = {name: util.snapshot(api, s, rs) for name, (api, s, rs, v, free) in objs.items()}
             util.assert_same_state(snaps["gpu"], snaps["oracle"], f"seed {seed} step {step} after {log[-1]}")
             if p.use_swapping:
