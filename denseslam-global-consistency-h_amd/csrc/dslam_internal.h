@@ -76,6 +76,7 @@ struct dslam_engine {
   size_t mesh_bytes = 0;              // capacity of each of the two buffers
   int mesh_triangles = 0;
   bool mesh_has_colour = false;
+  bool mesh_table_ready = false;      // the case table sits in this device's constant memory
 };
 
 struct dslam_scene {

@@ -198,10 +198,9 @@ __global__ __launch_bounds__(512) void k_mesh_emit(MeshParams p) {
 }
 
 int launch_mesh_scene(dslam_engine *e, const dslam_scene *s, int max_triangles, int with_colour, int *out_num) {
-  static bool table_uploaded = false;
-  if (!table_uploaded) {
+  if (!e->mesh_table_ready) {  // __constant__ memory is per device: once per engine, not once per process
     DSLAM_HIP(hipMemcpyToSymbol(HIP_SYMBOL(d_mc_triangles), kMcTriangles, sizeof(kMcTriangles)));
-    table_uploaded = true;
+    e->mesh_table_ready = true;
   }
   const int N = s->n_entries, n_tiles = num_tiles(N);
   int rc = ensure_scratch(e, N, s->p.num_local_blocks);
