@@ -234,20 +234,34 @@ int main(int argc, char **argv) {
     }
     int fused = 0;
     const auto t_loop0 = std::chrono::steady_clock::now();
+    const bool raycast_each = getenv("DRIVER_HARNESS_RAYCAST_EACH_FRAME") != nullptr;
+    double phase_us[3] = {0, 0, 0};  // UpdateView, fusion + window + decay, per-keyframe raycast
+    auto lap = [](std::chrono::steady_clock::time_point &t) {
+      const auto now = std::chrono::steady_clock::now();
+      const double us = std::chrono::duration<double, std::micro>(now - t).count();
+      t = now;
+      return us;
+    };
     for (int i = 0; i < N && !oc.enabled; i++) {
+      auto t = std::chrono::steady_clock::now();
       currentLocalMap->trackingState->pose_d->SetM(poses[i]);                 // SetPoseLocalMap (InfiniTamDriver.h:173-178)
       drv.UpdateView(rgba[i].data(), depth[i].data(), (double)i);             // DenseSlam.cpp:212
+      phase_us[0] += lap(t);
       drv.IntegrateLocalMap(currentLocalMap);                                 // DenseSlam.cpp:213
       fused++;
       if (sw.enabled && fused > sw.max_age) drv.SlideWindow(currentLocalMap);  // DenseSlam.cpp:215-225
       drv.Decay(currentLocalMap);                                             // DenseSlam.cpp:227-232
-      if (getenv("DRIVER_HARNESS_RAYCAST_EACH_FRAME")) {                      // SaveRaycastDepth's per-keyframe raycast
+      phase_us[1] += lap(t);
+      if (raycast_each) {                                                     // SaveRaycastDepth's per-keyframe raycast
         free_pose.SetM(poses[i]);
         drv.GetFloatImage(&out_float, free_pose, currentLocalMap);
+        phase_us[2] += lap(t);
       }
     }
     const double loop_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_loop0).count();
-    if (!oc.enabled && N > 0) printf("driver_harness loop: %d keyframes in %.3f ms (%.1f us per keyframe, host-synchronous calls)\n", N, loop_s * 1e3, loop_s * 1e6 / N);
+    if (!oc.enabled && N > 0)
+      printf("driver_harness loop: %d keyframes in %.3f ms (%.1f us per keyframe, host-synchronous calls: UpdateView %.1f, fusion %.1f, raycast %.1f)\n",
+             N, loop_s * 1e3, loop_s * 1e6 / N, phase_us[0] / N, phase_us[1] / N, phase_us[2] / N);
     free_pose.SetM(poses[N - 1]);
     drv.GetFloatImage(&out_float, free_pose, currentLocalMap);                // DenseSlam.h:146-153
     drv.GetImage(&out_rgba, ITMMainEngine::InfiniTAM_IMAGE_FREECAMERA_COLOUR_FROM_VOLUME, free_pose, currentLocalMap);
