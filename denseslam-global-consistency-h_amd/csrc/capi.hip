@@ -850,16 +850,16 @@ int dslam_render_image(dslam_engine *e, const dslam_scene *s, dslam_render_state
 // FindVisibleBlocks + CreateExpectedDepths + march for (scene version, pose, intrinsics), unless the render state
 // still holds exactly that (see dslam_render_state::memo_*); then the image of the requested type.
 static int get_image_on_device(dslam_engine *e, const dslam_scene *s, dslam_render_state *r, const float *M,
-                               const float *intr, int type) {
+                               const float *intr, int type, void *direct_out = nullptr) {
   // a map whose voxel blocks live in caller memory can change behind the engine's back: never memoised
   const bool hit = r->memo_valid && !s->voxels_external && r->memo_scene == s && r->memo_version == s->version &&
                    r->memo_budget == e->render_tile_budget && memcmp(r->memo_M, M, sizeof(r->memo_M)) == 0 &&
                    memcmp(r->memo_intr, intr, sizeof(r->memo_intr)) == 0;
   int rc;
-  if (hit) return launch_render(e, s, r, M, intr, type, true);
+  if (hit) return launch_render(e, s, r, M, intr, type, true, direct_out);
   r->memo_valid = false;
   if ((rc = launch_find_visible_and_depths(e, s, r, M, intr))) return rc;
-  if ((rc = launch_render(e, s, r, M, intr, type))) return rc;
+  if ((rc = launch_render(e, s, r, M, intr, type, false, direct_out))) return rc;
   r->memo_valid = true; r->memo_scene = s; r->memo_version = s->version; r->memo_budget = e->render_tile_budget;
   memcpy(r->memo_M, M, sizeof(r->memo_M));
   memcpy(r->memo_intr, intr, sizeof(r->memo_intr));
@@ -870,6 +870,15 @@ int dslam_get_image(dslam_engine *e, const dslam_scene *s, dslam_render_state *r
                     const float intr[4], int type, uint8_t *out_rgba, float *out_float) {
   DSLAM_REQUIRE(e && s && r && M && intr, "null argument");
   DSLAM_REQUIRE(type >= 0 && type <= DSLAM_IMAGE_DEPTH, "unknown image type");
+  // a page-locked output image (dslam_host_alloc) is written by the render kernel itself: no copy behind the kernel
+  void *out = type == DSLAM_IMAGE_DEPTH ? (void *)out_float : (void *)out_rgba;
+  const size_t bytes = (size_t)r->w * r->h * 4;
+  if (out && !(out_rgba && out_float) && in_pinned_range(out, bytes)) {
+    int rc = get_image_on_device(e, s, r, M, intr, type, out);
+    if (rc) return rc;
+    DSLAM_HIP(hipStreamSynchronize(e->stream));  // host buffers are valid on return
+    return DSLAM_OK;
+  }
   int rc = get_image_on_device(e, s, r, M, intr, type);
   if (rc) return rc;
   return image_out(e, r, type, out_rgba, out_float);

@@ -191,7 +191,7 @@ int launch_find_visible_and_depths(dslam_engine *e, const dslam_scene *s, dslam_
 int launch_track_camera(dslam_engine *e, const dslam_view *v, dslam_render_state *r, const float *scenePose, float *pose_M,
                         const float *intr, const dslam_tracker_params *tp, dslam_tracker_result *res);
 int launch_render(dslam_engine *e, const dslam_scene *s, dslam_render_state *r, const float *M, const float *intr,
-                  int type, bool reuse_raycast = false);
+                  int type, bool reuse_raycast = false, void *image_out_override = nullptr);
 int launch_icp_maps(dslam_engine *e, const dslam_scene *s, dslam_render_state *r, const float *M, const float *intr);
 int launch_mesh_scene(dslam_engine *e, const dslam_scene *s, int max_triangles, int with_colour, int *out_num);
 int launch_decay(dslam_engine *e, dslam_scene *s, dslam_render_state *r, int max_weight, int min_age, int force_all,

@@ -924,10 +924,14 @@ static int fill_render_params(RenderParams &rp, const dslam_scene *s, dslam_rend
 }
 
 int launch_render(dslam_engine *e, const dslam_scene *s, dslam_render_state *r, const float *M, const float *intr,
-                  int type, bool reuse_raycast) {
+                  int type, bool reuse_raycast, void *image_out_override) {
   RenderParams rp;
   int rc = fill_render_params(rp, s, r, M, intr, type);
   if (rc) return rc;
+  if (image_out_override) {  // a page-locked caller image: the kernel stores the pixels there itself (over PCIe)
+    if (type == DSLAM_IMAGE_DEPTH) rp.out_float = static_cast<float *>(image_out_override);
+    else rp.out_rgba = static_cast<uchar4 *>(image_out_override);
+  }
   static const char *dbg_file = getenv("DSLAM_DBG_WAVETIME");
   static int dbg_calls = 0;
   const int n_waves = ((r->w + 7) / 8) * ((r->h + 7) / 8);

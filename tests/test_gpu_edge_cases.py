@@ -379,3 +379,31 @@ def test_get_image_memo_same_view_is_shaded_only_and_invalidated_by_any_change(p
     # (5) different intrinsics
     intr2 = np.array(wl.intr, np.float32) * np.float32(0.9)
     same(g.get_image(s, free, M0, intr2, pkg.IMAGE_DEPTH), o.get_image(so, freeo, M0, intr2, pkg.IMAGE_DEPTH), "other intrinsics")
+
+
+def test_get_image_into_page_locked_caller_image(pkg, synth, gpu):
+    """A page-locked output image (dslam_host_alloc, what the ITMLib mirror's images are) is written by the render
+    kernel itself instead of by a copy queued behind it: same pixels as the ordinary path, for float and RGBA images,
+    from a fresh march and from the GetImage memo, and for a pinned buffer that is larger than the image."""
+    wl = synth.s_tiny(96, 72)
+    p = util.small_params(pkg, wl)
+    s, rs, v = util.run_sequence(gpu, pkg, wl, p, 3)
+    free = gpu.create_render_state(s, wl.W, wl.H)
+    M0, M1 = wl.frame(2)[2], wl.frame(1)[2]
+    pin_f = gpu.host_alloc((wl.H, wl.W), np.float32)
+    pin_c = gpu.host_alloc((wl.H + 3, wl.W, 4), np.uint8)
+    try:
+        want_f = gpu.get_image(s, gpu.create_render_state(s, wl.W, wl.H), M0, wl.intr, pkg.IMAGE_DEPTH)
+        want_c = gpu.get_image(s, gpu.create_render_state(s, wl.W, wl.H), M0, wl.intr, pkg.IMAGE_COLOUR_FROM_VOLUME)
+        pin_f[...] = -7.0
+        got = gpu.get_image(s, free, M0, wl.intr, pkg.IMAGE_DEPTH, out=pin_f)      # fresh march, direct store
+        assert got is pin_f and np.array_equal(pin_f, want_f) and (want_f > 0).mean() > 0.3
+        pin_c[...] = 9
+        gpu.get_image(s, free, M0, wl.intr, pkg.IMAGE_COLOUR_FROM_VOLUME, out=pin_c[:wl.H])  # from the memo, direct store
+        assert np.array_equal(pin_c[:wl.H], want_c) and (pin_c[wl.H:] == 9).all()
+        # the device copy of the image is not needed afterwards: another view, ordinary output, still right
+        other = gpu.get_image(s, free, M1, wl.intr, pkg.IMAGE_DEPTH)
+        assert np.array_equal(other, gpu.get_image(s, gpu.create_render_state(s, wl.W, wl.H), M1, wl.intr, pkg.IMAGE_DEPTH))
+    finally:
+        gpu.host_free(pin_f)
+        gpu.host_free(pin_c)
