@@ -318,7 +318,12 @@ int dslam_render_image(dslam_engine *e, const dslam_scene *s, dslam_render_state
                        const float intrinsics[4], int image_type, uint8_t *out_rgba_host,
                        float *out_float_host);
 /* ITMMainEngine::GetImage(out, outFloat, type, pose, intrinsics, localMap) for the FREECAMERA_* types
- * (InfiniTamDriver.cpp:229-277): FindVisibleBlocks + CreateExpectedDepths + RenderImage. */
+ * (InfiniTamDriver.cpp:229-277): FindVisibleBlocks + CreateExpectedDepths + RenderImage.
+ * Two things the caller gets for free: (1) the render state remembers the view (map version, pose, intrinsics) its
+ * raycast result belongs to, so a second image type of the same view -- the GUI's depth + colour pair per tick,
+ * DenseSlam.h:146-164 -- is only shaded; any call that can change the map or the render state drops that memo (maps
+ * over caller-owned voxel memory are never memoised); (2) an output image inside a dslam_host_alloc buffer is written
+ * by the render kernel itself instead of by a copy queued behind it. */
 int dslam_get_image(dslam_engine *e, const dslam_scene *s, dslam_render_state *r, const float M[16],
                     const float intrinsics[4], int image_type, uint8_t *out_rgba_host,
                     float *out_float_host);
