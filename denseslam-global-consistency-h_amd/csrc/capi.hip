@@ -2,6 +2,7 @@
 // composition of kernels into the ITMLib engine calls (ITMDenseMapper::ProcessFrame, ITMMainEngine::GetImage ...).
 // No arithmetic of the hot path lives here; there is no CPU fallback: without a HIP device the engine cannot be
 // created and every entry point fails.
+#include <atomic>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -63,6 +64,13 @@ bool invert_matrix(const float *m, float *dst) {
   }
   for (int i = 0; i < 16; i++) dst[i] = dst[i] * (1.0f / det);
   return true;
+}
+
+// Map versions are drawn from one process-wide counter, so a version never repeats -- not even on a new scene that
+// happens to be allocated where a destroyed one was (the GetImage memo compares scene pointer and version).
+unsigned long long next_map_version() {
+  static std::atomic<unsigned long long> counter{0};
+  return ++counter;
 }
 
 int finish_call(dslam_engine *e) {
@@ -197,6 +205,7 @@ int dslam_scene_create(dslam_engine *e, const dslam_scene_params *p, void *ext_v
   *out = nullptr;
   DSLAM_HIP(hipSetDevice(e->device));
   dslam_scene *s = new dslam_scene();
+  s->version = next_map_version();
   s->engine = e;
   s->p = *p;
   if (s->p.num_local_blocks <= 0) s->p.num_local_blocks = DSLAM_DEFAULT_LOCAL_BLOCK_NUM;
@@ -257,7 +266,7 @@ int dslam_scene_destroy(dslam_scene *s) {
 
 int dslam_scene_reset(dslam_engine *e, dslam_scene *s) {
   DSLAM_REQUIRE(e && s, "null argument");
-  s->version++;  // the map may change: GetImage memos of this scene are stale
+  s->version = next_map_version();  // the map may change: GetImage memos of this scene are stale
   int rc = launch_scene_reset(e, s);
   if (rc) return rc;
   for (int q = 0; q < 2; q++) { s->ring_head[q] = 0; s->ring_next[q] = 0; s->decay_cursor[q] = 0; }
@@ -310,7 +319,7 @@ int dslam_shard_pack(dslam_engine *e, const dslam_scene *s, int first_block, int
 int dslam_shard_unpack(dslam_engine *e, dslam_scene *s, int first_block, int groups, int num_shards, int chunk_blocks,
                        const void *recv_dev) {
   DSLAM_REQUIRE(e && recv_dev, "bad argument");
-  s->version++;  // the map may change: GetImage memos of this scene are stale
+  s->version = next_map_version();  // the map may change: GetImage memos of this scene are stale
   int rc = shard_region_ok(s, first_block, groups, num_shards, chunk_blocks);
   if (rc || groups == 0) return rc;
   const size_t chunk_bytes = (size_t)chunk_blocks * kBlock3 * sizeof(uint2);
@@ -676,7 +685,7 @@ int dslam_allocate_scene_from_depth(dslam_engine *e, dslam_scene *s, const dslam
                                     const float M_d[16], const float intr[4], int only_visible) {
   int rc = check_frame_args(e, s, v, r, M_d, intr);
   if (rc) return rc;
-  s->version++;  // the map may change: GetImage memos of this scene are stale
+  s->version = next_map_version();  // the map may change: GetImage memos of this scene are stale
   if (r) r->memo_valid = false;
   rc = launch_allocate(e, s, v, r, M_d, intr, only_visible);
   if (rc) return rc;
@@ -688,7 +697,7 @@ int dslam_integrate_into_scene(dslam_engine *e, dslam_scene *s, const dslam_view
                                const float intr_rgb[4]) {
   int rc = check_frame_args(e, s, v, r, M_d, intr_d);
   if (rc) return rc;
-  s->version++;  // the map may change: GetImage memos of this scene are stale
+  s->version = next_map_version();  // the map may change: GetImage memos of this scene are stale
   rc = launch_integrate(e, s, v, r, M_d, intr_d, M_rgb, intr_rgb, false);
   if (rc) return rc;
   return finish_call(e);
@@ -699,7 +708,7 @@ int dslam_process_frame(dslam_engine *e, dslam_scene *s, const dslam_view *v, ds
                         int only_visible, int is_defusion) {
   int rc = check_frame_args(e, s, v, r, M_d, intr_d);
   if (rc) return rc;
-  s->version++;  // the map may change: GetImage memos of this scene are stale
+  s->version = next_map_version();  // the map may change: GetImage memos of this scene are stale
   if (r) r->memo_valid = false;
   if ((rc = launch_allocate(e, s, v, r, M_d, intr_d, only_visible))) return rc;
   if ((rc = launch_integrate(e, s, v, r, M_d, intr_d, M_rgb, intr_rgb, false, is_defusion ? 1 : 0))) return rc;
@@ -714,7 +723,7 @@ int dslam_deprocess_frame(dslam_engine *e, dslam_scene *s, const dslam_view *v, 
                           const float M_d[16], const float intr_d[4], const float M_rgb[16], const float intr_rgb[4]) {
   int rc = check_frame_args(e, s, v, r, M_d, intr_d);
   if (rc) return rc;
-  s->version++;  // the map may change: GetImage memos of this scene are stale
+  s->version = next_map_version();  // the map may change: GetImage memos of this scene are stale
   if (r) r->memo_valid = false;
   if ((rc = launch_allocate(e, s, v, r, M_d, intr_d, 1))) return rc;
   if ((rc = launch_integrate(e, s, v, r, M_d, intr_d, M_rgb, intr_rgb, true))) return rc;
@@ -733,7 +742,7 @@ int dslam_track_camera(dslam_engine *e, const dslam_view *v, dslam_render_state 
 // ---- decay / sliding window ----------------------------------------------------------------------------------
 int dslam_decay(dslam_engine *e, dslam_scene *s, dslam_render_state *r, int max_weight, int min_age, int force_all) {
   DSLAM_REQUIRE(e && s, "null argument");
-  s->version++;  // the map may change: GetImage memos of this scene are stale
+  s->version = next_map_version();  // the map may change: GetImage memos of this scene are stale
   if (r) r->memo_valid = false;
   int rc = launch_decay(e, s, r, max_weight, min_age, force_all, 0);
   if (rc) return rc;
@@ -742,7 +751,7 @@ int dslam_decay(dslam_engine *e, dslam_scene *s, dslam_render_state *r, int max_
 int dslam_decay_defusion_part(dslam_engine *e, dslam_scene *s, dslam_render_state *r, int max_weight, int min_age,
                               int force_all) {
   DSLAM_REQUIRE(e && s, "null argument");
-  s->version++;  // the map may change: GetImage memos of this scene are stale
+  s->version = next_map_version();  // the map may change: GetImage memos of this scene are stale
   if (r) r->memo_valid = false;
   int rc = launch_decay(e, s, r, max_weight, min_age, force_all, 1);
   if (rc) return rc;
@@ -750,7 +759,7 @@ int dslam_decay_defusion_part(dslam_engine *e, dslam_scene *s, dslam_render_stat
 }
 int dslam_slide_window(dslam_engine *e, dslam_scene *s, dslam_render_state *r, int max_age) {
   DSLAM_REQUIRE(e && s, "null argument");
-  s->version++;  // the map may change: GetImage memos of this scene are stale
+  s->version = next_map_version();  // the map may change: GetImage memos of this scene are stale
   if (r) r->memo_valid = false;
   if (max_age < 0) max_age = 0;
   while (s->ring_next[0] - s->ring_head[0] > max_age) {
@@ -761,7 +770,7 @@ int dslam_slide_window(dslam_engine *e, dslam_scene *s, dslam_render_state *r, i
 }
 int dslam_slide_window_defusion_part(dslam_engine *e, dslam_scene *s, dslam_render_state *r, int max_age, int max_size) {
   DSLAM_REQUIRE(e && s, "null argument");
-  s->version++;  // the map may change: GetImage memos of this scene are stale
+  s->version = next_map_version();  // the map may change: GetImage memos of this scene are stale
   if (r) r->memo_valid = false;
   (void)max_age;
   if (max_size < 0) max_size = 0;
@@ -775,7 +784,7 @@ int dslam_slide_window_defusion_part(dslam_engine *e, dslam_scene *s, dslam_rend
 // ---- swapping ------------------------------------------------------------------------------------------------
 int dslam_swap_in(dslam_engine *e, dslam_scene *s, dslam_render_state *r) {
   DSLAM_REQUIRE(e && s && s->p.use_swapping, "scene was created without swapping");
-  s->version++;  // the map may change: GetImage memos of this scene are stale
+  s->version = next_map_version();  // the map may change: GetImage memos of this scene are stale
   if (r) r->memo_valid = false;
   int rc = launch_swap_in(e, s, r);
   if (rc) return rc;
@@ -783,7 +792,7 @@ int dslam_swap_in(dslam_engine *e, dslam_scene *s, dslam_render_state *r) {
 }
 int dslam_swap_out(dslam_engine *e, dslam_scene *s, dslam_render_state *r) {
   DSLAM_REQUIRE(e && s && r && s->p.use_swapping, "scene was created without swapping");
-  s->version++;  // the map may change: GetImage memos of this scene are stale
+  s->version = next_map_version();  // the map may change: GetImage memos of this scene are stale
   if (r) r->memo_valid = false;
   int rc = launch_swap_out(e, s, r, false);
   if (rc) return rc;
@@ -791,7 +800,7 @@ int dslam_swap_out(dslam_engine *e, dslam_scene *s, dslam_render_state *r) {
 }
 int dslam_save_to_global_memory(dslam_engine *e, dslam_scene *s) {
   DSLAM_REQUIRE(e && s && s->p.use_swapping, "scene was created without swapping");
-  s->version++;  // the map may change: GetImage memos of this scene are stale
+  s->version = next_map_version();  // the map may change: GetImage memos of this scene are stale
   int rc = launch_save_to_global(e, s);
   if (rc) return rc;
   return finish_call(e);
@@ -1057,7 +1066,7 @@ int dslam_download_alloc_scratch(dslam_engine *e, const dslam_scene *s, uint8_t 
 int dslam_upload_scene_state(dslam_engine *e, dslam_scene *s, const dslam_hash_entry *hash, const int32_t *alloc_list,
                              int last_free, const int32_t *excess_list, int last_free_ex) {
   DSLAM_REQUIRE(e && s, "null argument");
-  s->version++;  // the map may change: GetImage memos of this scene are stale
+  s->version = next_map_version();  // the map may change: GetImage memos of this scene are stale
   int rc = 0;
   if (hash) {
     rc = h2d(e, s->hash, hash, (size_t)s->n_entries * sizeof(HashEntry));
@@ -1080,7 +1089,7 @@ int dslam_upload_scene_state(dslam_engine *e, dslam_scene *s, const dslam_hash_e
 }
 int dslam_upload_voxel_blocks(dslam_engine *e, dslam_scene *s, int first, int n, const dslam_voxel *host) {
   DSLAM_REQUIRE(e && s && host && first >= 0 && n >= 0 && first + n <= s->p.num_local_blocks, "bad block range");
-  s->version++;  // the map may change: GetImage memos of this scene are stale
+  s->version = next_map_version();  // the map may change: GetImage memos of this scene are stale
   return h2d(e, s->voxels + (size_t)first * kBlock3, host, (size_t)n * kBlock3 * sizeof(uint2));
 }
 int dslam_upload_visible_ids(dslam_engine *e, dslam_render_state *r, const int32_t *ids, int count) {
@@ -1107,7 +1116,7 @@ int dslam_time_integrate(dslam_engine *e, dslam_scene *s, const dslam_view *v, c
                          const float M_d[16], const float intr[4], int iterations, float *out_ms, int *out_blocks) {
   int rc = check_frame_args(e, s, v, r, M_d, intr);
   if (rc) return rc;
-  s->version++;  // the map may change: GetImage memos of this scene are stale
+  s->version = next_map_version();  // the map may change: GetImage memos of this scene are stale
   DSLAM_REQUIRE(iterations > 0 && out_ms, "bad argument");
   hipEvent_t a, b;
   DSLAM_HIP(hipEventCreate(&a));
