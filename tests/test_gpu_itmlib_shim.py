@@ -104,3 +104,60 @@ def test_driver_harness_matches_oracle(pkg, synth, oracle, tmp_path, decay, slid
     assert m_rgb == fnv1a(frames[-1][0].tobytes())
     assert m_depth == fnv1a(oracle.download_view_depth(v).tobytes())
     assert n_pts == int((o_pts[..., 3] > 0).sum()) and n_nrm == int((o_nrm[..., 3] == 0).sum()) and n_pts > 500
+
+
+RCCL_PROG = os.path.join(os.path.dirname(HARNESS), "reintegrate_rccl")
+
+
+def test_rccl_program_is_built():
+    assert os.path.exists(RCCL_PROG), "run python __graft_entry__.py (build) first"
+
+
+@pytest.mark.gpu
+def test_native_rccl_reintegration_single_rank_matches_unsharded_oracle(pkg, synth, oracle, tmp_path):
+    """INTEGRATION.md section 5 as a compiled program (C ABI + RCCL): fuse, then de-integrate / re-integrate the last
+    keyframes at corrected poses with the voxel blocks sharded by slot, one ncclAllGather.  With one rank the exchange is
+    a single-rank all-gather through exactly the multi-rank code path (pack -> ncclAllGather -> unpack); the map must
+    equal the unsharded oracle run byte for byte.  (More ranks need more GPUs than the test box has; the same logic
+    runs over gloo with two ranks in tests/test_multigpu_gloo.py.)"""
+    wl = synth.s_tiny()
+    n_frames, K = 6, 3
+    p = util.small_params(pkg, wl, num_local_blocks=0x800, num_buckets=0x1000, num_excess=0x400)
+    frames = [wl.frame(i) for i in range(n_frames)]
+    fin, fout = tmp_path / "frames.bin", tmp_path / "out.bin"
+    with open(fin, "wb") as f:
+        f.write(struct.pack("<3i", wl.W, wl.H, n_frames))
+        for rgba, mm, M in frames:
+            f.write(rgba.tobytes()); f.write(mm.tobytes()); f.write(pkg.mat_to_abi(M).tobytes())
+        f.write(np.asarray(wl.intr, np.float32).tobytes())
+        f.write(struct.pack("<4f", p.voxel_size, p.mu, p.frustum_min, p.frustum_max))
+        f.write(struct.pack("<4i", p.max_w, p.num_local_blocks, p.num_buckets, p.num_excess))
+    env = dict(os.environ, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    res = subprocess.run([RCCL_PROG, str(fin), str(fout), str(K)], capture_output=True, text=True, timeout=300, env=env)
+    assert res.returncode == 0, res.stdout + res.stderr
+    raw = open(fout, "rb").read()
+    last_free, no_vis = struct.unpack_from("<2i", raw, 0)
+    h_hash, h_vox = struct.unpack_from("<2Q", raw, 8)
+    ms_reint, ms_gather = struct.unpack_from("<2d", raw, 24)
+    (gathered,) = struct.unpack_from("<Q", raw, 40)
+
+    s = oracle.create_scene(p)
+    rs = oracle.create_render_state(s, wl.W, wl.H)
+    v = oracle.create_view(wl.W, wl.H)
+    for i, (rgba, mm, M) in enumerate(frames):
+        oracle.view_update(v, rgba, mm, timestamp=float(i))
+        oracle.process_frame(s, v, rs, M, wl.intr)
+    for j in range(K):
+        rgba, mm, M = frames[n_frames - K + j]
+        Mc = np.array(M, np.float32)
+        Mc[0, 3] += np.float32(0.01) * np.float32(j + 1)  # row-major here; the program adds to column 3 of the ABI layout
+        Mc[2, 3] += np.float32(0.02)
+        oracle.view_update(v, rgba, mm, timestamp=float(n_frames - K + j))
+        oracle.deprocess_frame(s, v, rs, M, wl.intr)
+        oracle.process_frame(s, v, rs, Mc, wl.intr, is_defusion=True)
+    st = oracle.stats(s, rs)
+    assert last_free == st["last_free_block_id"] and no_vis == st["no_visible_entries"]
+    assert h_hash == fnv1a(oracle.download_hash_table(s).tobytes())
+    assert h_vox == fnv1a(oracle.download_voxel_blocks(s).tobytes())
+    used = p.num_local_blocks - 1 - last_free
+    assert gathered == ((used + 63) // 64) * 64 * 4096 and ms_reint > 0 and ms_gather > 0
