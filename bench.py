@@ -172,7 +172,7 @@ def main():
     eng.kernel_timer_enable(True)
 
     def barrier():
-        if world > 1:
+        if use_dist:  # (also with --force-dist on one rank: the RCCL barrier / all-reduce path is exercised)
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -185,7 +185,7 @@ def main():
     t1 = time.perf_counter()
     barrier()
     elapsed = t1 - t0
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -218,7 +218,7 @@ def main():
             barrier()
             tt = torch.tensor([timers["total_s"], timers["reintegrate_s"], timers["all_gather_s"]], device=dev,
                               dtype=torch.float64)
-            if world > 1:
+            if use_dist:
                 dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             tot, rei, agt = [float(x) for x in tt.tolist()]
             reint_out = {"keyframes": Kre, "keyframes_per_s": Kre / tot, "total_ms": tot * 1e3, "compute_ms": rei * 1e3,
