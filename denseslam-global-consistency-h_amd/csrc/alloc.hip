@@ -21,9 +21,17 @@ namespace dslam {
 // ---------------------------------------------------------------------------------------------------------
 // ResetScene
 // ---------------------------------------------------------------------------------------------------------
+// One short-lived workgroup per 16 KiB (4 x 16 bytes per lane), not a persistent grid-stride loop: on MI355X a 1 GiB
+// fill runs at 6.0 TB/s this way against 3.9 TB/s for 4096 looping workgroups (scratch microbenchmark).
+constexpr int kFillUnroll = 4;
 __global__ __launch_bounds__(256) void k_fill_voxels(uint4 *__restrict__ v, size_t n16) {
   const uint4 empty2 = make_uint4(kEmptyVoxelLo, kEmptyVoxelHi, kEmptyVoxelLo, kEmptyVoxelHi);
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (size_t)gridDim.x * blockDim.x) v[i] = empty2;
+  const size_t base = (size_t)blockIdx.x * (256 * kFillUnroll) + threadIdx.x;
+#pragma unroll
+  for (int u = 0; u < kFillUnroll; u++) {
+    const size_t i = base + (size_t)u * 256;
+    if (i < n16) v[i] = empty2;
+  }
 }
 
 __global__ __launch_bounds__(256) void k_reset_tables(HashEntry *hash, int n_entries, int *alloc_list, int *last_seen,
@@ -44,7 +52,8 @@ __global__ __launch_bounds__(256) void k_reset_tables(HashEntry *hash, int n_ent
 
 int launch_scene_reset(dslam_engine *e, dslam_scene *s) {
   const size_t n16 = (size_t)s->p.num_local_blocks * kBlock3 / 2;
-  hipLaunchKernelGGL(k_fill_voxels, dim3(4096), dim3(256), 0, e->stream, reinterpret_cast<uint4 *>(s->voxels), n16);
+  const unsigned fill_wgs = (unsigned)((n16 + 256 * kFillUnroll - 1) / (256 * kFillUnroll));
+  hipLaunchKernelGGL(k_fill_voxels, dim3(fill_wgs), dim3(256), 0, e->stream, reinterpret_cast<uint4 *>(s->voxels), n16);
   hipLaunchKernelGGL(k_reset_tables, dim3(2048), dim3(256), 0, e->stream, s->hash, s->n_entries, s->alloc_list,
                      s->last_seen, s->p.num_local_blocks, s->excess_list, s->p.num_excess, s->counters);
   DSLAM_HIP(hipMemsetAsync(s->masks, 0, (size_t)s->p.num_local_blocks * 2 * s->history_words * sizeof(unsigned long long),
