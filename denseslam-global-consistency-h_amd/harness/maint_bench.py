@@ -168,7 +168,9 @@ def main():
         eng.view_update(view, c, mm, timestamp=float(i))
         eng.process_frame(scene, view, rs, M, wl.intr)
     M = frames[-1][2]
-    t = min(timed(eng, lambda: eng.get_image(scene, rsf, M, wl.intr, pkg.IMAGE_DEPTH, download=False)) for _ in range(20))
+    # (alternating between the last two poses: a repeated view would be served from the GetImage memo, shading only)
+    poses2 = [frames[-1][2], frames[-2][2]]
+    t = min(timed(eng, lambda k=k: eng.get_image(scene, rsf, poses2[k % 2], wl.intr, pkg.IMAGE_DEPTH, download=False)) for k in range(20))
     out["get_image_depth"] = {"us": round(t, 1), "rays_per_s": round(W * H / t * 1e6), "what": "A14: FindVisibleBlocks + CreateExpectedDepths + march of 640x480 rays"}
     eng.view_update(view, frames[-1][0], frames[-1][1])
     t = min(timed(eng, lambda: eng.allocate_scene_from_depth(scene, view, rs, M, wl.intr)) for _ in range(20))
