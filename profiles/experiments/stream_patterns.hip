@@ -35,6 +35,30 @@ __global__ __launch_bounds__(256) void mostly_empty(const int *n, uint4 *v) {
 #pragma unroll
   for (int j = 0; j < 4; j++) { uint4 x = blk[j * 64 + lane]; x.x += 1; blk[j * 64 + lane] = x; }
 }
+// one 4 KiB block per wave, RMW; LEVELS dependent loads in front of the block address: 0 = contiguous, 1 = ptr list,
+// 2 = id list -> 16-byte entry holding ptr (the integration kernel's chain, plus the count read when COUNT is set)
+template <int LEVELS, bool COUNT, bool HALVES>
+__global__ __launch_bounds__(256) void chain(const int *n, const int *ids, const uint4 *entries, const int *ptrs, uint4 *v) {
+  const int wave = (blockIdx.x * 256 + threadIdx.x) >> 6;
+  const int nv = COUNT ? *n : 7884;
+  if (wave >= nv) return;
+  int ptr = wave;
+  if (LEVELS == 1) ptr = ptrs[wave];
+  if (LEVELS == 2) ptr = (int)entries[ids[wave]].w;
+  uint4 *blk = v + (size_t)ptr * 256;
+  const int lane = threadIdx.x & 63;
+  if (HALVES) {
+#pragma unroll 1
+    for (int h = 0; h < 2; h++) {
+      uint4 x0 = blk[(2 * h) * 64 + lane], x1 = blk[(2 * h + 1) * 64 + lane];
+      x0.x += 1; x1.x += 1;
+      blk[(2 * h) * 64 + lane] = x0; blk[(2 * h + 1) * 64 + lane] = x1;
+    }
+  } else {
+#pragma unroll
+    for (int j = 0; j < 4; j++) { uint4 x = blk[j * 64 + lane]; x.x += 1; blk[j * 64 + lane] = x; }
+  }
+}
 int main() {
   const size_t bytes = (size_t)1 << 30, n16 = bytes / 16;
   uint4 *v; unsigned *o; CK(hipMalloc(&v, bytes)); CK(hipMalloc(&o, 4));
@@ -63,6 +87,28 @@ int main() {
       float ms; hipEventElapsedTime(&ms, a, b);
       printf("one block per wave, nvis=%6d, grid=%6d WGs: %.1f us per launch (%.2f TB/s)\n", nv, g, ms / 20 * 1e3, nv * 8192.0 / (ms / 20) / 1e9);
     }
+  }
+  {  // 7884 random blocks of the 262144 in the 1 GiB buffer
+    const int nv = 7884, nb = 262144;
+    int *h_ptr = new int[nv], *h_ids = new int[nv]; uint4 *h_ent = new uint4[1179648];
+    unsigned r = 12345u;
+    for (int i = 0; i < nv; i++) { r = r * 1664525u + 1013904223u; h_ptr[i] = (int)((r >> 8) % nb); }
+    // ids ascending over a 1.18 M-entry table (as the visible list is)
+    for (int i = 0; i < nv; i++) { h_ids[i] = (int)((long)i * 1179648 / nv); h_ent[h_ids[i]] = make_uint4(0, 0, 0, (unsigned)h_ptr[i]); }
+    int *d_ptr, *d_ids; uint4 *d_ent;
+    CK(hipMalloc(&d_ptr, nv * 4)); CK(hipMalloc(&d_ids, nv * 4)); CK(hipMalloc(&d_ent, 1179648 * 16));
+    CK(hipMemcpy(d_ptr, h_ptr, nv * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(d_ids, h_ids, nv * 4, hipMemcpyHostToDevice));
+    CK(hipMemcpy(d_ent, h_ent, 1179648 * 16, hipMemcpyHostToDevice)); CK(hipMemcpy(dn, &nv, 4, hipMemcpyHostToDevice));
+    auto tm = [&](const char *name, auto launch) {
+      for (int i = 0; i < 3; i++) launch();
+      hipEventRecord(a); for (int i = 0; i < 20; i++) launch(); hipEventRecord(b); hipEventSynchronize(b);
+      float ms; hipEventElapsedTime(&ms, a, b); printf("%-58s %.1f us\n", name, ms / 20 * 1e3);
+    };
+    tm("7884 blocks contiguous", [&] { hipLaunchKernelGGL((chain<0, false, false>), dim3(2048), dim3(256), 0, 0, dn, d_ids, d_ent, d_ptr, v); });
+    tm("7884 blocks random (ptr list)", [&] { hipLaunchKernelGGL((chain<1, false, false>), dim3(2048), dim3(256), 0, 0, dn, d_ids, d_ent, d_ptr, v); });
+    tm("7884 blocks random (id list -> entry)", [&] { hipLaunchKernelGGL((chain<2, false, false>), dim3(2048), dim3(256), 0, 0, dn, d_ids, d_ent, d_ptr, v); });
+    tm("  + count read first", [&] { hipLaunchKernelGGL((chain<2, true, false>), dim3(2048), dim3(256), 0, 0, dn, d_ids, d_ent, d_ptr, v); });
+    tm("  + count read first + two sequential halves", [&] { hipLaunchKernelGGL((chain<2, true, true>), dim3(2048), dim3(256), 0, 0, dn, d_ids, d_ent, d_ptr, v); });
   }
   return 0;
 }
