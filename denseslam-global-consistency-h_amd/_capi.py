@@ -464,6 +464,13 @@ class CApi:
         self._call("download_icp_maps", self._engine, rs.ptr, _fptr(pts), _fptr(nrm))
         return pts, nrm
 
+    def download_raycast_image(self, rs):
+        """renderState->raycastImage: the grey tracking raycast the last create_icp_maps drew (what
+        ITMMainEngine::GetImage(InfiniTAM_IMAGE_SCENERAYCAST) copies out)."""
+        out = np.empty((rs.height, rs.width, 4), dtype=np.uint8)
+        self._call("download_raycast_image", self._engine, rs.ptr, _vptr(out))
+        return out
+
     # -- meshing export --------------------------------------------------------------------------------
     def mesh_scene(self, scene, max_triangles=0, colour=False):
         """SaveCurrSceneToMesh's MeshScene: returns (positions [n, 3, 3] float32 in metres, colours [n, 3, 3] float32

@@ -128,6 +128,15 @@ extern "C" {
 const char *dslam_last_error(void) { return g_last_error.c_str(); }
 const char *dslam_version(void) { return "dslam_fusion 0.1 (gfx950)"; }
 
+static int engine_allocate(dslam_engine *e) {
+  DSLAM_HIP(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
+  e->pinned_bytes = 64 * 1024;
+  DSLAM_HIP(hipHostMalloc(&e->pinned, e->pinned_bytes, hipHostMallocDefault));
+  memset(e->pinned, 0, e->pinned_bytes);
+  DSLAM_HIP(hipMalloc(&e->misc_counter, 16 * sizeof(int)));
+  return DSLAM_OK;
+}
+
 int dslam_engine_create(int device_index, dslam_engine **out) {
   if (!out) return DSLAM_ERR_INVALID;
   *out = nullptr;
@@ -140,11 +149,11 @@ int dslam_engine_create(int device_index, dslam_engine **out) {
   DSLAM_HIP(hipSetDevice(device_index));
   dslam_engine *e = new dslam_engine();
   e->device = device_index;
-  DSLAM_HIP(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
-  e->pinned_bytes = 64 * 1024;
-  DSLAM_HIP(hipHostMalloc(&e->pinned, e->pinned_bytes, hipHostMallocDefault));
-  memset(e->pinned, 0, e->pinned_bytes);
-  DSLAM_HIP(hipMalloc(&e->misc_counter, 16 * sizeof(int)));
+  const int rc = engine_allocate(e);
+  if (rc) {
+    (void)dslam_engine_destroy(e);
+    return rc;
+  }
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, device_index) == hipSuccess) e->sm_count = prop.multiProcessorCount;
   *out = e;
@@ -154,7 +163,7 @@ int dslam_engine_create(int device_index, dslam_engine **out) {
 int dslam_engine_destroy(dslam_engine *e) {
   if (!e) return DSLAM_OK;
   (void)hipSetDevice(e->device);
-  (void)hipStreamSynchronize(e->stream);
+  if (e->stream) (void)hipStreamSynchronize(e->stream);
   free_dev(e->order_keys); free_dev(e->block_coords); free_dev(e->tile_counts); free_dev(e->tile_offsets);
   free_dev(e->list_a); free_dev(e->list_b); free_dev(e->list_c); free_dev(e->pos_scratch);
   if (e->staging_dev) (void)hipFree(e->staging_dev);
@@ -165,7 +174,7 @@ int dslam_engine_destroy(dslam_engine *e) {
   free_dev(e->mesh_positions); free_dev(e->mesh_colours);
   if (e->icp_partials_host) (void)hipHostFree(e->icp_partials_host);  // (icp_partials is its device alias)
   for (auto ev : e->ev_pool) (void)hipEventDestroy(ev);
-  (void)hipStreamDestroy(e->stream);
+  if (e->stream) (void)hipStreamDestroy(e->stream);
   delete e;
   return DSLAM_OK;
 }
@@ -200,26 +209,9 @@ int dslam_engine_synchronize(dslam_engine *e) {
 void *dslam_engine_stream(dslam_engine *e) { return e ? (void *)e->stream : nullptr; }
 
 // ---- scene ---------------------------------------------------------------------------------------------------
-int dslam_scene_create(dslam_engine *e, const dslam_scene_params *p, void *ext_voxels, dslam_scene **out) {
-  DSLAM_REQUIRE(e && p && out, "null argument");
-  *out = nullptr;
-  DSLAM_HIP(hipSetDevice(e->device));
-  dslam_scene *s = new dslam_scene();
-  s->version = next_map_version();
-  s->engine = e;
-  s->p = *p;
-  if (s->p.num_local_blocks <= 0) s->p.num_local_blocks = DSLAM_DEFAULT_LOCAL_BLOCK_NUM;
-  if (s->p.num_buckets <= 0) s->p.num_buckets = DSLAM_DEFAULT_BUCKET_NUM;
-  if (s->p.num_excess <= 0) s->p.num_excess = DSLAM_DEFAULT_EXCESS_LIST_SIZE;
-  if (s->p.history_words <= 0) s->p.history_words = 4;
-  s->history_words = s->p.history_words;
-  if ((s->p.num_buckets & (s->p.num_buckets - 1)) || ((s->p.num_buckets + s->p.num_excess) & 15) ||
-      s->p.max_w < 1 || s->p.max_w > 255 || !(s->p.voxel_size > 0) || !(s->p.mu > 0)) {
-    delete s;
-    set_last_error("invalid scene parameters (buckets must be a power of two, entries a multiple of 16, 1<=max_w<=255)");
-    return DSLAM_ERR_INVALID;
-  }
-  s->n_entries = s->p.num_buckets + s->p.num_excess;
+// every device / pinned allocation of a scene; on failure the caller destroys the half-built object (the destroy
+// function frees whatever is there), so no error path leaks
+static int scene_allocate(dslam_engine *e, dslam_scene *s, void *ext_voxels) {
   const size_t vox_bytes = (size_t)s->p.num_local_blocks * kBlock3 * sizeof(uint2);
   DSLAM_HIP(hipMalloc(&s->hash, (size_t)s->n_entries * sizeof(HashEntry)));
   if (ext_voxels) {
@@ -243,9 +235,36 @@ int dslam_scene_create(dslam_engine *e, const dslam_scene_params *p, void *ext_v
   }
   int rc = ensure_scratch(e, s->n_entries, s->p.num_local_blocks);
   if (rc) return rc;
-  rc = launch_scene_reset(e, s);
-  if (rc) return rc;
+  if ((rc = launch_scene_reset(e, s))) return rc;
   DSLAM_HIP(hipStreamSynchronize(e->stream));
+  return DSLAM_OK;
+}
+
+int dslam_scene_create(dslam_engine *e, const dslam_scene_params *p, void *ext_voxels, dslam_scene **out) {
+  DSLAM_REQUIRE(e && p && out, "null argument");
+  *out = nullptr;
+  DSLAM_HIP(hipSetDevice(e->device));
+  dslam_scene *s = new dslam_scene();
+  s->version = next_map_version();
+  s->engine = e;
+  s->p = *p;
+  if (s->p.num_local_blocks <= 0) s->p.num_local_blocks = DSLAM_DEFAULT_LOCAL_BLOCK_NUM;
+  if (s->p.num_buckets <= 0) s->p.num_buckets = DSLAM_DEFAULT_BUCKET_NUM;
+  if (s->p.num_excess <= 0) s->p.num_excess = DSLAM_DEFAULT_EXCESS_LIST_SIZE;
+  if (s->p.history_words <= 0) s->p.history_words = 4;
+  s->history_words = s->p.history_words;
+  if ((s->p.num_buckets & (s->p.num_buckets - 1)) || ((s->p.num_buckets + s->p.num_excess) & 15) ||
+      s->p.max_w < 1 || s->p.max_w > 255 || !(s->p.voxel_size > 0) || !(s->p.mu > 0)) {
+    delete s;
+    set_last_error("invalid scene parameters (buckets must be a power of two, entries a multiple of 16, 1<=max_w<=255)");
+    return DSLAM_ERR_INVALID;
+  }
+  s->n_entries = s->p.num_buckets + s->p.num_excess;
+  const int rc = scene_allocate(e, s, ext_voxels);
+  if (rc) {
+    (void)dslam_scene_destroy(s);  // frees whatever was allocated before the failure (last_error is kept)
+    return rc;
+  }
   *out = s;
   return DSLAM_OK;
 }
@@ -332,11 +351,8 @@ int dslam_shard_unpack(dslam_engine *e, dslam_scene *s, int first_block, int gro
 }
 
 // ---- render state / view --------------------------------------------------------------------------------------
-int dslam_render_state_create(dslam_engine *e, const dslam_scene *s, int w, int h, dslam_render_state **out) {
-  DSLAM_REQUIRE(e && s && out && w > 0 && h > 0, "bad argument");
-  dslam_render_state *r = new dslam_render_state();
-  r->engine = e; r->w = w; r->h = h; r->n_entries = s->n_entries; r->n_local = s->p.num_local_blocks;
-  const size_t npix = (size_t)w * h;
+static int render_state_allocate(dslam_engine *e, dslam_render_state *r) {
+  const size_t npix = (size_t)r->w * r->h;
   DSLAM_HIP(hipMalloc(&r->visible_ids, (size_t)r->n_local * sizeof(int)));
   DSLAM_HIP(hipMalloc(&r->visible_type, r->n_entries));
   DSLAM_HIP(hipMalloc(&r->range, npix * sizeof(float2)));
@@ -355,6 +371,19 @@ int dslam_render_state_create(dslam_engine *e, const dslam_scene *s, int w, int 
   DSLAM_HIP(hipMemsetAsync(r->image_rgba, 0, npix * sizeof(uchar4), e->stream));
   DSLAM_HIP(hipMemsetAsync(r->image_float, 0, npix * sizeof(float), e->stream));
   DSLAM_HIP(hipStreamSynchronize(e->stream));
+  return DSLAM_OK;
+}
+
+int dslam_render_state_create(dslam_engine *e, const dslam_scene *s, int w, int h, dslam_render_state **out) {
+  DSLAM_REQUIRE(e && s && out && w > 0 && h > 0, "bad argument");
+  *out = nullptr;
+  dslam_render_state *r = new dslam_render_state();
+  r->engine = e; r->w = w; r->h = h; r->n_entries = s->n_entries; r->n_local = s->p.num_local_blocks;
+  const int rc = render_state_allocate(e, r);
+  if (rc) {
+    (void)dslam_render_state_destroy(r);
+    return rc;
+  }
   *out = r;
   return DSLAM_OK;
 }
@@ -364,15 +393,14 @@ int dslam_render_state_destroy(dslam_render_state *r) {
   (void)hipStreamSynchronize(r->engine->stream);
   free_dev(r->visible_ids); free_dev(r->visible_type); free_dev(r->range); free_dev(r->raycast);
   free_dev(r->image_rgba); free_dev(r->image_float); free_dev(r->icp_points); free_dev(r->icp_normals);
+  free_dev(r->raycast_image);
   free_dev(r->proj_boxes); free_dev(r->proj_z); free_dev(r->proj_req); free_dev(r->proj_wg_tiles); free_dev(r->counters);
   delete r;
   return DSLAM_OK;
 }
 
-int dslam_view_create(dslam_engine *e, int w_rgb, int h_rgb, int w_d, int h_d, dslam_view **out) {
-  DSLAM_REQUIRE(e && out && w_rgb > 0 && h_rgb > 0 && w_d > 0 && h_d > 0, "bad argument");
-  dslam_view *v = new dslam_view();
-  v->engine = e; v->w_rgb = w_rgb; v->h_rgb = h_rgb; v->w_d = w_d; v->h_d = h_d;
+static int view_allocate(dslam_engine *e, dslam_view *v) {
+  const int w_rgb = v->w_rgb, h_rgb = v->h_rgb, w_d = v->w_d, h_d = v->h_d;
   DSLAM_HIP(hipMalloc(&v->rgba, (size_t)w_rgb * h_rgb * sizeof(uchar4)));
   DSLAM_HIP(hipMalloc(&v->depth, (size_t)w_d * h_d * sizeof(float)));
   DSLAM_HIP(hipMalloc(&v->raw_depth, (size_t)w_d * h_d * sizeof(short)));
@@ -381,6 +409,19 @@ int dslam_view_create(dslam_engine *e, int w_rgb, int h_rgb, int w_d, int h_d, d
   DSLAM_HIP(hipMemsetAsync(v->depth, 0, (size_t)w_d * h_d * sizeof(float), e->stream));
   DSLAM_HIP(hipMemsetAsync(v->raw_depth, 0, (size_t)w_d * h_d * sizeof(short), e->stream));
   DSLAM_HIP(hipStreamSynchronize(e->stream));
+  return DSLAM_OK;
+}
+
+int dslam_view_create(dslam_engine *e, int w_rgb, int h_rgb, int w_d, int h_d, dslam_view **out) {
+  DSLAM_REQUIRE(e && out && w_rgb > 0 && h_rgb > 0 && w_d > 0 && h_d > 0, "bad argument");
+  *out = nullptr;
+  dslam_view *v = new dslam_view();
+  v->engine = e; v->w_rgb = w_rgb; v->h_rgb = h_rgb; v->w_d = w_d; v->h_d = h_d;
+  const int rc = view_allocate(e, v);
+  if (rc) {
+    (void)dslam_view_destroy(v);
+    return rc;
+  }
   *out = v;
   return DSLAM_OK;
 }
@@ -669,7 +710,9 @@ int dslam_depth_post_processing(dslam_engine *e, int16_t *curr_host, const int16
 // ---- fusion --------------------------------------------------------------------------------------------------
 int dslam_set_fusion_weight_params(dslam_engine *e, const dslam_weight_params *w) {
   DSLAM_REQUIRE(e && w, "null argument");
-  DSLAM_REQUIRE(!w->depth_weighting || (w->max_distance > 0 && w->max_new_w >= 1), "bad weight params");
+  // newW <= 255: the voxel weight is one byte and k_integrate indexes its reciprocal table with w_depth + newW <= 510
+  DSLAM_REQUIRE(!w->depth_weighting || (w->max_distance > 0 && w->max_new_w >= 1 && w->max_new_w <= 255),
+                "bad weight params (need max_distance > 0 and 1 <= max_new_w <= 255)");
   e->wp = *w;
   return DSLAM_OK;
 }
@@ -919,6 +962,14 @@ int dslam_create_icp_maps(dslam_engine *e, const dslam_scene *s, dslam_render_st
   if (out_normals) DSLAM_HIP(hipMemcpyAsync(out_normals, r->icp_normals, bytes, hipMemcpyDeviceToHost, e->stream));
   if (out_points || out_normals) { DSLAM_HIP(hipStreamSynchronize(e->stream)); return DSLAM_OK; }
   return finish_call(e);
+}
+
+int dslam_download_raycast_image(dslam_engine *e, const dslam_render_state *r, uint8_t *out_rgba) {
+  DSLAM_REQUIRE(e && r && out_rgba, "null argument");
+  DSLAM_REQUIRE(r->raycast_image, "dslam_create_icp_maps has not run on this render state");
+  DSLAM_HIP(hipMemcpyAsync(out_rgba, r->raycast_image, (size_t)r->w * r->h * 4, hipMemcpyDeviceToHost, e->stream));
+  DSLAM_HIP(hipStreamSynchronize(e->stream));
+  return DSLAM_OK;
 }
 
 int dslam_download_icp_maps(dslam_engine *e, const dslam_render_state *r, float *out_points, float *out_normals) {

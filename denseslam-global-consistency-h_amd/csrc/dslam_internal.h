@@ -118,9 +118,10 @@ struct dslam_render_state {
   unsigned char *visible_type = nullptr;
   float2 *range = nullptr;      // renderingRangeImage (full image stride)
   float4 *raycast = nullptr;    // raycastResult
-  uchar4 *image_rgba = nullptr; // raycastImage
+  uchar4 *image_rgba = nullptr; // RenderImage's outputImage (rgba types)
   float *image_float = nullptr;
   float4 *icp_points = nullptr, *icp_normals = nullptr;  // allocated on first use
+  uchar4 *raycast_image = nullptr;  // ITMRenderState::raycastImage: the grey tracking raycast CreateICPMaps draws (with the maps)
   int4 *proj_boxes = nullptr;   // per visible block: render bbox (ul.x, ul.y, lr.x, lr.y)
   float2 *proj_z = nullptr;     // per visible block: z range
   int *proj_req = nullptr;      // per visible block: render tiles required (0 = invalid projection)

@@ -124,13 +124,27 @@ int launch_selftest_division(dslam_engine *e, long long samples, unsigned long l
   return DSLAM_OK;
 }
 
-constexpr int kInvTab = 512;  // reciprocals of the integer weights 1..511 (w_depth <= 255, newW <= 255)
+constexpr int kInvTab = 512;  // reciprocals of the integer weights 1..511 (w_depth <= 255, newW <= 255: the ABI rejects
+                              // max_new_w > 255, so w_depth + newW <= 510 always indexes inside the table)
+
+// A voxel is skipped unless its camera-frame depth is a NORMAL positive float (upstream: `pt_camera.z <= 0` skips).
+// A denormal z (> 0, < 1.18e-38 m: the voxel centre lies in the camera plane to within nothing) would be divided by:
+// v_rcp_f32 has no denormal support (-> inf -> NaN in the scaling-free division below), and NaN passes every
+// `u < 1 || u > W - 2` test, so the depth image would be indexed with (int)NaN.  Both the kernel and the oracle
+// therefore treat a denormal z like z <= 0, and every bounds test is written so that NaN fails it.
+constexpr float kMinCamZ = 1.17549435e-38f;  // FLT_MIN
+
+__device__ __forceinline__ bool in_image(float u, float w, float umax, float wmax) {
+  return u >= 1.0f && u <= umax && w >= 1.0f && w <= wmax;  // false for NaN
+}
 
 __device__ __forceinline__ int new_weight(const IntegrateParams &p, float depth_measure) {
   if (!p.depth_weighting) return 1;
   const float dd = depth_measure < p.max_distance ? depth_measure : p.max_distance;
   const int w = (int)roundf((float)p.max_new_w * (1.0f - dd / p.max_distance));
-  return w < 1 ? 1 : w;
+  // (the upper clamp never acts on a measured depth > 0; it keeps the table index of an inactive lane, which
+  // evaluates this on depth[0] whatever that holds, inside the table)
+  return w < 1 ? 1 : (w > p.max_new_w ? p.max_new_w : w);
 }
 
 __device__ __forceinline__ void bilinear_rgb(const uchar4 *__restrict__ rgba, float px, float py, int W, float out[3]) {
@@ -155,10 +169,10 @@ __device__ __forceinline__ bool update_voxel(unsigned &lo, unsigned &hi, const V
   float eta, eta_mu, u, w;
   bool changed = false;
   {  // computeUpdatedVoxelDepthInfo
-    if (pc.z <= 0) return false;
+    if (!(pc.z >= kMinCamZ)) return false;
     u = p.fx_d * pc.x / pc.z + p.cx_d;
     w = p.fy_d * pc.y / pc.z + p.cy_d;
-    if ((u < 1) || (u > p.Wd - 2) || (w < 1) || (w > p.Hd - 2)) return false;
+    if (!in_image(u, w, (float)(p.Wd - 2), (float)(p.Hd - 2))) return false;
     const float dm = p.depth[(int)(u + 0.5f) + (int)(w + 0.5f) * p.Wd];
     if (dm <= 0.0f) return false;
     eta = dm - pc.z;
@@ -195,7 +209,7 @@ __device__ __forceinline__ bool update_voxel(unsigned &lo, unsigned &hi, const V
       const Vec4 pcr = mul(p.M_rgb, pm);
       u = p.fx_r * pcr.x / pcr.z + p.cx_r;
       w = p.fy_r * pcr.y / pcr.z + p.cy_r;
-      if ((u < 1) || (u > p.Wr - 2) || (w < 1) || (w > p.Hr - 2)) return changed;
+      if (!in_image(u, w, (float)(p.Wr - 2), (float)(p.Hr - 2))) return changed;
     }
     float m[3];
     bilinear_rgb(p.rgba, u, w, p.Wr, m);
@@ -265,7 +279,7 @@ __device__ __forceinline__ bool fuse_colour(unsigned &lo, unsigned &hi, float u,
     const Vec4 pcr = mul(p.M_rgb, pm);
     u = p.fx_r * pcr.x / pcr.z + p.cx_r;
     w = p.fy_r * pcr.y / pcr.z + p.cy_r;
-    if ((u < 1) || (u > p.Wr - 2) || (w < 1) || (w > p.Hr - 2)) return false;
+    if (!in_image(u, w, (float)(p.Wr - 2), (float)(p.Hr - 2))) return false;
   }
   float m[3];
   bilinear_rgb(p.rgba, u, w, p.Wr, m);
@@ -293,7 +307,7 @@ __device__ __forceinline__ bool fuse_colour(unsigned &lo, unsigned &hi, float u,
 template <bool SAME_CAM>
 __device__ __forceinline__ bool fuse_pair(uint4 &vv, f2 pcx, f2 pcy, f2 pcz, const Vec4 &pm0, const Vec4 &pm1,
                                           const IntegrateParams &p, const float *inv_tab) {
-  bool act0 = pcz.x > 0.0f, act1 = pcz.y > 0.0f;
+  bool act0 = pcz.x >= kMinCamZ, act1 = pcz.y >= kMinCamZ;
   if (p.stop_max) {
     act0 = act0 && (int)((vv.x >> 16) & 0xffu) != p.max_w;
     act1 = act1 && (int)((vv.z >> 16) & 0xffu) != p.max_w;
@@ -303,8 +317,8 @@ __device__ __forceinline__ bool fuse_pair(uint4 &vv, f2 pcx, f2 pcy, f2 pcz, con
   const f2 u = div_ieee2(fx2 * pcx, pcz) + cx2;  // projParams.x * pt.x / pt.z + projParams.z
   const f2 w = div_ieee2(fy2 * pcy, pcz) + cy2;
   const float wmax = (float)(p.Wd - 2), hmax = (float)(p.Hd - 2);
-  act0 = act0 && !((u.x < 1) || (u.x > wmax) || (w.x < 1) || (w.x > hmax));
-  act1 = act1 && !((u.y < 1) || (u.y > wmax) || (w.y < 1) || (w.y > hmax));
+  act0 = act0 && in_image(u.x, w.x, wmax, hmax);
+  act1 = act1 && in_image(u.y, w.y, wmax, hmax);
   if (!(act0 || act1)) return false;
   const f2 half = {0.5f, 0.5f};
   const f2 ur = u + half, wr = w + half;

@@ -966,14 +966,18 @@ int launch_render(dslam_engine *e, const dslam_scene *s, dslam_render_state *r, 
 // ---------------------------------------------------------------------------------------------------------
 // CreateICPMaps: processPixelICP<useSmoothing = true, flipNormals = false>
 // ---------------------------------------------------------------------------------------------------------
+// Also drawPixelGrey into renderState->raycastImage: the picture ITMMainEngine::GetImage(InfiniTAM_IMAGE_SCENERAYCAST)
+// copies out (PreviewType::kRaycastImage, InfiniTamDriver.cpp:28-29) -- (0.8 angle + 0.2) 255 on all four channels, 0
+// where the ray found nothing.
 __global__ __launch_bounds__(256) void k_icp_maps(const float4 *__restrict__ pr, int W, int H, float vs, float lx,
-                                                  float ly, float lz, float4 *points, float4 *normals) {
+                                                  float ly, float lz, float4 *points, float4 *normals,
+                                                  uchar4 *grey) {
   const int x = blockIdx.x * 16 + (threadIdx.x & 15), y = blockIdx.y * 16 + (threadIdx.x >> 4);
   if (x >= W || y >= H) return;
   const int loc = x + y * W;
   const float4 point = pr[loc];
   bool found = point.w > 0.0f;
-  float nx = 0, ny = 0, nz = 0;
+  float nx = 0, ny = 0, nz = 0, angle = 0.0f;
   if (found && (y <= 2 || y >= H - 3 || x <= 2 || x >= W - 3)) found = false;
   if (found) {
     float4 xp = pr[(x + 2) + y * W], yp = pr[x + (y + 2) * W], xm = pr[(x - 2) + y * W], ym = pr[x + (y - 2) * W];
@@ -998,14 +1002,17 @@ __global__ __launch_bounds__(256) void k_icp_maps(const float4 *__restrict__ pr,
       nz = -(dx.x * dy.y - dx.y * dy.x);
       const float ns = 1.0f / sqrtf(nx * nx + ny * ny + nz * nz);
       nx *= ns; ny *= ns; nz *= ns;
-      const float angle = nx * lx + ny * ly + nz * lz;
+      angle = nx * lx + ny * ly + nz * lz;
       if (!(angle > 0.0f)) found = false;
     }
   }
   if (found) {
+    const unsigned char g = (unsigned char)((0.8f * angle + 0.2f) * 255.0f);
+    grey[loc] = make_uchar4(g, g, g, g);
     points[loc] = make_float4(point.x * vs, point.y * vs, point.z * vs, 1.0f);
     normals[loc] = make_float4(nx, ny, nz, 0.0f);
   } else {
+    grey[loc] = make_uchar4(0, 0, 0, 0);
     points[loc] = make_float4(0.0f, 0.0f, 0.0f, -1.0f);
     normals[loc] = make_float4(0.0f, 0.0f, 0.0f, -1.0f);
   }
@@ -1015,6 +1022,7 @@ int launch_icp_maps(dslam_engine *e, const dslam_scene *s, dslam_render_state *r
   if (!r->icp_points) {
     DSLAM_HIP(hipMalloc(&r->icp_points, (size_t)r->w * r->h * sizeof(float4)));
     DSLAM_HIP(hipMalloc(&r->icp_normals, (size_t)r->w * r->h * sizeof(float4)));
+    DSLAM_HIP(hipMalloc(&r->raycast_image, (size_t)r->w * r->h * sizeof(uchar4)));
   }
   RenderParams rp;
   int rc = fill_render_params(rp, s, r, M, intr, -1);
@@ -1022,7 +1030,7 @@ int launch_icp_maps(dslam_engine *e, const dslam_scene *s, dslam_render_state *r
   const dim3 grid((r->w + 15) / 16, (r->h + 15) / 16);
   hipLaunchKernelGGL((k_render<1, false>), dim3((r->w + 7) / 8, (r->h + 7) / 8), dim3(64), 0, e->stream, rp);
   hipLaunchKernelGGL(k_icp_maps, grid, dim3(256), 0, e->stream, r->raycast, r->w, r->h, s->p.voxel_size, -rp.invM.m[8],
-                     -rp.invM.m[9], -rp.invM.m[10], r->icp_points, r->icp_normals);
+                     -rp.invM.m[9], -rp.invM.m[10], r->icp_points, r->icp_normals, r->raycast_image);
   DSLAM_HIP(hipGetLastError());
   return DSLAM_OK;
 }

@@ -165,6 +165,9 @@ class ITMTrackingController {
     ts->normalsMap->SetHostPull([eng, h](Vector4f *dst) { dslam_check(dslam_download_icp_maps(eng, h, nullptr, &dst->x), "dslam_download_icp_maps"); });
     ts->pointsMap->MarkHostStale();
     ts->normalsMap->MarkHostStale();
+    // renderState->raycastImage: the grey rendering CreateICPMaps draws next to the maps (InfiniTAM_IMAGE_SCENERAYCAST)
+    rs->raycastImage->SetHostPull([eng, h](Vector4u *dst) { dslam_check(dslam_download_raycast_image(eng, h, &dst->x), "dslam_download_raycast_image"); });
+    rs->raycastImage->MarkHostStale();
     ts->pose_pointCloud->SetM(M);
     ts->preparedWith = rs;
     ts->age_pointCloud = 0;
@@ -267,7 +270,8 @@ class ITMMainEngine {
   ITMLocalMap *GetPrimaryLocalMap() const { return mapManager->getLocalMap(0); }
 
   /// FREECAMERA_* render the given local map (primary when null; nothing before the first keyframe, B.1);
-  /// SCENERAYCAST shows the tracking raycast, which only Prepare produces; ORIGINAL_* copy the view.
+  /// SCENERAYCAST copies renderState->raycastImage, the grey tracking raycast trackingController->Prepare draws
+  /// (zero until the first Prepare, as upstream); ORIGINAL_* copy the view.
   void GetImage(ITMUChar4Image *out, ITMFloatImage *outFloat, GetImageType type, ITMPose *pose = nullptr,
                 ITMIntrinsics *intrinsics = nullptr, const ITMLocalMap *localMap = nullptr) {
     if (view == nullptr) return;

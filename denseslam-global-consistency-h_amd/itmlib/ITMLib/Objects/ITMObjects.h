@@ -2,6 +2,7 @@
 // ITMLocalMap: the object surface InfiniTamDriver / DenseSlam touch, each holding the C-ABI
 // handle of its device-side counterpart.
 #pragma once
+#include <cstdlib>
 #include <memory>
 #include <string>
 #include <vector>
@@ -91,9 +92,32 @@ class ITMSceneParams {
         stopIntegratingAtMaxW(stopAtMax) {}
 };
 
-/// ITMLibSettings is default-constructed by the reference and never edited (SystemEntry.cpp:238-243).  The fork's
-/// defaults are not knowable; these are the upstream InfiniTAM v2 defaults, with the device fixed to HIP.
+/// ITMLibSettings is default-constructed by the reference and never edited (SystemEntry.cpp:238-243), so whatever
+/// scene parameters a run uses are the ones this constructor sets.  The fork's defaults are not knowable; these are
+/// the upstream InfiniTAM v2 defaults (5 mm voxels, 3 m frustum: an indoor RGB-D set-up), with the device fixed to HIP.
+/// A KITTI-scale run needs other values: either two lines after SystemEntry.cpp:238
+/// (`driver_settings->sceneParams = ITMSceneParams(mu, maxW, voxelSize, vfMin, vfMax, false);`), or -- with the
+/// reference sources untouched -- the environment of the process, read here once per construction:
+///   DSLAM_VOXEL_SIZE, DSLAM_MU, DSLAM_FRUSTUM_MIN, DSLAM_FRUSTUM_MAX (metres), DSLAM_MAX_W, DSLAM_USE_SWAPPING,
+///   DSLAM_USE_BILATERAL_FILTER, DSLAM_LOCAL_BLOCKS, DSLAM_BUCKETS, DSLAM_EXCESS, DSLAM_DEVICE
+/// (unset or unparsable variables leave the default).
 class ITMLibSettings {
+  static void envFloat(const char *name, float &v) {
+    const char *s = getenv(name);
+    if (s == nullptr || *s == 0) return;
+    char *end = nullptr;
+    const float x = strtof(s, &end);
+    if (end != s && x > 0.0f) v = x;
+  }
+  static void envInt(const char *name, int &v) {
+    const char *s = getenv(name);
+    if (s == nullptr || *s == 0) return;
+    char *end = nullptr;
+    const long x = strtol(s, &end, 0);
+    if (end != s && x >= 0) v = (int)x;
+  }
+  static void envBool(const char *name, bool &v) { int x = v ? 1 : 0; envInt(name, x); v = x != 0; }
+
  public:
   typedef enum { DEVICE_CPU, DEVICE_CUDA, DEVICE_HIP } DeviceType;
   DeviceType deviceType;
@@ -118,6 +142,12 @@ class ITMLibSettings {
     trackingRegime[2] = TRACKER_ITERATION_ROTATION; trackingRegime[3] = TRACKER_ITERATION_ROTATION;
     trackingRegime[4] = TRACKER_ITERATION_ROTATION;
     for (int i = 5; i < 8; i++) trackingRegime[i] = TRACKER_ITERATION_NONE;
+    envFloat("DSLAM_VOXEL_SIZE", sceneParams.voxelSize); envFloat("DSLAM_MU", sceneParams.mu);
+    envFloat("DSLAM_FRUSTUM_MIN", sceneParams.viewFrustum_min); envFloat("DSLAM_FRUSTUM_MAX", sceneParams.viewFrustum_max);
+    envInt("DSLAM_MAX_W", sceneParams.maxW);
+    envBool("DSLAM_USE_SWAPPING", useSwapping); envBool("DSLAM_USE_BILATERAL_FILTER", useBilateralFilter);
+    envInt("DSLAM_LOCAL_BLOCKS", numLocalBlocks); envInt("DSLAM_BUCKETS", numBuckets); envInt("DSLAM_EXCESS", numExcess);
+    envInt("DSLAM_DEVICE", hipDeviceIndex);
   }
 };
 

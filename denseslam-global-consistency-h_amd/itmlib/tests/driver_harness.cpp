@@ -14,7 +14,9 @@
 //             from the pose of the frame before it);
 //             with keyframes.bin, per frame: int32 nCorrected, double ts[nCorrected] (in re-fusion order),
 //             int32 nCulled, int32 databaseSize;
-//             trailer: uint64 fnv1a(view->rgb host mirror), uint64 fnv1a(view->depth host mirror),
+//             trailer: uint64 fnv1a(GetImage(kRaycastImage = InfiniTAM_IMAGE_SCENERAYCAST) after Prepare), int32 its
+//             non-zero bytes before the first Prepare (must be 0), int32 after;
+//             uint64 fnv1a(view->rgb host mirror), uint64 fnv1a(view->depth host mirror),
 //             int32 valid points, int32 valid normals of the tracking state's host ICP maps
 #include <chrono>
 #include <cstdint>
@@ -172,8 +174,10 @@ int main(int argc, char **argv) {
 
   try {
     ITMLibSettings *settings = new ITMLibSettings();  // SystemEntry.cpp:238
-    settings->sceneParams = ITMSceneParams(sp[1], ip[0], sp[0], sp[2], sp[3], false);
-    settings->numLocalBlocks = ip[1]; settings->numBuckets = ip[2]; settings->numExcess = ip[3];
+    if (getenv("DRIVER_HARNESS_SETTINGS_FROM_ENV") == nullptr) {
+      settings->sceneParams = ITMSceneParams(sp[1], ip[0], sp[0], sp[2], sp[3], false);
+      settings->numLocalBlocks = ip[1]; settings->numBuckets = ip[2]; settings->numExcess = ip[3];
+    }  // else: exactly the reference's two lines -- the settings object is used as constructed (DSLAM_* environment)
     // CreateItmCalib (InfiniTamDriver.cpp:55-81)
     ITMRGBDCalib *calib = new ITMRGBDCalib;
     ITMIntrinsics intrinsics;
@@ -265,7 +269,21 @@ int main(int argc, char **argv) {
     free_pose.SetM(poses[N - 1]);
     drv.GetFloatImage(&out_float, free_pose, currentLocalMap);                // DenseSlam.h:146-153
     drv.GetImage(&out_rgba, ITMMainEngine::InfiniTAM_IMAGE_FREECAMERA_COLOUR_FROM_VOLUME, free_pose, currentLocalMap);
+    // PreviewType::kRaycastImage -> InfiniTAM_IMAGE_SCENERAYCAST (InfiniTamDriver.cpp:28-29): the grey tracking raycast;
+    // nothing has drawn it before the first Prepare (the reference's ORB-SLAM2 mode never does), afterwards it is there
+    ITMUChar4Image out_ray(Vector2i(W, H), true, true);
+    auto nonzero = [&](ITMUChar4Image &img) {
+      int32_t n = 0;
+      const uint8_t *b = &img.GetData(MEMORYDEVICE_CPU)->x;
+      for (size_t i = 0; i < (size_t)W * H * 4; i++) n += b[i] != 0;
+      return n;
+    };
+    drv.GetImage(&out_ray, ITMMainEngine::InfiniTAM_IMAGE_SCENERAYCAST, free_pose, currentLocalMap);
+    const int32_t ray_nonzero_before = nonzero(out_ray);
     drv.PrepareNextStepLocalMap(currentLocalMap);
+    drv.GetImage(&out_ray, ITMMainEngine::InfiniTAM_IMAGE_SCENERAYCAST, free_pose, currentLocalMap);
+    const int32_t ray_nonzero_after = nonzero(out_ray);
+    const uint64_t ray_sum = fnv1a(out_ray.GetData(MEMORYDEVICE_CPU), (size_t)W * H * 4);
     // DenseSlam::ProcessFrame without ORB-SLAM2 odometry (DenseSlam.cpp:200-206): Prepare, UpdateView, TrackLocalMap.
     // The view still holds the last frame; start from the previous frame's pose and let the tracker pull it over.
     Matrix4f trackedM = poses[N - 1];
@@ -317,6 +335,9 @@ int main(int argc, char **argv) {
       const Vector4f *nrm = currentLocalMap->trackingState->normalsMap->GetData(MEMORYDEVICE_CPU);
       int32_t valid[2] = {0, 0};
       for (size_t i = 0; i < npx; i++) { valid[0] += pts[i].w > 0.0f; valid[1] += nrm[i].w == 0.0f; }
+      const int32_t ray_counts[2] = {ray_nonzero_before, ray_nonzero_after};
+      fwrite(&ray_sum, 8, 1, o);
+      fwrite(ray_counts, 4, 2, o);
       fwrite(mirror, 8, 2, o);
       fwrite(valid, 4, 2, o);
     }

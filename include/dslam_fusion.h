@@ -87,7 +87,7 @@ typedef struct {
  * InfiniTamDriver.h:189,196). */
 typedef struct {
   int32_t depth_weighting;
-  int32_t max_new_w;
+  int32_t max_new_w;   /* 1..255 (a voxel weight is one byte; the kernels tabulate 1/(w_depth + newW)) */
   float max_distance;
 } dslam_weight_params;
 
@@ -332,6 +332,14 @@ int dslam_get_image(dslam_engine *e, const dslam_scene *s, dslam_render_state *r
  * Vector4f per pixel (points: metres, world frame, w = 1 or -1; normals: w = 0 or -1); may be NULL. */
 int dslam_create_icp_maps(dslam_engine *e, const dslam_scene *s, dslam_render_state *r, const float M[16],
                           const float intrinsics[4], float *out_points_host, float *out_normals_host);
+/* ITMMainEngine::GetImage(out, NULL, InfiniTAM_IMAGE_SCENERAYCAST, ...) = PreviewType::kRaycastImage
+ * (InfiniTamDriver.cpp:28-29), the GUI's default rgb preview (DenseSLAMGUI.h:240): a copy of renderState->raycastImage,
+ * the grey rendering upstream's CreateICPMaps draws with the ICP maps (processPixelICP -> drawPixelGrey: all four
+ * channels (uchar)((0.8 angle + 0.2) 255) with the image-space normal, 0 where the ray found nothing), i.e. what
+ * dslam_create_icp_maps (PrepareNextStepLocalMap, InfiniTamDriver.h:208-220) last left in this render state.
+ * Vector4u per pixel.  DSLAM_ERR_INVALID before the first dslam_create_icp_maps (upstream: a zero image -- the
+ * mirror's GetImage returns that). */
+int dslam_download_raycast_image(dslam_engine *e, const dslam_render_state *r, uint8_t *out_rgba_host);
 
 /* ---- meshing export ---------------------------------------------------------------------------- */
 /* ITMMainEngine::SaveCurrSceneToMesh(objFileName, scene) -> ITMMeshingEngine::MeshScene(mesh, scene) (DenseSlam.cpp:

@@ -176,6 +176,7 @@ struct oracle_render_state {
   std::vector<uint8_t> image_rgba;
   std::vector<float> image_float;
   std::vector<V4f> icp_points, icp_normals;  // CreateICPMaps output, kept for the depth tracker
+  std::vector<uint8_t> raycast_image;        // ITMRenderState::raycastImage: CreateICPMaps' grey rendering (drawPixelGrey)
 };
 
 struct oracle_view {
@@ -486,7 +487,12 @@ extern "C" int oracle_max_threads(void) {
   return 1;
 #endif
 }
-extern "C" int oracle_set_fusion_weight_params(oracle_engine *e, const dslam_weight_params *w) { e->wp = *w; return 0; }
+extern "C" int oracle_set_fusion_weight_params(oracle_engine *e, const dslam_weight_params *w) {
+  // same contract as dslam_set_fusion_weight_params: a voxel weight is one byte
+  if (w->depth_weighting && !(w->max_distance > 0 && w->max_new_w >= 1 && w->max_new_w <= 255)) return DSLAM_ERR_INVALID;
+  e->wp = *w;
+  return 0;
+}
 
 // ResetScene (InfiniTamDriver.h:354-360)
 extern "C" int oracle_scene_reset(oracle_engine *, oracle_scene *s) {
@@ -962,8 +968,16 @@ static inline int new_weight(const dslam_weight_params &wp, float depth_measure)
   if (!wp.depth_weighting) return 1;
   float dd = depth_measure < wp.max_distance ? depth_measure : wp.max_distance;
   int w = (int)roundf((float)wp.max_new_w * (1.0f - dd / wp.max_distance));
-  return w < 1 ? 1 : w;
+  return w < 1 ? 1 : (w > wp.max_new_w ? wp.max_new_w : w);  // (the upper clamp never acts for a measured depth > 0)
 }
+
+// Upstream skips a voxel with `pt_camera.z <= 0` and then tests `u < 1 || u > W - 2 || ...`, which NaN passes.  Here a
+// voxel is skipped unless its camera depth is a NORMAL positive float (a denormal z -- the voxel centre in the camera
+// plane to within 1e-38 m -- is "not in front of the camera"), and the image-bounds tests are written so that NaN
+// fails them: no pose, however degenerate, can index the depth / colour image with (int)NaN.  Identical to upstream
+// for every finite, non-degenerate input.  The HIP kernel states the same two rules (csrc/integrate.hip kMinCamZ).
+static constexpr float kMinCamZ = 1.17549435e-38f;  // FLT_MIN
+static inline bool in_image(float u, float w, float umax, float wmax) { return u >= 1.0f && u <= umax && w >= 1.0f && w <= wmax; }
 
 template <bool DEINTEGRATE>
 static inline void update_voxel(dslam_voxel &vox, const V4f &pt_model, const float *M_d, const float *proj_d,
@@ -973,10 +987,10 @@ static inline void update_voxel(dslam_voxel &vox, const V4f &pt_model, const flo
   float eta;
   {
     V4f pc = mul(M_d, pt_model);
-    if (pc.z <= 0) return;
+    if (!(pc.z >= kMinCamZ)) return;
     float u = proj_d[0] * pc.x / pc.z + proj_d[2];
     float w = proj_d[1] * pc.y / pc.z + proj_d[3];
-    if ((u < 1) || (u > Wd - 2) || (w < 1) || (w > Hd - 2)) return;
+    if (!in_image(u, w, (float)(Wd - 2), (float)(Hd - 2))) return;
     float dm = depth[(int)(u + 0.5f) + (int)(w + 0.5f) * Wd];
     if (dm <= 0.0f) return;
     eta = dm - pc.z;
@@ -1011,7 +1025,7 @@ static inline void update_voxel(dslam_voxel &vox, const V4f &pt_model, const flo
     V4f pc = mul(M_rgb, pt_model);
     float u = proj_rgb[0] * pc.x / pc.z + proj_rgb[2];
     float w = proj_rgb[1] * pc.y / pc.z + proj_rgb[3];
-    if ((u < 1) || (u > Wr - 2) || (w < 1) || (w > Hr - 2)) return;
+    if (!in_image(u, w, (float)(Wr - 2), (float)(Hr - 2))) return;
     float m[3];
     bilinear_rgb(rgba, u, w, Wr, m);
     float oldW = (float)vox.w_color;
@@ -1657,6 +1671,7 @@ extern "C" int oracle_create_icp_maps(oracle_engine *e, const oracle_scene *s, o
   inv4(M, invM);
   r->icp_points.resize((size_t)W * H);
   r->icp_normals.resize((size_t)W * H);
+  r->raycast_image.resize((size_t)W * H * 4);
   oracle_create_expected_depths(e, s, r, M, intr);
   generic_raycast(e, s, r, invM, intr);
   V3f light = {-invM[8], -invM[9], -invM[10]};
@@ -1668,6 +1683,7 @@ extern "C" int oracle_create_icp_maps(oracle_engine *e, const oracle_scene *s, o
       V4f point = pr[loc];
       bool found = point.w > 0.0f;
       V3f n = {0, 0, 0};
+      float angle = 0.0f;
       if (found) {
         if (y <= 2 || y >= H - 3 || x <= 2 || x >= W - 3) found = false;
       }
@@ -1694,10 +1710,14 @@ extern "C" int oracle_create_icp_maps(oracle_engine *e, const oracle_scene *s, o
           n.z = -(dx.x * dy.y - dx.y * dy.x);
           float ns = 1.0f / sqrtf(n.x * n.x + n.y * n.y + n.z * n.z);
           n.x *= ns; n.y *= ns; n.z *= ns;
-          float angle = n.x * light.x + n.y * light.y + n.z * light.z;
+          angle = n.x * light.x + n.y * light.y + n.z * light.z;
           if (!(angle > 0.0f)) found = false;
         }
       }
+      // drawPixelGrey into renderState->raycastImage (what InfiniTAM_IMAGE_SCENERAYCAST shows, InfiniTamDriver.cpp:28-29)
+      const uint8_t g = found ? (uint8_t)((0.8f * angle + 0.2f) * 255.0f) : (uint8_t)0;
+      uint8_t *o = &r->raycast_image[(size_t)loc * 4];
+      o[0] = o[1] = o[2] = o[3] = g;
       V4f pv, nv;
       if (found) {
         pv = V4f{point.x * vs, point.y * vs, point.z * vs, 1.0f};
@@ -1711,6 +1731,12 @@ extern "C" int oracle_create_icp_maps(oracle_engine *e, const oracle_scene *s, o
       if (out_points) memcpy(out_points + (size_t)loc * 4, &pv, 16);
       if (out_normals) memcpy(out_normals + (size_t)loc * 4, &nv, 16);
     }
+  return 0;
+}
+
+extern "C" int oracle_download_raycast_image(oracle_engine *, const oracle_render_state *r, uint8_t *out) {
+  if (r->raycast_image.empty()) return DSLAM_ERR_INVALID;
+  memcpy(out, r->raycast_image.data(), r->raycast_image.size());
   return 0;
 }
 

@@ -28,8 +28,12 @@ def test_harness_is_built():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("decay,slide", [(0, -1), (1, 3)])
+@pytest.mark.parametrize("decay,slide", [(0, -1), (1, 3), (1, -3)])
 def test_driver_harness_matches_oracle(pkg, synth, oracle, tmp_path, decay, slide):
+    # slide = -3: as (1, 3), but the scene parameters reach the default-constructed ITMLibSettings through the DSLAM_*
+    # environment (SystemEntry.cpp:238-243 never edits the settings object)
+    env_settings = slide == -3
+    slide = 3 if env_settings else slide
     wl = synth.s_tiny()
     n_frames = 7
     p = util.small_params(pkg, wl, num_local_blocks=0x800, num_buckets=0x1000, num_excess=0x400)
@@ -43,8 +47,13 @@ def test_driver_harness_matches_oracle(pkg, synth, oracle, tmp_path, decay, slid
         f.write(struct.pack("<4f", p.voxel_size, p.mu, p.frustum_min, p.frustum_max))
         f.write(struct.pack("<4i", p.max_w, p.num_local_blocks, p.num_buckets, p.num_excess))
     fobj = tmp_path / "mesh.obj"
-    res = subprocess.run([HARNESS, str(fin), str(fout), str(decay), str(slide)], capture_output=True, text=True, timeout=120,
-                         env=dict(os.environ, DRIVER_HARNESS_MESH_OBJ=str(fobj), DRIVER_HARNESS_MESH_STL=str(tmp_path / "mesh.stl")))
+    env = dict(os.environ, DRIVER_HARNESS_MESH_OBJ=str(fobj), DRIVER_HARNESS_MESH_STL=str(tmp_path / "mesh.stl"))
+    if env_settings:
+        env.update(DRIVER_HARNESS_SETTINGS_FROM_ENV="1", DSLAM_VOXEL_SIZE=repr(float(p.voxel_size)), DSLAM_MU=repr(float(p.mu)),
+                   DSLAM_FRUSTUM_MIN=repr(float(p.frustum_min)), DSLAM_FRUSTUM_MAX=repr(float(p.frustum_max)),
+                   DSLAM_MAX_W=str(p.max_w), DSLAM_LOCAL_BLOCKS=hex(p.num_local_blocks), DSLAM_BUCKETS=str(p.num_buckets),
+                   DSLAM_EXCESS=str(p.num_excess))
+    res = subprocess.run([HARNESS, str(fin), str(fout), str(decay), str(slide)], capture_output=True, text=True, timeout=120, env=env)
     assert res.returncode == 0, res.stdout + res.stderr
 
     # same call sequence on the oracle (DenseSlam.cpp:210-232; Decay passes forceAllVoxels=true, InfiniTamDriver.h:280)
@@ -104,6 +113,13 @@ def test_driver_harness_matches_oracle(pkg, synth, oracle, tmp_path, decay, slid
     assert m_rgb == fnv1a(frames[-1][0].tobytes())
     assert m_depth == fnv1a(oracle.download_view_depth(v).tobytes())
     assert n_pts == int((o_pts[..., 3] > 0).sum()) and n_nrm == int((o_nrm[..., 3] == 0).sum()) and n_pts > 500
+    # GetImage(kRaycastImage -> InfiniTAM_IMAGE_SCENERAYCAST, InfiniTamDriver.cpp:28-29): all zero before the first
+    # Prepare, afterwards the grey tracking raycast CreateICPMaps drew -- the oracle's image, byte for byte
+    (ray_sum,) = struct.unpack_from("<Q", raw, len(raw) - 40)
+    ray_before, ray_after = struct.unpack_from("<2i", raw, len(raw) - 32)
+    o_ray = oracle.download_raycast_image(rs)
+    assert ray_before == 0 and ray_after == int((o_ray != 0).sum()) and ray_after > 4 * 500
+    assert ray_sum == fnv1a(o_ray.tobytes())
 
 
 RCCL_PROG = os.path.join(os.path.dirname(HARNESS), "reintegrate_rccl")

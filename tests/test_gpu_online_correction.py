@@ -149,7 +149,7 @@ def test_cpp_scheduler_matches_oracle_replay(pkg, synth, oracle, tmp_path):
         order = list(struct.unpack_from(f"<{n}d", raw, off)); off += 8 * n
         culled, size = struct.unpack_from("<2i", raw, off); off += 8
         cpp_log.append((order, culled, size))
-    assert off + 24 == len(raw)  # the rest is the host-mirror trailer
+    assert off + 40 == len(raw)  # the rest is the trailer (raycast image sums + host mirrors)
 
     # the oracle replays DenseSlam::ProcessFrame with the Python scheduler (float64 pose errors, same rules)
     s = oracle.create_scene(p)

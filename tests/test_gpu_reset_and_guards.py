@@ -1,0 +1,118 @@
+"""GPU parity for the round-2 parity holes: ResetScene on a used map (InfiniTamDriver.h:354-360), the
+InfiniTAM_IMAGE_SCENERAYCAST picture (InfiniTamDriver.cpp:28-29), the NaN / denormal guards of the voxel update and
+the WeightParams bound.  HIP engine vs CPU oracle, byte for byte."""
+import numpy as np
+import pytest
+
+import scenarios
+import util
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("swapping", [0, 1])
+def test_reset_scene_on_used_map(pkg, synth, gpu, oracle, swapping):
+    wl = synth.s_tiny()
+    p = util.small_params(pkg, wl, use_swapping=swapping)
+    g = scenarios.reset_scenario(gpu, pkg, wl, p)
+    o = scenarios.reset_scenario(oracle, pkg, wl, p)
+    for stage in ("used", "reset", "reused", "fresh", "fresh_used") + (("reset_flushed",) if swapping else ()):
+        scenarios.assert_same_full_state(g[stage], o[stage], f"{stage} (swapping={swapping})")
+    scenarios.assert_same_full_state(g["reset"], g["fresh"], "HIP: reset vs fresh scene")
+    if swapping:
+        assert g["parked_before"] == o["parked_before"] > 0 and g["stored_after_reset"] == 0
+        scenarios.assert_same_full_state(g["reset_flushed"], g["fresh"], "HIP: reset + flush vs fresh scene")
+    for k in ("img_used", "img_reset", "img_reused"):
+        assert np.array_equal(g[k] > 0, o[k] > 0) and np.abs(g[k] - o[k]).max() <= 1e-4, k
+    assert not (g["img_reset"] > 0).any(), "GetImage memo survived ResetScene"
+    assert (g["img_used"] > 0).sum() > 500 and (g["img_reused"] > 0).sum() > 500
+
+
+def test_reset_scene_full_size_default_pools(pkg, synth, gpu):
+    """640x480 S-street at the default pool sizes: after a reset the 1 GiB voxel array, the tables and the rings are
+    those of a new scene (sampled for the voxels: first, last and 64 used slots)."""
+    wl = synth.s_street(640, 480)
+    p = pkg.SceneParams(**wl.scene_kwargs)
+    s = gpu.create_scene(p)
+    rs, v = gpu.create_render_state(s, wl.W, wl.H), gpu.create_view(wl.W, wl.H)
+    scenarios.use_map(gpu, pkg, wl, s, rs, v, range(3), slide=None, decay=None)
+    used = np.nonzero(gpu.download_hash_table(s)["ptr"] >= 0)[0]
+    slots = gpu.download_hash_table(s)["ptr"][used[:: max(1, len(used) // 64)]]
+    assert len(used) > 5000
+    gpu.reset_scene(s)
+    st = gpu.stats(s)
+    assert st["last_free_block_id"] == s.params.num_local_blocks - 1 and st["last_free_excess_id"] == s.params.num_excess - 1
+    assert st["frame_counter"] == 0 and st["fusion_fifo_len"] == 0
+    h = gpu.download_hash_table(s)
+    assert (h["ptr"] == -2).all() and not h["offset"].any()
+    assert np.array_equal(gpu.download_allocation_list(s), np.arange(s.params.num_local_blocks))
+    assert (gpu.download_last_seen(s) == -1).all()
+    for slot in [0, s.params.num_local_blocks - 1] + [int(x) for x in slots]:
+        b = gpu.download_voxel_blocks(s, slot, 1)
+        assert (b["sdf"] == 32767).all() and not b["w_depth"].any() and not b["clr"].any() and not b["w_color"].any()
+    scenarios.use_map(gpu, pkg, wl, s, rs, v, range(1), slide=None, decay=None)
+    assert gpu.download_hash_table(s)["ptr"].max() == s.params.num_local_blocks - 1
+
+
+def test_raycast_image_parity(pkg, synth, gpu, oracle):
+    wl = synth.s_tiny()
+    p = util.small_params(pkg, wl)
+    res = {}
+    for name, api in (("gpu", gpu), ("oracle", oracle)):
+        s, rs, v = util.run_sequence(api, pkg, wl, p, 4)
+        with pytest.raises(pkg.DslamError):
+            api.download_raycast_image(rs)
+        M = synth.world_to_camera(wl.pose(3) @ synth.pose_matrix(synth.look_rotation(0.04, 0.02), [0.02, -0.01, 0.01]))
+        pts, nrm = api.create_icp_maps(s, rs, M, wl.intr)
+        res[name] = (api.download_raycast_image(rs), pts, nrm)
+    (gi, gp, gn), (oi, op, on) = res["gpu"], res["oracle"]
+    assert np.array_equal(gp[..., 3], op[..., 3]) and (gp[..., 3] > 0).sum() > 500
+    assert np.array_equal(gi, oi), "SCENERAYCAST image differs from the oracle"
+    assert (gi[..., 0] != 0).sum() == (gp[..., 3] > 0).sum()
+
+
+def test_degenerate_poses(pkg, synth, gpu, oracle):
+    wl = synth.s_tiny()
+    p = util.small_params(pkg, wl)
+    g = scenarios.degenerate_pose_scenario(gpu, pkg, wl, p)
+    o = scenarios.degenerate_pose_scenario(oracle, pkg, wl, p)
+    for a, b, what in zip(g, o, ("fused", "denormal camera depth", "NaN colour projection")):
+        assert np.array_equal(a.view(np.uint64), b.view(np.uint64)), what
+    assert np.array_equal(g[0].view(np.uint64), g[1].view(np.uint64))
+    # the same two poses through the de-integration kernel variant
+    s = gpu.create_scene(p)
+    rs, v = gpu.create_render_state(s, wl.W, wl.H), gpu.create_view(wl.W, wl.H)
+    so = oracle.create_scene(p)
+    rso, vo = oracle.create_render_state(so, wl.W, wl.H), oracle.create_view(wl.W, wl.H)
+    rgba, mm, M = wl.frame(0)
+    Md = np.eye(4, dtype=np.float32)
+    Md[2, :] = 0.0
+    Md[2, 2] = np.float32(1e-39)
+    for api, sc, r, vw in ((gpu, s, rs, v), (oracle, so, rso, vo)):
+        api.view_update(vw, rgba, mm)
+        api.process_frame(sc, vw, r, M, wl.intr)
+        api.process_frame(sc, vw, r, M, wl.intr)
+        ids = api.download_visible_ids(r)
+        api.deprocess_frame(sc, vw, r, M, wl.intr, M_rgb=np.zeros((4, 4), np.float32), intr_rgb=wl.intr)
+        api.upload_visible_ids(r, ids)
+    assert np.array_equal(gpu.download_voxel_blocks(s).view(np.uint64), oracle.download_voxel_blocks(so).view(np.uint64))
+
+
+def test_weight_params_bound(pkg, synth, gpu, oracle):
+    """max_new_w is bounded by the byte a voxel weight is (and by the kernel's reciprocal table): 255 works and matches
+    the oracle, 256 is refused by both."""
+    wl = synth.s_tiny()
+    p = util.small_params(pkg, wl, max_w=255)
+    res = {}
+    for name, api in (("gpu", gpu), ("oracle", oracle)):
+        for bad in ((True, 256, 10.0), (True, 0, 10.0), (True, 4, 0.0)):
+            with pytest.raises(pkg.DslamError):
+                api.set_fusion_weight_params(*bad)
+        api.set_fusion_weight_params(True, 255, 6.0)
+        try:
+            s, rs, v = util.run_sequence(api, pkg, wl, p, 3)
+            res[name] = util.snapshot(api, s, rs)
+        finally:
+            api.set_fusion_weight_params(False, 1, 1.0)
+    util.assert_same_state(res["gpu"], res["oracle"], "max_new_w = 255")
+    assert res["gpu"]["voxels"]["w_depth"].max() == 255
