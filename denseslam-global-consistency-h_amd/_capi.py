@@ -179,6 +179,23 @@ class CApi:
     def synchronize(self):
         self._call("engine_synchronize", self._engine)
 
+    # fences: markers in the engine's stream for callers that pipeline frames across PCIe (async mode)
+    def fence_create(self):
+        h = C.c_void_p()
+        self._call("fence_create", self._engine, C.byref(h))
+        return _Handle(self, h, self._fn("fence_destroy"))
+
+    def fence_record(self, fence):
+        self._call("fence_record", self._engine, fence.ptr)
+
+    def fence_wait(self, fence):
+        self._call("fence_wait", fence.ptr)
+
+    def fence_query(self, fence):
+        done = C.c_int(0)
+        self._call("fence_query", fence.ptr, C.byref(done))
+        return bool(done.value)
+
     def stream(self):
         f = getattr(self.lib, self.prefix + "engine_stream")
         f.restype = C.c_void_p

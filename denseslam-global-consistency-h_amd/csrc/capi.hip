@@ -130,6 +130,7 @@ const char *dslam_version(void) { return "dslam_fusion 0.1 (gfx950)"; }
 
 static int engine_allocate(dslam_engine *e) {
   DSLAM_HIP(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
+  DSLAM_HIP(hipStreamCreateWithFlags(&e->copy_stream, hipStreamNonBlocking));
   e->pinned_bytes = 64 * 1024;
   DSLAM_HIP(hipHostMalloc(&e->pinned, e->pinned_bytes, hipHostMallocDefault));
   memset(e->pinned, 0, e->pinned_bytes);
@@ -164,6 +165,7 @@ int dslam_engine_destroy(dslam_engine *e) {
   if (!e) return DSLAM_OK;
   (void)hipSetDevice(e->device);
   if (e->stream) (void)hipStreamSynchronize(e->stream);
+  if (e->copy_stream) { (void)hipStreamSynchronize(e->copy_stream); (void)hipStreamDestroy(e->copy_stream); }
   free_dev(e->order_keys); free_dev(e->block_coords); free_dev(e->tile_counts); free_dev(e->tile_offsets);
   free_dev(e->list_a); free_dev(e->list_b); free_dev(e->list_c); free_dev(e->pos_scratch);
   if (e->staging_dev) (void)hipFree(e->staging_dev);
@@ -203,7 +205,46 @@ int dslam_engine_set_async(dslam_engine *e, int async_mode) {
 }
 int dslam_engine_synchronize(dslam_engine *e) {
   DSLAM_REQUIRE(e, "null engine");
-  DSLAM_HIP(hipStreamSynchronize(e->stream));
+  DSLAM_HIP(hipStreamSynchronize(e->stream));  // (every pipelined upload is waited for by a kernel of this stream)
+  return DSLAM_OK;
+}
+
+// ---- fences --------------------------------------------------------------------------------------------------
+int dslam_fence_create(dslam_engine *e, dslam_fence **out) {
+  DSLAM_REQUIRE(e && out, "null argument");
+  *out = nullptr;
+  dslam_fence *f = new dslam_fence();
+  f->engine = e;
+  const hipError_t err = hipEventCreateWithFlags(&f->ev, hipEventDisableTiming);
+  if (err != hipSuccess) { delete f; return hip_fail(err, "hipEventCreateWithFlags", __FILE__, __LINE__); }
+  *out = f;
+  return DSLAM_OK;
+}
+int dslam_fence_destroy(dslam_fence *f) {
+  if (!f) return DSLAM_OK;
+  if (f->ev) (void)hipEventDestroy(f->ev);
+  delete f;
+  return DSLAM_OK;
+}
+int dslam_fence_record(dslam_engine *e, dslam_fence *f) {
+  DSLAM_REQUIRE(e && f && f->engine == e, "fence belongs to a different engine");
+  DSLAM_HIP(hipEventRecord(f->ev, e->stream));
+  f->recorded = true;
+  return DSLAM_OK;
+}
+int dslam_fence_wait(dslam_fence *f) {
+  DSLAM_REQUIRE(f, "null fence");
+  if (f->recorded) DSLAM_HIP(hipEventSynchronize(f->ev));
+  return DSLAM_OK;
+}
+int dslam_fence_query(dslam_fence *f, int *done) {
+  DSLAM_REQUIRE(f && done, "null argument");
+  *done = 1;
+  if (f->recorded) {
+    const hipError_t err = hipEventQuery(f->ev);
+    if (err == hipErrorNotReady) *done = 0;
+    else if (err != hipSuccess) return hip_fail(err, "hipEventQuery", __FILE__, __LINE__);
+  }
   return DSLAM_OK;
 }
 void *dslam_engine_stream(dslam_engine *e) { return e ? (void *)e->stream : nullptr; }
@@ -429,7 +470,13 @@ int dslam_view_create(dslam_engine *e, int w_rgb, int h_rgb, int w_d, int h_d, d
 int dslam_view_destroy(dslam_view *v) {
   if (!v) return DSLAM_OK;
   (void)hipStreamSynchronize(v->engine->stream);
+  if (v->engine->copy_stream) (void)hipStreamSynchronize(v->engine->copy_stream);
   free_dev(v->rgba); free_dev(v->depth); free_dev(v->raw_depth); free_dev(v->pyramid);
+  for (int b = 0; b < 2; b++) {
+    free_dev(v->up_rgba[b]);  // (up_raw[b] points into the same allocation)
+    if (v->up_done[b]) (void)hipEventDestroy(v->up_done[b]);
+    if (v->up_consumed[b]) (void)hipEventDestroy(v->up_consumed[b]);
+  }
   delete v;
   return DSLAM_OK;
 }
@@ -487,6 +534,52 @@ static bool in_pinned_range(const void *p, size_t bytes) {
   return false;
 }
 
+// Async engine + page-locked RGBA / depth images: the copy runs on the engine's copy stream into landing buffer b of
+// the view while the compute stream is still reading buffer b ^ 1 (the previous frame's kernels, enqueued earlier).
+//   up_consumed[b]  recorded on the compute stream at the NEXT update, i.e. behind every kernel that reads buffer b;
+//                   the copy that refills b (two updates later) may only start once it has passed
+//   up_done[b]      recorded on the copy stream behind the copy; this frame's kernels may only start once it has passed
+// Both conditions are awaited by the HOST (the calling thread sits out the copy, ~40 us per 640x480 frame, while the
+// GPU works on the previous frame), not by hipStreamWaitEvent: on this runtime a cross-stream wait in front of a
+// frame's kernels cost the compute stream ~30 us per frame (197 vs 167 us per step), more than the copy it hides;
+// DSLAM_PIPELINE_STREAM_WAITS=1 selects that variant for measurement.
+// *rgba_out / *raw_out receive the buffers the view reads from now on.
+static int upload_view_pipelined(dslam_engine *e, dslam_view *v, const uint8_t *rgba_host, const int16_t *depth_host,
+                                 const void **rgba_out, const void **raw_out) {
+  static const bool stream_waits = getenv("DSLAM_PIPELINE_STREAM_WAITS") && atoi(getenv("DSLAM_PIPELINE_STREAM_WAITS")) != 0;
+  const size_t c_bytes = (size_t)v->w_rgb * v->h_rgb * 4, d_bytes = (size_t)v->w_d * v->h_d * 2;
+  if (!v->up_rgba[0]) {
+    for (int b = 0; b < 2; b++) {
+      // one allocation per landing buffer (RGBA image, then the depth image): a caller that keeps a frame's two images
+      // back to back gets ONE copy per frame
+      DSLAM_HIP(hipMalloc(&v->up_rgba[b], c_bytes + d_bytes));
+      v->up_raw[b] = reinterpret_cast<short *>(reinterpret_cast<char *>(v->up_rgba[b]) + c_bytes);
+      DSLAM_HIP(hipEventCreateWithFlags(&v->up_done[b], hipEventDisableTiming));
+      DSLAM_HIP(hipEventCreateWithFlags(&v->up_consumed[b], hipEventDisableTiming));
+    }
+  }
+  const int b = v->up_next;
+  v->up_next ^= 1;
+  if (v->up_used[b ^ 1]) DSLAM_HIP(hipEventRecord(v->up_consumed[b ^ 1], e->stream));
+  if (v->up_used[b]) {
+    if (stream_waits) DSLAM_HIP(hipStreamWaitEvent(e->copy_stream, v->up_consumed[b], 0));
+    else DSLAM_HIP(hipEventSynchronize(v->up_consumed[b]));
+  }
+  if (reinterpret_cast<const uint8_t *>(depth_host) == rgba_host + c_bytes) {
+    DSLAM_HIP(hipMemcpyAsync(v->up_rgba[b], rgba_host, c_bytes + d_bytes, hipMemcpyHostToDevice, e->copy_stream));
+  } else {
+    DSLAM_HIP(hipMemcpyAsync(v->up_rgba[b], rgba_host, c_bytes, hipMemcpyHostToDevice, e->copy_stream));
+    DSLAM_HIP(hipMemcpyAsync(v->up_raw[b], depth_host, d_bytes, hipMemcpyHostToDevice, e->copy_stream));
+  }
+  DSLAM_HIP(hipEventRecord(v->up_done[b], e->copy_stream));
+  if (stream_waits) DSLAM_HIP(hipStreamWaitEvent(e->stream, v->up_done[b], 0));
+  else DSLAM_HIP(hipEventSynchronize(v->up_done[b]));
+  v->up_used[b] = true;
+  *rgba_out = v->up_rgba[b];
+  *raw_out = v->up_raw[b];
+  return DSLAM_OK;
+}
+
 static int upload_view_host(dslam_engine *e, dslam_view *v, const uint8_t *colour_host, int colour_channels,
                             const int16_t *depth_host) {
   const size_t c_bytes = (size_t)v->w_rgb * v->h_rgb * colour_channels, d_bytes = (size_t)v->w_d * v->h_d * 2;
@@ -514,6 +607,13 @@ static int upload_view_host(dslam_engine *e, dslam_view *v, const uint8_t *colou
 int dslam_view_update(dslam_engine *e, dslam_view *v, const uint8_t *rgba_host, const int16_t *depth_host, float a,
                       float b, double timestamp, int use_bilateral) {
   DSLAM_REQUIRE(e && v && rgba_host && depth_host, "null argument");
+  if (e->async_mode && in_pinned_range(rgba_host, (size_t)v->w_rgb * v->h_rgb * 4) &&
+      in_pinned_range(depth_host, (size_t)v->w_d * v->h_d * 2)) {
+    const void *rgba_dev = nullptr, *raw_dev = nullptr;
+    int rc = upload_view_pipelined(e, v, rgba_host, depth_host, &rgba_dev, &raw_dev);
+    if (rc) return rc;
+    return finish_view_update(e, v, rgba_dev, raw_dev, a, b, timestamp, use_bilateral);
+  }
   int rc = upload_view_host(e, v, rgba_host, 4, depth_host);
   if (rc) return rc;
   return finish_view_update(e, v, v->rgba, v->raw_depth, a, b, timestamp, use_bilateral);
@@ -928,8 +1028,9 @@ int dslam_get_image(dslam_engine *e, const dslam_scene *s, dslam_render_state *r
   if (out && !(out_rgba && out_float) && in_pinned_range(out, bytes)) {
     int rc = get_image_on_device(e, s, r, M, intr, type, out);
     if (rc) return rc;
-    DSLAM_HIP(hipStreamSynchronize(e->stream));  // host buffers are valid on return
-    return DSLAM_OK;
+    // synchronous engine: the image is there on return (what the reference's callers assume); async engine: the
+    // caller pipelines and learns from a fence (dslam_fence_*) when the kernel has stored the last pixel
+    return finish_call(e);
   }
   int rc = get_image_on_device(e, s, r, M, intr, type);
   if (rc) return rc;

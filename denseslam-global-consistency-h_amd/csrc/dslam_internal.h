@@ -37,6 +37,7 @@ bool invert_matrix(const float *m, float *dst);
 struct dslam_engine {
   int device = 0;
   hipStream_t stream = nullptr;
+  hipStream_t copy_stream = nullptr;  // pipelined uploads (async mode, page-locked sources): H2D of frame i + 1 under frame i's kernels
   bool async_mode = false;
   dslam_weight_params wp{0, 1, 1.0f};
   // scratch shared by all scenes of this engine (sized for the largest scene seen)
@@ -147,9 +148,24 @@ struct dslam_view {
   // what the kernels read: own buffers, or the caller's resident frame (dslam_view_update_device: no copy)
   const uchar4 *rgba_src = nullptr;
   const short *raw_src = nullptr;
+  // pipelined uploads (async engine + page-locked caller images): two landing buffers, filled on the engine's copy
+  // stream while the compute stream still reads the other one
+  uchar4 *up_rgba[2] = {nullptr, nullptr};
+  short *up_raw[2] = {nullptr, nullptr};
+  hipEvent_t up_done[2] = {nullptr, nullptr};      // copy stream: buffer b has landed
+  hipEvent_t up_consumed[2] = {nullptr, nullptr};  // compute stream: every kernel that reads buffer b has been passed
+  bool up_used[2] = {false, false};
+  int up_next = 0;
   float affine_a = 0.001f, affine_b = 0.0f;
   mutable bool depth_dirty = false;  // float depth not yet derived from raw_src (done by the next consumer)
   double timestamp = 0;
+};
+
+// a marker in the engine's stream (dslam_fence_*): lets a pipelining caller learn when a frame's results have landed
+struct dslam_fence {
+  dslam_engine *engine = nullptr;
+  hipEvent_t ev = nullptr;
+  bool recorded = false;
 };
 
 // mfusionFrameDataBase's image payload (fusionFrameInfo::rgbinfo / depthinfo, DenseSlam.h:431-433) kept in HBM:

@@ -61,7 +61,16 @@ def run(pkg, eng, n_side=64, iterations=20, W=640, H=480):
     eng.view_update(view, rgba, depth_mm)
     M = np.eye(4, dtype=np.float32)
     intr = np.array([100.0, 100.0, (W - 1) / 2.0, (H - 1) / 2.0], np.float32)  # wide FOV: the lattice projects inside
-    ms, nvis = eng.time_integrate(scene, view, rs, M, intr, iterations)
+    # one warm-up launch, then `iterations` launches timed one by one with events attached to the dispatch packets
+    # (the kernel's own start-to-end interval, what rocprofv3 reports; bench.py times the headline launch the same way)
+    eng.integrate_into_scene(scene, view, rs, M, intr)
+    eng.synchronize()
+    eng.kernel_timer_enable(True)
+    for _ in range(iterations):
+        eng.integrate_into_scene(scene, view, rs, M, intr)
+    total_ms, launches, blocks = eng.kernel_timer_read()
+    eng.kernel_timer_enable(False)
+    ms, nvis = total_ms / max(1, launches), blocks // max(1, launches)
     vox = eng.download_voxel_blocks(scene, 0, 64)
     updated = float((vox["w_depth"] > 0).mean())
     alg_bytes = 8212.0 * nvis + 8.0 * W * H

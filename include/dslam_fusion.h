@@ -119,6 +119,7 @@ typedef struct dslam_engine dslam_engine;             /* device + stream + scrat
 typedef struct dslam_scene dslam_scene;               /* ITMScene<ITMVoxel,ITMVoxelBlockHash> (+ITMGlobalCache) */
 typedef struct dslam_render_state dslam_render_state; /* ITMRenderState_VH */
 typedef struct dslam_view dslam_view;                 /* ITMView (rgb, depth) */
+typedef struct dslam_fence dslam_fence;               /* a marker in the engine's stream (async mode) */
 
 /* ---- engine ------------------------------------------------------------------------------------ */
 const char *dslam_last_error(void);
@@ -131,6 +132,20 @@ int dslam_engine_set_async(dslam_engine *e, int async_mode);
 int dslam_engine_synchronize(dslam_engine *e);
 /* native hipStream_t of the engine, for callers that enqueue their own work (RCCL, torch). */
 void *dslam_engine_stream(dslam_engine *e);
+/* Pipelining across PCIe (async mode only; the reference's own driver is synchronous and needs none of this).
+ * With dslam_engine_set_async(e, 1) and caller images in dslam_host_alloc memory:
+ *  - dslam_view_update copies on a second (copy) stream into one of two landing buffers of the view while the kernels
+ *    of the previous frame, enqueued earlier, keep the GPU busy; it returns when the frame has landed (the calling
+ *    thread sits out the copy, the GPU does not).  A frame whose depth image directly follows its RGBA image in
+ *    memory goes up as one copy.
+ *  - dslam_get_image into a page-locked image returns at once; the render kernel stores the pixels there itself.
+ *  - a fence marks "everything enqueued on the engine so far": record it after a frame's last call, wait for it
+ *    before reading that frame's output image or rewriting its input images. */
+int dslam_fence_create(dslam_engine *e, dslam_fence **out);
+int dslam_fence_destroy(dslam_fence *f);
+int dslam_fence_record(dslam_engine *e, dslam_fence *f);
+int dslam_fence_wait(dslam_fence *f);               /* blocks the calling thread; a fence never recorded has passed */
+int dslam_fence_query(dslam_fence *f, int *done);   /* non-blocking */
 /* Page-locked host memory for the caller's image buffers: what ORUtils::MemoryBlock's host side is whenever the
  * block also has a device side (upstream ORUtils/MemoryBlock.h Allocate: cudaMallocHost), i.e. the rgb / raw-depth
  * images DenseSlam::ProcessFrame fills each frame (DenseSlam.cpp:66-74).  Zero-filled.  In the default synchronous

@@ -23,3 +23,17 @@ def open_oracle(capi_cls, threads=1):
     o = capi_cls(LIB_PATH, "oracle_", has_engine_device=False)
     o.set_threads(threads)
     return o
+
+
+NATIVE_LIB_PATH = os.path.join(ORACLE_DIR, "_native", "liboracle_native.so")
+
+
+def open_native_oracle(capi_cls, threads=1):
+    """The -O3 -march=native build bench.py times as the CPU baseline; compiled on first use ON THIS MACHINE (the file
+    is specific to the host's CPU and never travels).  Falls back to the portable build if the compiler is missing."""
+    res = subprocess.run(["make", "-C", ORACLE_DIR, "_native/liboracle_native.so"], capture_output=True, text=True)
+    if res.returncode != 0 or not os.path.exists(NATIVE_LIB_PATH):
+        return open_oracle(capi_cls, threads), "-O2 -march=x86-64-v2 (portable build; native build failed)"
+    o = capi_cls(NATIVE_LIB_PATH, "oracle_", has_engine_device=False)
+    o.set_threads(threads)
+    return o, "-O3 -march=native -fopenmp -ffp-contract=off"

@@ -1,0 +1,71 @@
+"""Pipelining frames across PCIe (dslam_engine_set_async + page-locked caller images + fences): uploads run on the
+engine's copy stream under the previous frame's kernels, the render kernel stores the output image in page-locked
+host memory, a fence tells the caller when.  Results must equal the synchronous call sequence of the reference's
+driver (InfiniTamDriver.cpp:280-288, DenseSlam.cpp:210-232, DenseSlam.h:146-164) byte for byte."""
+import numpy as np
+import pytest
+
+import util
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("workload,n_frames", [("s_tiny", 14), ("s_street", 6)])
+def test_pipelined_frames_equal_synchronous_calls(pkg, synth, gpu, workload, n_frames):
+    wl = synth.s_tiny() if workload == "s_tiny" else synth.s_street(640, 480)
+    p = util.small_params(pkg, wl) if workload == "s_tiny" else pkg.SceneParams(num_local_blocks=0x8000, **wl.scene_kwargs)
+    frames = [wl.frame(i) for i in range(n_frames)]
+
+    # reference behaviour: every call synchronous, pageable images
+    s0 = gpu.create_scene(p)
+    rs0, free0, v0 = gpu.create_render_state(s0, wl.W, wl.H), gpu.create_render_state(s0, wl.W, wl.H), gpu.create_view(wl.W, wl.H)
+    want = []
+    for i, (rgba, mm, M) in enumerate(frames):
+        gpu.view_update(v0, rgba, mm, timestamp=float(i))
+        gpu.process_frame(s0, v0, rs0, M, wl.intr)
+        want.append(gpu.get_image(s0, free0, M, wl.intr, pkg.IMAGE_DEPTH))
+    ref = util.snapshot(gpu, s0, rs0)
+
+    # pipelined: page-locked inputs (all frames, as a capture ring would hold them), a ring of 3 page-locked outputs
+    s1 = gpu.create_scene(p)
+    rs1, free1, v1 = gpu.create_render_state(s1, wl.W, wl.H), gpu.create_render_state(s1, wl.W, wl.H), gpu.create_view(wl.W, wl.H)
+    rgba_p = gpu.host_alloc((n_frames, wl.H, wl.W, 4), np.uint8)
+    mm_p = gpu.host_alloc((n_frames, wl.H, wl.W), np.int16)
+    for i, (rgba, mm, M) in enumerate(frames):
+        rgba_p[i], mm_p[i] = rgba, mm
+    R = 3
+    out_p = gpu.host_alloc((R, wl.H, wl.W), np.float32)
+    fences = [gpu.fence_create() for _ in range(R)]
+    got = [None] * n_frames
+    gpu.set_async(True)
+    try:
+        for i, (rgba, mm, M) in enumerate(frames):
+            if i >= R:  # the consumer takes image i - R before its buffer is rendered into again
+                gpu.fence_wait(fences[i % R])
+                got[i - R] = out_p[i % R].copy()
+            gpu.view_update(v1, rgba_p[i], mm_p[i], timestamp=float(i))
+            gpu.process_frame(s1, v1, rs1, M, wl.intr)
+            gpu.get_image(s1, free1, M, wl.intr, pkg.IMAGE_DEPTH, out=out_p[i % R])
+            gpu.fence_record(fences[i % R])
+        for i in range(max(0, n_frames - R), n_frames):
+            gpu.fence_wait(fences[i % R])
+            assert gpu.fence_query(fences[i % R])
+            got[i] = out_p[i % R].copy()
+        gpu.synchronize()
+    finally:
+        gpu.set_async(False)
+    util.assert_same_state(util.snapshot(gpu, s1, rs1), ref, "pipelined vs synchronous")
+    for i in range(n_frames):
+        assert np.array_equal(got[i], want[i]), f"output image of frame {i}"
+    assert (want[-1] > 0).sum() > 500
+    for f in fences:
+        f.close()
+    for a in (rgba_p, mm_p, out_p):
+        gpu.host_free(a)
+
+
+def test_fence_that_was_never_recorded_has_passed(gpu):
+    f = gpu.fence_create()
+    gpu.fence_wait(f)
+    assert gpu.fence_query(f)
+    f.close()
