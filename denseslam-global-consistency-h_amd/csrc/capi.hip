@@ -89,20 +89,32 @@ int ensure_scratch(dslam_engine *e, int entries, int local_blocks) {
   DSLAM_HIP(hipStreamSynchronize(e->stream));
   const int N = entries > e->scratch_entries ? entries : e->scratch_entries;
   const int L = local_blocks > e->scratch_local_blocks ? local_blocks : e->scratch_local_blocks;
-  free_dev(e->order_keys); free_dev(e->block_coords); free_dev(e->tile_counts); free_dev(e->tile_offsets);
-  free_dev(e->list_a); free_dev(e->list_b); free_dev(e->list_c); free_dev(e->pos_scratch);
-  // order keys (4 B) and allocType (1 B) contiguous so one memset clears both
-  DSLAM_HIP(hipMalloc(&e->order_keys, (size_t)N * 5));
-  e->alloc_type = reinterpret_cast<unsigned char *>(e->order_keys) + (size_t)N * 4;
+  free_dev(e->order_keys); free_dev(e->alloc_type); free_dev(e->block_coords); free_dev(e->tile_counts); free_dev(e->tile_offsets);
+  free_dev(e->list_a); free_dev(e->list_b); free_dev(e->list_c); free_dev(e->list_d); free_dev(e->pos_scratch);
+  free_dev(e->req_list); free_dev(e->req_count); free_dev(e->agg);
+  // order keys and allocType: cleared here once, kept clean by the allocation passes (scenes of different sizes share
+  // them, so both start at fixed addresses: a pass only ever touches [0, its entry count) of each)
+  DSLAM_HIP(hipMalloc(&e->order_keys, (size_t)N * 4));
+  DSLAM_HIP(hipMemsetAsync(e->order_keys, 0, (size_t)N * 4, e->stream));
+  DSLAM_HIP(hipMalloc(&e->alloc_type, (size_t)N));
+  DSLAM_HIP(hipMemsetAsync(e->alloc_type, 0, (size_t)N, e->stream));
   DSLAM_HIP(hipMalloc(&e->block_coords, (size_t)N * sizeof(short4)));
+  DSLAM_HIP(hipMalloc(&e->req_list, (size_t)N * sizeof(int)));
+  DSLAM_HIP(hipMalloc(&e->req_count, sizeof(int)));
+  DSLAM_HIP(hipMemsetAsync(e->req_count, 0, sizeof(int), e->stream));
   const int tiles = num_tiles(N);
+  DSLAM_HIP(hipMalloc(&e->agg, (size_t)tiles * 3 * sizeof(unsigned long long)));
+  DSLAM_HIP(hipMemsetAsync(e->agg, 0, (size_t)tiles * 3 * sizeof(unsigned long long), e->stream));
+  e->agg_tiles = tiles;
   DSLAM_HIP(hipMalloc(&e->tile_counts, (size_t)tiles * 2 * sizeof(int)));
   DSLAM_HIP(hipMalloc(&e->tile_offsets, (size_t)tiles * 2 * sizeof(int)));
   const size_t list_len = (size_t)(N > L ? N : L);
   DSLAM_HIP(hipMalloc(&e->list_a, list_len * sizeof(int)));
   DSLAM_HIP(hipMalloc(&e->list_b, list_len * sizeof(int)));
   DSLAM_HIP(hipMalloc(&e->list_c, list_len * sizeof(int)));
+  DSLAM_HIP(hipMalloc(&e->list_d, list_len * sizeof(int)));
   DSLAM_HIP(hipMalloc(&e->pos_scratch, (size_t)L * sizeof(short4)));
+  DSLAM_HIP(hipStreamSynchronize(e->stream));
   e->scratch_entries = N;
   e->scratch_local_blocks = L;
   return DSLAM_OK;
@@ -166,8 +178,9 @@ int dslam_engine_destroy(dslam_engine *e) {
   (void)hipSetDevice(e->device);
   if (e->stream) (void)hipStreamSynchronize(e->stream);
   if (e->copy_stream) { (void)hipStreamSynchronize(e->copy_stream); (void)hipStreamDestroy(e->copy_stream); }
-  free_dev(e->order_keys); free_dev(e->block_coords); free_dev(e->tile_counts); free_dev(e->tile_offsets);
-  free_dev(e->list_a); free_dev(e->list_b); free_dev(e->list_c); free_dev(e->pos_scratch);
+  free_dev(e->order_keys); free_dev(e->alloc_type); free_dev(e->block_coords); free_dev(e->tile_counts); free_dev(e->tile_offsets);
+  free_dev(e->list_a); free_dev(e->list_b); free_dev(e->list_c); free_dev(e->list_d); free_dev(e->pos_scratch);
+  free_dev(e->req_list); free_dev(e->req_count); free_dev(e->agg);
   if (e->staging_dev) (void)hipFree(e->staging_dev);
   if (e->staging_host) (void)hipHostFree(e->staging_host);
   if (e->pinned) (void)hipHostFree(e->pinned);
@@ -954,6 +967,7 @@ int dslam_find_visible_blocks(dslam_engine *e, const dslam_scene *s, dslam_rende
                               const float intr[4]) {
   DSLAM_REQUIRE(e && s && r && M && intr, "null argument");
   r->memo_valid = false;  // raycastResult / the lists behind it are about to be rewritten
+  r->types_follow_list = false;
   int rc = launch_find_visible(e, s, r, M, intr);
   if (rc) return rc;
   return finish_call(e);
@@ -1010,6 +1024,7 @@ static int get_image_on_device(dslam_engine *e, const dslam_scene *s, dslam_rend
   int rc;
   if (hit) return launch_render(e, s, r, M, intr, type, true, direct_out);
   r->memo_valid = false;
+  r->types_follow_list = false;  // FindVisibleBlocks replaces this render state's list
   if ((rc = launch_find_visible_and_depths(e, s, r, M, intr))) return rc;
   if ((rc = launch_render(e, s, r, M, intr, type, false, direct_out))) return rc;
   r->memo_valid = true; r->memo_scene = s; r->memo_version = s->version; r->memo_budget = e->render_tile_budget;
@@ -1173,7 +1188,9 @@ int dslam_download_visible_ids(dslam_engine *e, const dslam_render_state *r, int
 }
 int dslam_download_visible_types(dslam_engine *e, const dslam_render_state *r, uint8_t *out) {
   DSLAM_REQUIRE(e && r && out, "null argument");
-  return d2h(e, out, r->visible_type, r->n_entries);
+  int rc = d2h(e, out, r->visible_type, r->n_entries);
+  for (int i = 0; i < r->n_entries; i++) out[i] &= 0x7f;  // the device bytes carry the pass' generation bit
+  return rc;
 }
 int dslam_download_range_image(dslam_engine *e, const dslam_render_state *r, float *out) {
   DSLAM_REQUIRE(e && r && out, "null argument");
@@ -1247,6 +1264,7 @@ int dslam_upload_voxel_blocks(dslam_engine *e, dslam_scene *s, int first, int n,
 int dslam_upload_visible_ids(dslam_engine *e, dslam_render_state *r, const int32_t *ids, int count) {
   DSLAM_REQUIRE(e && r && ids && count >= 0 && count <= r->n_local, "bad visible list");
   r->memo_valid = false;  // raycastResult / the lists behind it are about to be rewritten
+  r->types_follow_list = false;
   int rc = h2d(e, r->visible_ids, ids, (size_t)count * sizeof(int));
   if (rc) return rc;
   RenderCounters *rcn = reinterpret_cast<RenderCounters *>(reinterpret_cast<char *>(e->pinned) + 128);

@@ -369,4 +369,68 @@ static __global__ __launch_bounds__(256) void k_compact_apply(const unsigned cha
     }
 }
 
+// ---- in-launch hand-off of per-tile counts -----------------------------------------------------------------
+// One 8-byte word per tile and channel: {epoch (high 32), a (bits 16..31), b (bits 0..15)}, written by ONE relaxed
+// agent-scope store and polled with relaxed agent-scope loads (sc1: served past the CU's L1).  The word IS the
+// payload, so no fence is involved; the epoch (one per launch, never 0) makes words of earlier launches invisible.
+static __device__ __forceinline__ void publish(unsigned long long *agg, int tile, unsigned epoch, int a, int b) {
+  __hip_atomic_store(&agg[tile], ((unsigned long long)epoch << 32) | ((unsigned)a << 16) | (unsigned)b, __ATOMIC_RELAXED,
+                     __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// sums of both fields over the tiles [0, n) (every thread of the 256-thread workgroup gets the result).  Every thread
+// has its words (up to kLookbackBatch per round) in flight TOGETHER and re-polls only those that are not there yet: a
+// look-back costs about one round trip to the memory side, not one per word.
+constexpr int kLookbackBatch = 8;
+
+static __device__ __forceinline__ void lookback(const unsigned long long *agg, int n, unsigned epoch, int *lds8, int &sum_a,
+                                         int &sum_b) {
+  int sa = 0, sb = 0;
+  for (int j0 = threadIdx.x; j0 < n; j0 += 256 * kLookbackBatch) {
+    unsigned long long w[kLookbackBatch];
+    unsigned pending = 0;
+#pragma unroll
+    for (int q = 0; q < kLookbackBatch; q++) {
+      const int j = j0 + 256 * q;
+      w[q] = 0;
+      if (j < n) {
+        w[q] = __hip_atomic_load(&agg[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        pending |= 1u << q;
+      }
+    }
+    while (true) {
+#pragma unroll
+      for (int q = 0; q < kLookbackBatch; q++)
+        if ((pending >> q) & 1u) {
+          if ((unsigned)(w[q] >> 32) == epoch) {
+            sa += (int)((unsigned)w[q] >> 16);
+            sb += (int)((unsigned)w[q] & 0xffffu);
+            pending &= ~(1u << q);
+          }
+        }
+      if (!pending) break;
+      __builtin_amdgcn_s_sleep(8);
+#pragma unroll
+      for (int q = 0; q < kLookbackBatch; q++)
+        if ((pending >> q) & 1u) w[q] = __hip_atomic_load(&agg[j0 + 256 * q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+  for (int d = 32; d > 0; d >>= 1) { sa += __shfl_xor(sa, d, 64); sb += __shfl_xor(sb, d, 64); }
+  if ((threadIdx.x & 63) == 0) { lds8[threadIdx.x >> 6] = sa; lds8[4 + (threadIdx.x >> 6)] = sb; }
+  __syncthreads();
+  sum_a = lds8[0] + lds8[1] + lds8[2] + lds8[3];
+  sum_b = lds8[4] + lds8[5] + lds8[6] + lds8[7];
+  __syncthreads();
+}
+
+
+// A sweep tile = kSweepTile consecutive entries handled by one 256-thread workgroup, kSweepPer consecutive entries per
+// thread.  Fat tiles on purpose: the tiles of a launch wait for each other's words, and with 288 tiles instead of 1152
+// a look-back is one or two loads per thread, the polling traffic is 16x smaller and the publishing stores are not
+// queued behind it (with 1024-entry tiles the same kernel took 23-33 us, most of it waiting for store acknowledgements
+// and for the slowest predecessor; per-tile timestamps in profiles/).
+constexpr int kSweepPer = 16;
+constexpr int kSweepTile = 256 * kSweepPer;
+
+
 }  // namespace dslam

@@ -43,9 +43,20 @@ struct dslam_engine {
   // scratch shared by all scenes of this engine (sized for the largest scene seen)
   int scratch_entries = 0;
   int scratch_local_blocks = 0;
-  unsigned *order_keys = nullptr;     // [entries] mark-phase order keys / removal flags
-  unsigned char *alloc_type = nullptr;  // [entries] entriesAllocType
+  unsigned *order_keys = nullptr;     // [entries] mark-phase order keys; ALL ZERO between allocation passes (the pass that
+                                      // sets a key clears it again, so no pass starts with a 4.7 MB memset)
+  unsigned char *alloc_type = nullptr;  // [entries] entriesAllocType of the last pass (kept for the parity tests)
   short4 *block_coords = nullptr;     // [entries] blockCoords
+  int *req_list = nullptr;            // [entries] entries that got an allocType in the last pass (the next pass clears them)
+  int *req_count = nullptr;           // device: length of req_list
+  // single-pass ordered compactions: per-tile aggregates published inside one launch ({epoch, counts} in one 8-byte
+  // word per tile; three channels: allocation requests, commit results, visible counts) and the launch counter that
+  // tags them, so the arrays never need clearing
+  unsigned long long *agg = nullptr;  // [3][agg_tiles]
+  int agg_tiles = 0;
+  unsigned epoch = 0;
+  int sweep_grid_cap = 0;             // workgroups of the sweep kernels that are certainly co-resident on this device
+  int *list_d = nullptr;              // [max(local_blocks, entries)] general purpose scratch (bucket leaders, live flags)
   int *tile_counts = nullptr;         // [2 * tiles] per-tile counts of the ordered compactions
   int *tile_offsets = nullptr;        // [2 * tiles]
   int *list_a = nullptr;              // [max(local_blocks, entries)] general purpose int lists
@@ -128,6 +139,13 @@ struct dslam_render_state {
   int *proj_req = nullptr;      // per visible block: render tiles required (0 = invalid projection)
   int *proj_wg_tiles = nullptr; // render tiles requested per workgroup of the projection pass (summed by the next kernel)
   dslam::RenderCounters *counters = nullptr;  // device
+  // entriesVisibleType carries a generation bit (0x80): an allocation pass writes its marks with the pass' bit, so a
+  // non-zero byte with the OTHER bit is "visible in the previous pass" (upstream's re-arming of the previous visible
+  // list as type 3) without a pass over that list.  The C ABI hands out the plain types (bit masked off).
+  unsigned char gen = 0;
+  // the visible list was replaced behind the types' back (FindVisibleBlocks on this render state, an uploaded list):
+  // the next allocation pass re-derives the "previously visible" marks from the list first
+  bool types_follow_list = true;
   // GetImage memo: raycastResult (and the visible list / range image behind it) is still that of this scene version,
   // pose and intrinsics, so another image type of the same view only has to be shaded (the reference's GUI asks for
   // a depth and a colour image of the same free pose every tick, DenseSlam.h:146-164)

@@ -243,7 +243,7 @@ static MaintScratch carve(dslam_engine *e, int N) {
   m.freed_flags = b + 2 * (size_t)N;
   m.cand_list = e->list_a;
   m.rem_list = e->list_b;
-  m.leaders = reinterpret_cast<int *>(e->order_keys);  // >= N ints, dead outside allocation
+  m.leaders = e->list_d;
   return m;
 }
 

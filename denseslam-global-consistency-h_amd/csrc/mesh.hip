@@ -205,7 +205,7 @@ int launch_mesh_scene(dslam_engine *e, const dslam_scene *s, int max_triangles, 
   const int N = s->n_entries, n_tiles = num_tiles(N);
   int rc = ensure_scratch(e, N, s->p.num_local_blocks);
   if (rc) return rc;
-  unsigned char *flags = reinterpret_cast<unsigned char *>(e->order_keys);  // >= N bytes, dead outside allocation
+  unsigned char *flags = reinterpret_cast<unsigned char *>(e->list_d);  // >= N bytes
   int *live_count = e->misc_counter + 8, *total = e->misc_counter + 9;
   hipLaunchKernelGGL(k_mesh_flag_live, dim3(n_tiles), dim3(256), 0, e->stream, s->hash, N, flags, e->tile_counts);
   hipLaunchKernelGGL(k_scan_count, dim3(1), dim3(1024), 0, e->stream, e->tile_counts, e->tile_offsets, n_tiles, live_count, N);

@@ -116,3 +116,33 @@ def test_weight_params_bound(pkg, synth, gpu, oracle):
             api.set_fusion_weight_params(False, 1, 1.0)
     util.assert_same_state(res["gpu"], res["oracle"], "max_new_w = 255")
     assert res["gpu"]["voxels"]["w_depth"].max() == 255
+
+
+def test_visible_list_replaced_between_allocation_passes(pkg, synth, gpu, oracle):
+    """The allocation pass re-arms the PREVIOUS VISIBLE LIST as type 3 (upstream: `for i < noVisibleEntries:
+    visibleType[visibleIDs[i]] = 3`), and the types array keeps whatever it held.  The engine encodes "previous pass" in
+    a generation bit of the types instead of walking the list, so a list that was replaced behind the types' back --
+    FindVisibleBlocks into the local map's own render state, an uploaded list -- has to be folded in first.  Same calls
+    on both engines; list, types and map must agree after every pass."""
+    wl = synth.s_tiny()
+    p = util.small_params(pkg, wl)
+    objs = {}
+    for name, api in (("gpu", gpu), ("oracle", oracle)):
+        s = api.create_scene(p)
+        objs[name] = (api, s, api.create_render_state(s, wl.W, wl.H), api.create_view(wl.W, wl.H))
+    M_side = synth.world_to_camera(wl.pose(0) @ synth.pose_matrix(synth.look_rotation(0.6, 0.1), [0.1, 0.0, 0.0]))
+    for i in range(8):
+        rgba, mm, M = wl.frame(i)
+        snaps = {}
+        for name, (api, s, rs, v) in objs.items():
+            api.view_update(v, rgba, mm, timestamp=float(i))
+            if i == 3:    # the list becomes "everything allocated that a sideways camera sees"; the types stay
+                api.find_visible_blocks(s, rs, M_side, wl.intr)
+            if i == 5:    # the list becomes a thinned-out copy of itself
+                api.upload_visible_ids(rs, api.download_visible_ids(rs)[::3])
+            if i == 6:    # an allocation pass that only updates the list, from the sideways pose
+                api.allocate_scene_from_depth(s, v, rs, M_side, wl.intr, only_update_visible_list=True)
+            api.process_frame(s, v, rs, M, wl.intr)
+            snaps[name] = util.snapshot(api, s, rs)
+        util.assert_same_state(snaps["gpu"], snaps["oracle"], f"frame {i}")
+    assert len(snaps["gpu"]["visible_ids"]) > 200
