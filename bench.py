@@ -268,7 +268,7 @@ def main():
             batch = reint.Batch([("dev", rgba_d.data_ptr() + i * rgba_stride, depth_d.data_ptr() + i * depth_stride) for i in ids],
                                 [Ms[i] for i in ids], new_poses, wl.intr)
             chunk = 64
-            ag = reint.make_torch_all_gather(vox_t, dist, chunk, eng.synchronize, api=eng, scene=scene) if use_dist else None
+            ag = reint.make_torch_all_gather(eng, scene, dist, eng.synchronize) if use_dist else None
             timers = {}
             barrier()
             reint.reintegrate(eng, scene, view, rs, batch, rank=rank, world=world, chunk_blocks=chunk, all_gather=ag,
@@ -281,8 +281,10 @@ def main():
             tot, rei, agt = [float(x) for x in tt.tolist()]
             reint_out = {"keyframes": Kre, "keyframes_per_s": Kre / tot, "total_ms": tot * 1e3, "compute_ms": rei * 1e3,
                          "all_gather_ms": agt * 1e3, "gathered_bytes": timers["gathered_bytes"],
+                         "dirty_blocks": timers["dirty_blocks"],
                          "all_gather_GBps": (timers["gathered_bytes"] / agt / 1e9) if (use_dist and agt > 0) else None,
-                         "scaling": "strong (fixed batch; allocation replicated on every rank, voxel blocks sharded)"}
+                         "scaling": "strong (fixed batch; allocation replicated on every rank, voxel blocks sharded, "
+                                    "one all-gather of the blocks the batch touched)"}
         except Exception as ex:  # never lose the main line over the auxiliary measurement
             reint_out = {"error": repr(ex)}
 

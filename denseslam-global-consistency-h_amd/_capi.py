@@ -602,13 +602,19 @@ class CApi:
         self._call("upload_voxel_blocks", self._engine, scene.ptr, C.c_int(first), C.c_int(b.size // BLOCK_SIZE3),
                    _vptr(b))
 
-    def shard_pack(self, scene, first_block, groups, shard, num_shards, chunk_blocks, send_dev_ptr):
-        self._call("shard_pack", self._engine, scene.ptr, C.c_int(first_block), C.c_int(groups), C.c_int(shard),
-                   C.c_int(num_shards), C.c_int(chunk_blocks), C.c_void_p(send_dev_ptr))
+    def track_dirty(self, scene, enable):
+        self._call("scene_track_dirty", self._engine, scene.ptr, C.c_int(int(enable)))
 
-    def shard_unpack(self, scene, first_block, groups, num_shards, chunk_blocks, recv_dev_ptr):
-        self._call("shard_unpack", self._engine, scene.ptr, C.c_int(first_block), C.c_int(groups), C.c_int(num_shards),
-                   C.c_int(chunk_blocks), C.c_void_p(recv_dev_ptr))
+    def shard_dirty_plan(self, scene, num_shards, chunk_blocks):
+        counts = (C.c_int32 * num_shards)()
+        self._call("shard_dirty_plan", self._engine, scene.ptr, C.c_int(num_shards), C.c_int(chunk_blocks), counts)
+        return list(counts)
+
+    def shard_dirty_pack(self, scene, shard, send_ptr, capacity_blocks):
+        self._call("shard_dirty_pack", self._engine, scene.ptr, C.c_int(shard), C.c_void_p(send_ptr), C.c_int(capacity_blocks))
+
+    def shard_dirty_unpack(self, scene, skip_shard, recv_ptr, stride_blocks):
+        self._call("shard_dirty_unpack", self._engine, scene.ptr, C.c_int(skip_shard), C.c_void_p(recv_ptr), C.c_int(stride_blocks))
 
     def upload_visible_ids(self, rs, ids):
         ids = np.ascontiguousarray(ids, dtype=np.int32)

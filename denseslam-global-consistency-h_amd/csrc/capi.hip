@@ -330,6 +330,7 @@ int dslam_scene_destroy(dslam_scene *s) {
   if (!s->voxels_external) free_dev(s->voxels);
   free_dev(s->alloc_list); free_dev(s->excess_list); free_dev(s->last_seen); free_dev(s->masks); free_dev(s->counters);
   free_dev(s->swap_state); free_dev(s->slab_ptrs_dev);
+  free_dev(s->dirty); free_dev(s->dirty_list); free_dev(s->dirty_counts);
   for (uint4 *slab : s->slabs) (void)hipHostFree(slab);
   if (s->transfer_ids_host) (void)hipHostFree(s->transfer_ids_host);
   free(s->slot_host);
@@ -371,36 +372,40 @@ int dslam_scene_set_shard_range(dslam_scene *s, int first_block, int num_blocks)
   return DSLAM_OK;
 }
 
-static int shard_region_ok(const dslam_scene *s, int first_block, int groups, int num_shards, int chunk_blocks) {
-  DSLAM_REQUIRE(s && first_block >= 0 && groups >= 0 && num_shards >= 1 && chunk_blocks >= 1, "bad shard region");
-  DSLAM_REQUIRE((long long)first_block + (long long)groups * num_shards * chunk_blocks <= s->p.num_local_blocks,
-                "shard region exceeds the voxel-block pool");
-  return DSLAM_OK;
-}
-
-int dslam_shard_pack(dslam_engine *e, const dslam_scene *s, int first_block, int groups, int shard, int num_shards,
-                     int chunk_blocks, void *send_dev) {
-  DSLAM_REQUIRE(e && send_dev && shard >= 0 && shard < num_shards, "bad argument");
-  int rc = shard_region_ok(s, first_block, groups, num_shards, chunk_blocks);
-  if (rc || groups == 0) return rc;
-  const size_t chunk_bytes = (size_t)chunk_blocks * kBlock3 * sizeof(uint2);
-  const char *src = reinterpret_cast<const char *>(s->voxels) + (size_t)first_block * kBlock3 * sizeof(uint2) + (size_t)shard * chunk_bytes;
-  DSLAM_HIP(hipMemcpy2DAsync(send_dev, chunk_bytes, src, chunk_bytes * num_shards, chunk_bytes, groups, hipMemcpyDeviceToDevice, e->stream));
+// ---- which blocks a sharded batch touched, and moving exactly those (csrc/shard.hip) ------------------------------
+int dslam_scene_track_dirty(dslam_engine *e, dslam_scene *s, int enable) {
+  DSLAM_REQUIRE(e && s, "null argument");
+  if (enable) {
+    const size_t n = (size_t)s->p.num_local_blocks;
+    if (!s->dirty) {
+      DSLAM_HIP(hipMalloc(&s->dirty, n));
+      DSLAM_HIP(hipMalloc(&s->dirty_list, n * sizeof(int)));
+      DSLAM_HIP(hipMalloc(&s->dirty_counts, 128 * sizeof(int)));
+    }
+    DSLAM_HIP(hipMemsetAsync(s->dirty, 0, n, e->stream));
+    s->dirty_shards = 0;
+  }
+  s->dirty_tracking = enable != 0;
   return finish_call(e);
 }
 
-int dslam_shard_unpack(dslam_engine *e, dslam_scene *s, int first_block, int groups, int num_shards, int chunk_blocks,
-                       const void *recv_dev) {
-  DSLAM_REQUIRE(e && recv_dev, "bad argument");
-  s->version = next_map_version();  // the map may change: GetImage memos of this scene are stale
-  int rc = shard_region_ok(s, first_block, groups, num_shards, chunk_blocks);
-  if (rc || groups == 0) return rc;
-  const size_t chunk_bytes = (size_t)chunk_blocks * kBlock3 * sizeof(uint2);
-  char *dst = reinterpret_cast<char *>(s->voxels) + (size_t)first_block * kBlock3 * sizeof(uint2);
-  for (int r = 0; r < num_shards; r++)
-    DSLAM_HIP(hipMemcpy2DAsync(dst + (size_t)r * chunk_bytes, chunk_bytes * num_shards,
-                               reinterpret_cast<const char *>(recv_dev) + (size_t)r * groups * chunk_bytes, chunk_bytes, chunk_bytes, groups,
-                               hipMemcpyDeviceToDevice, e->stream));
+int dslam_shard_dirty_plan(dslam_engine *e, dslam_scene *s, int num_shards, int chunk_blocks, int32_t *counts_out) {
+  DSLAM_REQUIRE(e && s && counts_out, "null argument");
+  return launch_dirty_plan(e, s, num_shards, chunk_blocks, counts_out);
+}
+
+int dslam_shard_dirty_pack(dslam_engine *e, const dslam_scene *s, int shard, void *send_dev, int capacity_blocks) {
+  DSLAM_REQUIRE(e && s, "null argument");
+  int rc = launch_dirty_pack(e, s, shard, send_dev, capacity_blocks);
+  if (rc) return rc;
+  return finish_call(e);
+}
+
+int dslam_shard_dirty_unpack(dslam_engine *e, dslam_scene *s, int skip_shard, const void *recv_dev, int stride_blocks) {
+  DSLAM_REQUIRE(e && s, "null argument");
+  s->version = next_map_version();  // the map changes: GetImage memos of this scene are stale
+  int rc = launch_dirty_unpack(e, s, skip_shard, recv_dev, stride_blocks);
+  if (rc) return rc;
   return finish_call(e);
 }
 

@@ -316,6 +316,21 @@ __device__ __forceinline__ void block_prefix_and_total(const int *__restrict__ v
   __syncthreads();
 }
 
+// ---- generic flag counting -----------------------------------------------------------------------------------
+static __global__ __launch_bounds__(256) void k_flag_count(const unsigned char *__restrict__ flags, int n,
+                                                    int *__restrict__ tile_counts) {
+  __shared__ int red[4];
+  const int t0 = blockIdx.x * kTileEntries + threadIdx.x * 4;
+  int c = 0;
+  if (t0 < n) {
+    const uchar4 v = *reinterpret_cast<const uchar4 *>(flags + t0);
+    c = (v.x > 0) + (v.y > 0) + (v.z > 0) + (v.w > 0);
+  }
+  int tot;
+  block_excl_scan<4>(c, red, tot);
+  if (threadIdx.x == 0) tile_counts[blockIdx.x] = tot;
+}
+
 // fused pass 2: like k_compact_apply, but the tile's exclusive offset is the sum of the preceding tile counts,
 // computed here; the last tile also publishes the (capacity-clipped) total
 static __global__ __launch_bounds__(256) void k_compact_apply_fused(const unsigned char *__restrict__ flags,

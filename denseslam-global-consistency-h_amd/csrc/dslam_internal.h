@@ -121,6 +121,12 @@ struct dslam_scene {
   int shard = 0, num_shards = 1, chunk_blocks = 256;
   unsigned long long version = 0;       // bumped by every call that can change the map (GetImage memo key)
   int shard_first = 0, shard_count = -1;  // contiguous slot range (count < 0: off)
+  // sharded re-integration: per voxel-block slot "a (de-)integration pass visited this block since tracking began"
+  unsigned char *dirty = nullptr;       // device [num_local_blocks], allocated by dslam_scene_track_dirty
+  bool dirty_tracking = false;
+  int *dirty_list = nullptr;            // device [num_local_blocks]: the dirty slots in virtual (shard-major) order
+  int *dirty_counts = nullptr;          // device [128]: per shard its number of dirty slots (+ scratch)
+  int dirty_shards = 0, dirty_chunk = 0;  // the layout of the last dslam_shard_dirty_plan
 };
 
 struct dslam_render_state {
@@ -235,6 +241,9 @@ int launch_slide_pop(dslam_engine *e, dslam_scene *s, dslam_render_state *r, int
 int launch_swap_in(dslam_engine *e, dslam_scene *s, dslam_render_state *r);
 int launch_swap_out(dslam_engine *e, dslam_scene *s, dslam_render_state *r, bool ignore_visibility);
 int launch_save_to_global(dslam_engine *e, dslam_scene *s);
+int launch_dirty_plan(dslam_engine *e, dslam_scene *s, int num_shards, int chunk_blocks, int *counts_host);
+int launch_dirty_pack(dslam_engine *e, const dslam_scene *s, int shard, void *send_dev, int capacity_blocks);
+int launch_dirty_unpack(dslam_engine *e, dslam_scene *s, int skip_shard, const void *recv_dev, int stride_blocks);
 int ensure_scratch(dslam_engine *e, int entries, int local_blocks);
 int finish_call(dslam_engine *e);  // synchronise unless the engine is in async mode
 inline int num_tiles(int entries) { return (entries + kTileEntries - 1) / kTileEntries; }

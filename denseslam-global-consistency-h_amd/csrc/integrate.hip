@@ -52,6 +52,7 @@ struct IntegrateParams {
   int *last_seen;
   int push_words, push_ring, push_bit, push_frame;
   int *timer_slot;  // bench instrumentation: where to record this launch's visible-block count (or null)
+  unsigned char *dirty;  // sharded re-integration: per slot "visited since tracking began" (null: not tracked)
 };
 
 // a / b for a divisor whose correctly rounded reciprocal y = RN(1/b) is known: q = RN(a*y), r = a - b*q (exact, FMA),
@@ -402,6 +403,8 @@ __global__ __launch_bounds__(256, 8) void k_integrate(IntegrateParams p) {
         p.masks[((size_t)ptr * 2 + p.push_ring) * p.push_words + (p.push_bit >> 6)] |= 1ull << (p.push_bit & 63);
         p.last_seen[ptr] = p.push_frame;
       }
+      // (before the shard test: every rank of a sharded batch ends up with the same set of marks)
+      if (p.dirty && lane == 0) p.dirty[ptr] = 1;
       if (p.num_shards > 1 && ((ptr / p.chunk_blocks) % p.num_shards) != p.shard) continue;
       if (p.shard_count >= 0 && (ptr < p.shard_first || ptr >= p.shard_first + p.shard_count)) continue;
       const int gx = __builtin_amdgcn_readlane(e_px, k) * kBlock;
@@ -482,6 +485,7 @@ static void fill_params(IntegrateParams &ip, dslam_engine *e, dslam_scene *s, co
   ip.depth_weighting = e->wp.depth_weighting; ip.max_new_w = e->wp.max_new_w; ip.max_distance = e->wp.max_distance;
   ip.shard = s->shard; ip.num_shards = s->num_shards; ip.chunk_blocks = s->chunk_blocks;
   ip.shard_first = s->shard_first; ip.shard_count = s->shard_count;
+  ip.dirty = s->dirty_tracking ? s->dirty : nullptr;
 }
 
 constexpr int kIntegrateGrid = 2048;

@@ -21,21 +21,6 @@
 
 namespace dslam {
 
-// ---- generic flag counting -----------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_flag_count(const unsigned char *__restrict__ flags, int n,
-                                                    int *__restrict__ tile_counts) {
-  __shared__ int red[4];
-  const int t0 = blockIdx.x * kTileEntries + threadIdx.x * 4;
-  int c = 0;
-  if (t0 < n) {
-    const uchar4 v = *reinterpret_cast<const uchar4 *>(flags + t0);
-    c = (v.x > 0) + (v.y > 0) + (v.z > 0) + (v.w > 0);
-  }
-  int tot;
-  block_excl_scan<4>(c, red, tot);
-  if (threadIdx.x == 0) tile_counts[blockIdx.x] = tot;
-}
-
 // ---- candidate selection ---------------------------------------------------------------------------------------
 // MODE 0: block carries bit `bit` of ring `ring` (aged-list decay)
 // MODE 1: same, and the bit is cleared; flag only blocks no queued list references any more (sliding-window pop)

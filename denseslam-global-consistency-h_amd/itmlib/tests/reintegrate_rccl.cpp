@@ -104,6 +104,7 @@ int main(int argc, char **argv) {
   // ---- the corrected batch, sharded --------------------------------------------------------------------------------
   const int chunk = 64;  // voxel-block slots per ownership chunk (256 KiB)
   const auto t0 = std::chrono::steady_clock::now();
+  CHECK_DSLAM(dslam_scene_track_dirty(eng, scene, 1));  // from here on the kernels note every block they visit
   CHECK_DSLAM(dslam_scene_set_shard(scene, rank, world, chunk));
   for (int j = 0; j < K; j++) {
     const int i = N - K + j;
@@ -117,29 +118,27 @@ int main(int argc, char **argv) {
   dslam_stats st;
   CHECK_DSLAM(dslam_get_stats(eng, scene, rs, &st));  // synchronises; identical on every rank
   const auto t1 = std::chrono::steady_clock::now();
-  // used slots are [lo, Nb): slots are dealt from the top of the pool; whole chunk groups
-  const int Nb = st.num_allocated_blocks, group = chunk * world;
-  const int used = Nb - 1 - st.last_free_block_id;
-  const int groups = (used + group - 1) / group;
-  const int lo = Nb - groups * group;
+  // exactly the blocks the batch touched: every rank derives the same per-shard lists, so neither ids nor counts travel
+  std::vector<int32_t> counts(world);
+  CHECK_DSLAM(dslam_shard_dirty_plan(eng, scene, world, chunk, counts.data()));
+  int cap = 1;
+  for (int c : counts) cap = c > cap ? c : cap;
   size_t gathered = 0;
-  if (groups > 0 && lo >= 0) {
-    const size_t bytes_per_rank = (size_t)groups * chunk * 4096;
+  {
+    const size_t bytes_per_rank = (size_t)cap * 4096;
     void *send = nullptr, *recv = nullptr;
     CHECK_HIP(hipMalloc(&send, bytes_per_rank));
     CHECK_HIP(hipMalloc(&recv, bytes_per_rank * world));
     hipStream_t stream = static_cast<hipStream_t>(dslam_engine_stream(eng));
-    CHECK_DSLAM(dslam_shard_pack(eng, scene, lo, groups, rank, world, chunk, send));
-    CHECK_NCCL(ncclAllGather(send, recv, bytes_per_rank, ncclChar, comm, stream));
-    CHECK_DSLAM(dslam_shard_unpack(eng, scene, lo, groups, world, chunk, recv));
+    CHECK_DSLAM(dslam_shard_dirty_pack(eng, scene, rank, send, cap));
+    CHECK_NCCL(ncclAllGather(send, recv, bytes_per_rank, ncclChar, comm, stream));  // (same stream: ordered behind the pack)
+    CHECK_DSLAM(dslam_shard_dirty_unpack(eng, scene, rank, recv, cap));
     CHECK_DSLAM(dslam_engine_synchronize(eng));
     CHECK_HIP(hipFree(send));
     CHECK_HIP(hipFree(recv));
     gathered = bytes_per_rank;
-  } else if (groups > 0) {
-    fprintf(stderr, "pool too small to round the used range to whole chunk groups\n");
-    return 1;
   }
+  CHECK_DSLAM(dslam_scene_track_dirty(eng, scene, 0));
   CHECK_DSLAM(dslam_scene_set_shard(scene, 0, 1, chunk));  // back to single-GPU fusion
   const auto t2 = std::chrono::steady_clock::now();
 

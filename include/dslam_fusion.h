@@ -447,16 +447,23 @@ int dslam_scene_set_shard(dslam_scene *s, int shard, int num_shards, int chunk_b
 /* Same, with a contiguous slot range [first_block, first_block + num_blocks): the layout an in-place RCCL
  * all-gather over the voxel-block array needs.  num_blocks < 0 disables. */
 int dslam_scene_set_shard_range(dslam_scene *s, int first_block, int num_blocks);
-/* The exchange step of the chunk-interleaved scheme, for callers that drive RCCL themselves.
- * The slot range [first_block, first_block + groups * num_shards * chunk_blocks) is `groups` groups of `num_shards`
- * chunks.  pack: this shard's chunks, in group order, into one contiguous device buffer of
- * groups * chunk_blocks * 4096 bytes (the all-gather send buffer).  unpack: the all-gather result
- * [num_shards][groups][chunk_blocks * 4096] back into the voxel-block array.  Both are strided device-to-device
- * copies on the engine stream. */
-int dslam_shard_pack(dslam_engine *e, const dslam_scene *s, int first_block, int groups, int shard, int num_shards,
-                     int chunk_blocks, void *send_dev);
-int dslam_shard_unpack(dslam_engine *e, dslam_scene *s, int first_block, int groups, int num_shards, int chunk_blocks,
-                       const void *recv_dev);
+/* The exchange for a batch whose blocks may sit ANYWHERE in the pool (after decay, the sliding window or swapping have
+ * returned slots to the free list in arbitrary order, the used slots are no longer a top range): move exactly the blocks
+ * the batch touched.  Allocation is replicated and bit-identical on every rank, and the (de-)integration kernels mark
+ * every visible resident block they walk over BEFORE their shard test, so all ranks hold the same marks and derive the
+ * same per-shard lists of dirty slots -- no ids travel, no counts are exchanged:
+ *   dslam_scene_track_dirty(e, s, 1)            clear the marks, start marking         (before the batch)
+ *   ... the batch: dslam_deprocess_frame / dslam_process_frame under dslam_scene_set_shard(rank, world, chunk) ...
+ *   dslam_shard_dirty_plan(e, s, world, chunk, counts)   counts[r] = dirty blocks of shard r, identical on all ranks
+ *   dslam_shard_dirty_pack(e, s, rank, send, cap)        this rank's dirty blocks, ascending in slot, 4096 B each
+ *   ncclAllGather(send, recv, cap * 4096 bytes) with cap = max(counts)   (the one collective)
+ *   dslam_shard_dirty_unpack(e, s, rank, recv, cap)      every other shard's blocks into place
+ *   dslam_scene_track_dirty(e, s, 0)
+ * num_local_blocks must be a multiple of world * chunk; world <= 64. */
+int dslam_scene_track_dirty(dslam_engine *e, dslam_scene *s, int enable);
+int dslam_shard_dirty_plan(dslam_engine *e, dslam_scene *s, int num_shards, int chunk_blocks, int32_t *counts_out);
+int dslam_shard_dirty_pack(dslam_engine *e, const dslam_scene *s, int shard, void *send_dev, int capacity_blocks);
+int dslam_shard_dirty_unpack(dslam_engine *e, dslam_scene *s, int skip_shard, const void *recv_dev, int stride_blocks);
 
 /* ---- instrumentation ---------------------------------------------------------------------------- */
 /* Time `iterations` back-to-back launches of the integrate kernel alone on the engine stream with HIP

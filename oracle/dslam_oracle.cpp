@@ -163,6 +163,12 @@ struct oracle_scene {
   dslam_voxel *stored;  // n_entries * 512, calloc'ed lazily by the OS
   int shard, num_shards, chunk_blocks;
   int shard_first, shard_count;
+  // sharded re-integration: per slot "a (de-)integration pass visited this block since tracking began"
+  std::vector<uint8_t> dirty;
+  bool dirty_tracking = false;
+  std::vector<int32_t> dirty_list;      // dirty slots, shard by shard, ascending inside a shard
+  std::vector<int32_t> dirty_counts;    // per shard
+  int dirty_chunk = 0;
 };
 
 struct oracle_render_state {
@@ -551,6 +557,48 @@ extern "C" int oracle_scene_set_shard(oracle_scene *s, int shard, int num_shards
 
 extern "C" int oracle_scene_set_shard_range(oracle_scene *s, int first, int count) {
   s->shard_first = first; s->shard_count = count; return 0;
+}
+
+// ---- the exchange step of the sharded re-integration (same contract as dslam_scene_track_dirty / dslam_shard_dirty_*;
+// the "device" buffers are host memory here) --------------------------------------------------------------------------
+extern "C" int oracle_scene_track_dirty(oracle_engine *, oracle_scene *s, int enable) {
+  if (enable) s->dirty.assign((size_t)s->p.num_local_blocks, 0);
+  s->dirty_tracking = enable != 0;
+  return 0;
+}
+extern "C" int oracle_shard_dirty_plan(oracle_engine *, oracle_scene *s, int num_shards, int chunk_blocks, int32_t *counts_out) {
+  const int N = s->p.num_local_blocks;
+  if (s->dirty.empty() || num_shards < 1 || num_shards > 64 || chunk_blocks < 1 || N % (num_shards * chunk_blocks)) return DSLAM_ERR_INVALID;
+  s->dirty_list.clear();
+  s->dirty_counts.assign(num_shards, 0);
+  for (int r = 0; r < num_shards; r++)
+    for (int c = r; c < N / chunk_blocks; c += num_shards)
+      for (int slot = c * chunk_blocks; slot < (c + 1) * chunk_blocks; slot++)
+        if (s->dirty[slot]) { s->dirty_list.push_back(slot); s->dirty_counts[r]++; }
+  for (int r = 0; r < num_shards; r++) counts_out[r] = s->dirty_counts[r];
+  s->dirty_chunk = chunk_blocks;
+  return 0;
+}
+extern "C" int oracle_shard_dirty_pack(oracle_engine *, const oracle_scene *s, int shard, void *send, int capacity_blocks) {
+  if (s->dirty_counts.empty() || shard < 0 || shard >= (int)s->dirty_counts.size()) return DSLAM_ERR_INVALID;
+  size_t off = 0;
+  for (int r = 0; r < shard; r++) off += s->dirty_counts[r];
+  const int n = std::min(s->dirty_counts[shard], capacity_blocks);
+  for (int i = 0; i < n; i++)
+    memcpy((char *)send + (size_t)i * 4096, &s->vba[(size_t)s->dirty_list[off + i] * 512], 4096);
+  return 0;
+}
+extern "C" int oracle_shard_dirty_unpack(oracle_engine *, oracle_scene *s, int skip_shard, const void *recv, int stride_blocks) {
+  if (s->dirty_counts.empty()) return DSLAM_ERR_INVALID;
+  size_t off = 0;
+  for (int r = 0; r < (int)s->dirty_counts.size(); r++) {
+    const int n = std::min(s->dirty_counts[r], stride_blocks);
+    if (r != skip_shard)
+      for (int i = 0; i < n; i++)
+        memcpy(&s->vba[(size_t)s->dirty_list[off + i] * 512], (const char *)recv + ((size_t)r * stride_blocks + i) * 4096, 4096);
+    off += s->dirty_counts[r];
+  }
+  return 0;
 }
 
 extern "C" int oracle_render_state_create(oracle_engine *, const oracle_scene *s, int w, int h, oracle_render_state **out) {
@@ -1071,6 +1119,7 @@ static void integrate_impl(oracle_engine *e, oracle_scene *s, const oracle_view 
   for (int i = 0; i < n; i++) {
     const dslam_hash_entry &he = s->hash[r->visible_ids[i]];
     if (he.ptr < 0) continue;
+    if (s->dirty_tracking) s->dirty[he.ptr] = 1;  // (before the shard test: every rank ends up with the same marks)
     if (s->num_shards > 1 && ((he.ptr / s->chunk_blocks) % s->num_shards) != s->shard) continue;
     if (s->shard_count >= 0 && (he.ptr < s->shard_first || he.ptr >= s->shard_first + s->shard_count)) continue;
     int gx = he.pos[0] * DSLAM_BLOCK_SIZE, gy = he.pos[1] * DSLAM_BLOCK_SIZE, gz = he.pos[2] * DSLAM_BLOCK_SIZE;

@@ -9,14 +9,18 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 
-def build_map(api, pkg, wl, params, n_frames):
+def build_map(api, pkg, wl, params, n_frames, maintenance):
+    """Fuse n_frames; with `maintenance` the map is also decayed and slid like BASELINE configs[2] (reference
+    DenseSlam.cpp:215-232), so that freed slots have gone back to the pool in arbitrary order and live blocks sit anywhere."""
     import util
-    return util.run_sequence(api, pkg, wl, params, n_frames)
+    if not maintenance:
+        return util.run_sequence(api, pkg, wl, params, n_frames)
+    return util.run_sequence(api, pkg, wl, params, n_frames, decay=(1, 2, True), slide=2)
 
 
-def make_batch(pkg, synth, reint, wl, n_frames):
+def make_batch(pkg, synth, reint, wl, first, n):
     frames, old, new = [], [], []
-    for j in range(n_frames):
+    for j in range(first, first + n):
         rgba, mm, M_old = wl.frame(j)
         T_new = wl.pose(j) @ synth.pose_matrix(synth.look_rotation(0.004 * (j + 1), -0.002), [0.01, 0.002 * j, -0.005])
         frames.append(("host", rgba, mm))
@@ -25,7 +29,7 @@ def make_batch(pkg, synth, reint, wl, n_frames):
     return reint.Batch(frames, old, new, wl.intr)
 
 
-def main(rank, world, port, out_path):
+def main(rank, world, port, out_path, maintenance):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     import torch
@@ -40,25 +44,35 @@ def main(rank, world, port, out_path):
     wl = synth.s_tiny()
     chunk = 16
     params = util.small_params(pkg, wl, num_local_blocks=0x800, num_buckets=0x1000, num_excess=0x400)
-    n_frames = 5
-    s, rs, v = build_map(api, pkg, wl, params, n_frames)
-    batch = make_batch(pkg, synth, reint, wl, n_frames)
+    n_frames = 12 if maintenance else 5
+    s, rs, v = build_map(api, pkg, wl, params, n_frames, maintenance)
+    # the keyframes still inside the window are the ones a correction re-fuses
+    batch = make_batch(pkg, synth, reint, wl, n_frames - 3 if maintenance else 0, 3 if maintenance else n_frames)
     timers = {}
-    reint.reintegrate(api, s, v, rs, batch, rank=rank, world=world, chunk_blocks=chunk,
-                      all_gather=reint.make_numpy_all_gather(api, s, dist, chunk), timers=timers)
+    counts = reint.reintegrate(api, s, v, rs, batch, rank=rank, world=world, chunk_blocks=chunk,
+                               all_gather=reint.make_numpy_all_gather(api, s, dist), timers=timers)
     snap = util.snapshot(api, s, rs)
     ok = True
     msg = ""
     if rank == 0:
         # single-rank reference in the same process
-        s1, rs1, v1 = build_map(api, pkg, wl, params, n_frames)
+        s1, rs1, v1 = build_map(api, pkg, wl, params, n_frames, maintenance)
+        before = util.snapshot(api, s1, rs1)
         reint.reintegrate(api, s1, v1, rs1, batch, rank=0, world=1)
         ref = util.snapshot(api, s1, rs1)
         try:
             util.assert_same_state(snap, ref, "sharded vs single")
-            assert timers["gathered_bytes"] > 0
-            changed = (ref["voxels"]["w_depth"] > 0).sum()
-            assert changed > 1000
+            changed = int((ref["voxels"].view(np.uint64) != before["voxels"].view(np.uint64)).any(axis=1).sum())
+            assert changed > 200, f"the batch changed only {changed} blocks"
+            assert timers["dirty_blocks"] >= changed and timers["gathered_bytes"] == world * max(counts) * 4096
+            if maintenance:
+                # the premise of the old exchange ("used slots are a top range of the pool") must be FALSE here, or the
+                # test does not cover the case it exists for
+                st = before["stats"]
+                used = params.num_local_blocks - 1 - st["last_free_block_id"]
+                lowest = int(before["hash"]["ptr"][before["hash"]["ptr"] >= 0].min())
+                assert lowest < params.num_local_blocks - used, "live blocks still form a top range"
+                assert st["slid_block_count"] + st["decayed_block_count"] > 0
         except AssertionError as ex:
             ok, msg = False, str(ex)
     # every rank must hold the same gathered map
@@ -76,4 +90,4 @@ def main(rank, world, port, out_path):
 
 
 if __name__ == "__main__":
-    main(int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]), sys.argv[4])
+    main(int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]), sys.argv[4], int(sys.argv[5]) != 0)

@@ -224,57 +224,69 @@ def test_full_size_parity_with_oracle(pkg, synth, gpu, oracle, swapping):
     assert np.abs(imgs["gpu"][1].astype(int) - imgs["oracle"][1].astype(int)).max() <= 1
 
 
-def test_sharded_reintegration_with_abi_pack_unpack(pkg, synth, gpu):
-    """The multi-GPU re-integration scheme rehearsed on one GPU: two map replicas play ranks 0 and 1, each
-    de-/re-integrates only its own slot chunks, the exchange is dslam_shard_pack -> (what an all-gather delivers) ->
-    dslam_shard_unpack.  Both replicas must end byte-identical to the unsharded run."""
+@pytest.mark.parametrize("maintenance", [False, True])
+def test_sharded_reintegration_exchanges_dirty_blocks(pkg, synth, gpu, oracle, maintenance):
+    """The multi-GPU re-integration scheme rehearsed on one GPU: `world` map replicas play the ranks, each
+    de-/re-integrates only its own slot chunks, the exchange is dslam_shard_dirty_plan -> dslam_shard_dirty_pack -> (what
+    an all-gather delivers) -> dslam_shard_dirty_unpack.  Every replica must end byte-identical to the unsharded run --
+    also on a map that was decayed and slid first (BASELINE configs[2]), where freed slots have gone back to the pool in
+    arbitrary order and live blocks no longer form a top range of it -- and the lists must be the oracle's."""
     torch = pytest.importorskip("torch")
-    from dslam_amd.harness import reintegrate
     wl = synth.s_tiny()
-    p = util.small_params(pkg, wl)
-    world, chunk = 2, 16
-    n_frames = 6
-    frames = [wl.frame(i) for i in range(n_frames)]
-    new_M = [synth.world_to_camera(wl.pose(i) @ synth.pose_matrix(synth.look_rotation(0.004, 0.002), [0.004, -0.002, 0.003]))
-             for i in range(n_frames)]
+    p = util.small_params(pkg, wl, num_local_blocks=0x800, num_buckets=0x1000, num_excess=0x400)
+    world, chunk = 4, 16
+    n_frames = 12 if maintenance else 6
+    fix = (9, 10, 11) if maintenance else (1, 3, 4)
+    new_M = {i: synth.world_to_camera(wl.pose(i) @ synth.pose_matrix(synth.look_rotation(0.004, 0.002), [0.004, -0.002, 0.003])) for i in fix}
 
-    def build():
-        s = gpu.create_scene(p)
-        rs, v = gpu.create_render_state(s, wl.W, wl.H), gpu.create_view(wl.W, wl.H)
-        for i, (rgba, mm, M) in enumerate(frames):
-            gpu.view_update(v, rgba, mm, timestamp=float(i))
-            gpu.process_frame(s, v, rs, M, wl.intr)
-        return s, rs, v
+    def build(api):
+        if maintenance:
+            return util.run_sequence(api, pkg, wl, p, n_frames, decay=(1, 2, True), slide=2)
+        return util.run_sequence(api, pkg, wl, p, n_frames)
 
-    def correct(s, rs, v):
-        for i in (1, 3, 4):
-            rgba, mm, M = frames[i]
-            gpu.view_update(v, rgba, mm, timestamp=float(i))
-            gpu.deprocess_frame(s, v, rs, M, wl.intr)
-            gpu.process_frame(s, v, rs, new_M[i], wl.intr, is_defusion=True)
+    def correct(api, s, rs, v):
+        for i in fix:
+            rgba, mm, M = wl.frame(i)
+            api.view_update(v, rgba, mm, timestamp=float(i))
+            api.deprocess_frame(s, v, rs, M, wl.intr)
+            api.process_frame(s, v, rs, new_M[i], wl.intr, is_defusion=True)
 
-    ref = build()
-    correct(*ref)
+    ref = build(gpu)
+    before = util.snapshot(gpu, ref[0], ref[1])
+    correct(gpu, *ref)
     want = util.snapshot(gpu, ref[0], ref[1])
+    if maintenance:  # the case the slot-range exchange of round 1 got wrong
+        used = p.num_local_blocks - 1 - before["stats"]["last_free_block_id"]
+        assert int(before["hash"]["ptr"][before["hash"]["ptr"] >= 0].min()) < p.num_local_blocks - used
 
-    ranks = [build() for _ in range(world)]
+    ranks = [build(gpu) for _ in range(world)]
+    counts = None
     for r, (s, rs, v) in enumerate(ranks):
+        gpu.track_dirty(s, True)
         gpu.set_shard(s, r, world, chunk)
-        correct(s, rs, v)
-    st = gpu.stats(ranks[0][0], ranks[0][1])
-    lo, groups = reintegrate.plan_region(st["last_free_block_id"], p.num_local_blocks, world, chunk)
-    chunk_bytes = chunk * reintegrate.BLOCK_BYTES
-    recv = torch.empty((world, groups, chunk_bytes), dtype=torch.uint8, device="cuda")
+        correct(gpu, s, rs, v)
+        c = gpu.shard_dirty_plan(s, world, chunk)
+        assert counts is None or c == counts, "ranks disagree about the dirty lists"
+        counts = c
+    # the oracle, unsharded but tracking, names the same blocks
+    so, rso, vo = build(oracle)
+    oracle.track_dirty(so, True)
+    correct(oracle, so, rso, vo)
+    assert oracle.shard_dirty_plan(so, world, chunk) == counts and min(counts) > 20
+    cap = max(counts)
+    recv = torch.zeros((world, cap, 4096), dtype=torch.uint8, device="cuda")
     for r, (s, rs, v) in enumerate(ranks):  # every rank's send buffer lands in slice r of every rank's recv buffer
-        gpu.shard_pack(s, lo, groups, r, world, chunk, recv[r].data_ptr())
+        gpu.shard_dirty_pack(s, r, recv[r].data_ptr(), cap)
     gpu.synchronize()
     for r, (s, rs, v) in enumerate(ranks):
-        gpu.shard_unpack(s, lo, groups, world, chunk, recv.data_ptr())
+        if r == 0:  # before the exchange a rank holds only its own shard's updates
+            assert not np.array_equal(gpu.download_voxel_blocks(s).view(np.uint64), want["voxels"].view(np.uint64))
+        gpu.shard_dirty_unpack(s, r, recv.data_ptr(), cap)
         gpu.set_shard(s, 0, 1, chunk)
-        got = util.snapshot(gpu, s, rs)
-        util.assert_same_state(got, want, f"rank {r} after the exchange")
-    # and the shards really were disjoint halves of the work: before the exchange the ranks differed
-    assert groups >= 2
+        gpu.track_dirty(s, False)
+        util.assert_same_state(util.snapshot(gpu, s, rs), want, f"rank {r} after the exchange")
+    changed = int((want["voxels"].view(np.uint64) != before["voxels"].view(np.uint64)).any(axis=1).sum())
+    assert sum(counts) >= changed > 200
 
 
 @pytest.mark.parametrize("size", [(912, 228), (1226, 370), (70, 45)])

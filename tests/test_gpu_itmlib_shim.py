@@ -175,5 +175,6 @@ def test_native_rccl_reintegration_single_rank_matches_unsharded_oracle(pkg, syn
     assert last_free == st["last_free_block_id"] and no_vis == st["no_visible_entries"]
     assert h_hash == fnv1a(oracle.download_hash_table(s).tobytes())
     assert h_vox == fnv1a(oracle.download_voxel_blocks(s).tobytes())
+    # one rank: the send buffer holds every block the batch visited (the union of the visible lists of its passes)
     used = p.num_local_blocks - 1 - last_free
-    assert gathered == ((used + 63) // 64) * 64 * 4096 and ms_reint > 0 and ms_gather > 0
+    assert 4096 * 300 < gathered <= used * 4096 and gathered % 4096 == 0 and ms_reint > 0 and ms_gather > 0
