@@ -285,6 +285,29 @@ def main():
                          "all_gather_GBps": (timers["gathered_bytes"] / agt / 1e9) if (use_dist and agt > 0) else None,
                          "scaling": "strong (fixed batch; allocation replicated on every rank, voxel blocks sharded, "
                                     "one all-gather of the blocks the batch touched)"}
+            # the same batch undone again (poses back to the originals), this time de-integrating from each keyframe's
+            # stored visible list instead of an allocation pass at the old pose (dslam_deprocess_frame_stored)
+            store = eng.create_frame_store(wl.W, wl.H, Kre)
+            eng.frame_store_enable_lists(store, scene)
+            eng.set_async(False)
+            for n_, i in enumerate(ids):  # keyframe images into the store; lists as a re-fusion at the corrected pose leaves them
+                eng.view_update_device(view, rgba_d.data_ptr() + i * rgba_stride, depth_d.data_ptr() + i * depth_stride, timestamp=float(i))
+                eng.frame_store_put_view(store, n_, view)
+                eng.allocate_scene_from_depth(scene, view, rs, new_poses[n_], wl.intr, only_update_visible_list=True)
+                eng.frame_store_put_visible_list(store, n_, scene, rs)
+            batch2 = reint.Batch([("store", store, n_) for n_ in range(Kre)], new_poses, [Ms[i] for i in ids], wl.intr)
+            eng.set_async(args.mode != "sync")
+            timers2 = {}
+            barrier()
+            reint.reintegrate(eng, scene, view, rs, batch2, rank=rank, world=world, chunk_blocks=chunk, all_gather=ag,
+                              timers=timers2, force_collective=use_dist, stored_lists=True)
+            barrier()
+            t2 = torch.tensor([timers2["total_s"]], device=dev, dtype=torch.float64)
+            if use_dist:
+                dist.all_reduce(t2, op=dist.ReduceOp.MAX)
+            reint_out["stored_lists_keyframes_per_s"] = Kre / float(t2.item())
+            reint_out["stored_lists_total_ms"] = float(t2.item()) * 1e3
+            store.close()
         except Exception as ex:  # never lose the main line over the auxiliary measurement
             reint_out = {"error": repr(ex)}
 

@@ -309,6 +309,21 @@ class CApi:
         self._call("frame_store_get", self._engine, fs.ptr, C.c_int(slot), _vptr(rgba), _vptr(depth))
         return rgba, depth
 
+    def frame_store_enable_lists(self, fs, scene):
+        self._call("frame_store_enable_lists", self._engine, fs.ptr, scene.ptr)
+
+    def frame_store_put_visible_list(self, fs, slot, scene, rs):
+        """Keep the render state's visible list (the blocks the keyframe was just fused into) with the keyframe."""
+        self._call("frame_store_put_visible_list", self._engine, fs.ptr, C.c_int(slot), scene.ptr, rs.ptr)
+
+    def deprocess_frame_stored(self, scene, view, fs, slot, M_d, intr, M_rgb=None, intr_rgb=None):
+        """DeProcessFrame on exactly the blocks stored with the keyframe (no allocation pass; render state untouched)."""
+        m, k = self._mi(M_d, intr)
+        mr = mat_to_abi(M_rgb) if M_rgb is not None else None
+        kr = np.ascontiguousarray(intr_rgb, dtype=np.float32) if intr_rgb is not None else None
+        self._call("deprocess_frame_stored", self._engine, scene.ptr, view.ptr, fs.ptr, C.c_int(slot), _fptr(m), _fptr(k),
+                   _fptr(mr), _fptr(kr))
+
     def view_update_from_store(self, view, fs, slot, affine_a=1.0 / 1000.0, affine_b=0.0, timestamp=0.0, bilateral=False):
         self._call("view_update_from_store", self._engine, view.ptr, fs.ptr, C.c_int(slot), C.c_float(affine_a),
                    C.c_float(affine_b), C.c_double(timestamp), C.c_int(int(bilateral)))

@@ -709,7 +709,7 @@ int dslam_frame_store_create(dslam_engine *e, int w_rgb, int h_rgb, int w_d, int
 int dslam_frame_store_destroy(dslam_frame_store *fs) {
   if (!fs) return DSLAM_OK;
   (void)hipStreamSynchronize(fs->engine->stream);
-  free_dev(fs->rgba); free_dev(fs->depth);
+  free_dev(fs->rgba); free_dev(fs->depth); free_dev(fs->lists);
   delete fs;
   return DSLAM_OK;
 }
@@ -776,6 +776,52 @@ int dslam_view_update_from_store(dslam_engine *e, dslam_view *v, const dslam_fra
   DSLAM_REQUIRE(v && v->engine == e, "null argument");
   DSLAM_REQUIRE(v->w_rgb == fs->w_rgb && v->h_rgb == fs->h_rgb && v->w_d == fs->w_d && v->h_d == fs->h_d, "view and frame store sizes differ");
   return finish_view_update(e, v, fs->rgba + fs->rgba_bytes * slot, fs->depth + fs->depth_bytes * slot, a, b, timestamp, use_bilateral);
+}
+
+// ---- the visible list of a keyframe's fusion, kept with the keyframe ------------------------------------------------
+static const size_t kListHeader = 64;  // (a RenderCounters-shaped count block, padded)
+
+int dslam_frame_store_enable_lists(dslam_engine *e, dslam_frame_store *fs, const dslam_scene *s) {
+  DSLAM_REQUIRE(e && fs && s && fs->engine == e, "bad argument");
+  if (fs->lists && fs->list_cap >= s->p.num_local_blocks) return DSLAM_OK;
+  DSLAM_HIP(hipStreamSynchronize(e->stream));
+  free_dev(fs->lists);
+  fs->list_cap = s->p.num_local_blocks;
+  fs->list_bytes = (kListHeader + (size_t)fs->list_cap * (sizeof(int) + sizeof(short4)) + 255) & ~(size_t)255;
+  DSLAM_HIP(hipMalloc(&fs->lists, fs->list_bytes * fs->capacity));
+  fs->has_list.assign(fs->capacity, 0);
+  return DSLAM_OK;
+}
+
+static unsigned char *list_slot(const dslam_frame_store *fs, int slot) { return fs->lists + fs->list_bytes * slot; }
+
+int dslam_frame_store_put_visible_list(dslam_engine *e, dslam_frame_store *fs, int slot, const dslam_scene *s,
+                                       const dslam_render_state *r) {
+  int rc = store_slot_ok(e, fs, slot);
+  if (rc) return rc;
+  DSLAM_REQUIRE(s && r && fs->lists, "dslam_frame_store_enable_lists has not been called");
+  DSLAM_REQUIRE(fs->list_cap >= r->n_local, "the store's lists are smaller than this render state's visible list");
+  unsigned char *base = list_slot(fs, slot);
+  rc = launch_store_visible_list(e, s, r, base, reinterpret_cast<int *>(base + kListHeader),
+                                 reinterpret_cast<short4 *>(base + kListHeader + (size_t)fs->list_cap * sizeof(int)), fs->list_cap);
+  if (rc) return rc;
+  fs->has_list[slot] = 1;
+  return finish_call(e);
+}
+
+int dslam_deprocess_frame_stored(dslam_engine *e, dslam_scene *s, const dslam_view *v, const dslam_frame_store *fs, int slot,
+                                 const float M_d[16], const float intr_d[4], const float M_rgb[16], const float intr_rgb[4]) {
+  int rc = store_slot_ok(e, fs, slot);
+  if (rc) return rc;
+  DSLAM_REQUIRE(s && v && M_d && intr_d && s->engine == e && v->engine == e, "bad argument");
+  DSLAM_REQUIRE(fs->lists && fs->has_list[slot], "no visible list was stored for this keyframe slot");
+  s->version = next_map_version();  // the map changes: GetImage memos of this scene are stale
+  const unsigned char *base = list_slot(fs, slot);
+  rc = launch_integrate_list(e, s, v, base, reinterpret_cast<const int *>(base + kListHeader),
+                             reinterpret_cast<const short4 *>(base + kListHeader + (size_t)fs->list_cap * sizeof(int)), M_d, intr_d,
+                             M_rgb, intr_rgb, true);
+  if (rc) return rc;
+  return finish_call(e);
 }
 
 // ---- depthPostProcessing -------------------------------------------------------------------------------------

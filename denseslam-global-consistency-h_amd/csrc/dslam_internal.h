@@ -200,6 +200,12 @@ struct dslam_frame_store {
   size_t rgba_bytes = 0, depth_bytes = 0;  // per slot
   unsigned char *rgba = nullptr;
   unsigned char *depth = nullptr;
+  // optional: per slot the visible list of the keyframe's fusion (dslam_frame_store_enable_lists):
+  // [RenderCounters-sized header: count][int ids[list_cap]][short4 pos[list_cap]]
+  unsigned char *lists = nullptr;
+  int list_cap = 0;
+  size_t list_bytes = 0;  // per slot
+  std::vector<unsigned char> has_list;
 };
 
 namespace dslam {
@@ -218,6 +224,12 @@ int launch_allocate(dslam_engine *e, dslam_scene *s, const dslam_view *v, dslam_
 int launch_integrate(dslam_engine *e, dslam_scene *s, const dslam_view *v, const dslam_render_state *r,
                      const float *M_d, const float *intr_d, const float *M_rgb, const float *intr_rgb,
                      bool deintegrate, int push_ring = -1);
+// the same kernel over a stored list (count header, ids, expected block positions) instead of a render state's
+int launch_integrate_list(dslam_engine *e, dslam_scene *s, const dslam_view *v, const void *count_header, const int *ids,
+                          const short4 *expect_pos, const float *M_d, const float *intr_d, const float *M_rgb,
+                          const float *intr_rgb, bool deintegrate);
+int launch_store_visible_list(dslam_engine *e, const dslam_scene *s, const dslam_render_state *r, void *header, int *ids,
+                              short4 *pos, int capacity);
 int ensure_view_depth(dslam_engine *e, const dslam_view *v);
 int launch_selftest_division(dslam_engine *e, long long samples, unsigned long long *mismatches_dev);
 int prepare_push_visible_list(dslam_engine *e, dslam_scene *s, int q, int *bit_out, int *frame_out);

@@ -53,6 +53,7 @@ struct IntegrateParams {
   int push_words, push_ring, push_bit, push_frame;
   int *timer_slot;  // bench instrumentation: where to record this launch's visible-block count (or null)
   unsigned char *dirty;  // sharded re-integration: per slot "visited since tracking began" (null: not tracked)
+  const short4 *expect_pos;  // stored keyframe list: the block each listed entry held at fusion time (null: a live list)
 };
 
 // a / b for a divisor whose correctly rounded reciprocal y = RN(1/b) is known: q = RN(a*y), r = a - b*q (exact, FMA),
@@ -395,6 +396,10 @@ __global__ __launch_bounds__(256, 8) void k_integrate(IntegrateParams p) {
     if (lane < G && base + lane < nvis) {
       const HashEntry e = load_entry(p.hash, p.visible_ids[base + lane]);
       e_ptr = e.ptr; e_px = e.pos[0]; e_py = e.pos[1]; e_pz = e.pos[2];
+      if (p.expect_pos) {  // a list stored with a keyframe: the entry must still hold the block it held then
+        const short4 ep = p.expect_pos[base + lane];
+        if (ep.x != e.pos[0] || ep.y != e.pos[1] || ep.z != e.pos[2]) e_ptr = -2;
+      }
     }
     for (int k = 0; k < G; k++) {
       const int ptr = __builtin_amdgcn_readlane(e_ptr, k);
@@ -486,22 +491,12 @@ static void fill_params(IntegrateParams &ip, dslam_engine *e, dslam_scene *s, co
   ip.shard = s->shard; ip.num_shards = s->num_shards; ip.chunk_blocks = s->chunk_blocks;
   ip.shard_first = s->shard_first; ip.shard_count = s->shard_count;
   ip.dirty = s->dirty_tracking ? s->dirty : nullptr;
+  ip.expect_pos = nullptr;
 }
 
 constexpr int kIntegrateGrid = 2048;
 
-int launch_integrate(dslam_engine *e, dslam_scene *s, const dslam_view *v, const dslam_render_state *r,
-                     const float *M_d, const float *intr_d, const float *M_rgb, const float *intr_rgb,
-                     bool deintegrate, int push_ring) {
-  int rc = ensure_view_depth(e, v);
-  if (rc) return rc;
-  IntegrateParams ip;
-  fill_params(ip, e, s, v, r, M_d, intr_d, M_rgb, intr_rgb);
-  ip.masks = s->masks; ip.last_seen = s->last_seen; ip.push_words = 0; ip.push_ring = 0; ip.push_bit = 0; ip.push_frame = 0;
-  if (push_ring >= 0) {
-    if ((rc = prepare_push_visible_list(e, s, push_ring, &ip.push_bit, &ip.push_frame))) return rc;
-    ip.push_words = s->history_words; ip.push_ring = push_ring;
-  }
+static int launch_integrate_params(dslam_engine *e, IntegrateParams &ip, bool deintegrate) {
   ip.timer_slot = nullptr;
   // Timed launches (bench roofline) attach their two events to the dispatch packet itself (hipExtLaunchKernelGGL), so
   // the elapsed time is the kernel's own start-to-end interval -- what rocprofv3 reports -- not the interval between
@@ -522,6 +517,60 @@ int launch_integrate(dslam_engine *e, dslam_scene *s, const dslam_view *v, const
     if (ip.same_cam) hipExtLaunchKernelGGL((k_integrate<false, true>), grid, block, 0, e->stream, ev0, ev1, 0, ip);
     else hipExtLaunchKernelGGL((k_integrate<false, false>), grid, block, 0, e->stream, ev0, ev1, 0, ip);
   }
+  DSLAM_HIP(hipGetLastError());
+  return DSLAM_OK;
+}
+
+int launch_integrate(dslam_engine *e, dslam_scene *s, const dslam_view *v, const dslam_render_state *r,
+                     const float *M_d, const float *intr_d, const float *M_rgb, const float *intr_rgb,
+                     bool deintegrate, int push_ring) {
+  int rc = ensure_view_depth(e, v);
+  if (rc) return rc;
+  IntegrateParams ip;
+  fill_params(ip, e, s, v, r, M_d, intr_d, M_rgb, intr_rgb);
+  ip.masks = s->masks; ip.last_seen = s->last_seen; ip.push_words = 0; ip.push_ring = 0; ip.push_bit = 0; ip.push_frame = 0;
+  if (push_ring >= 0) {
+    if ((rc = prepare_push_visible_list(e, s, push_ring, &ip.push_bit, &ip.push_frame))) return rc;
+    ip.push_words = s->history_words; ip.push_ring = push_ring;
+  }
+  return launch_integrate_params(e, ip, deintegrate);
+}
+
+int launch_integrate_list(dslam_engine *e, dslam_scene *s, const dslam_view *v, const void *count_header, const int *ids,
+                          const short4 *expect_pos, const float *M_d, const float *intr_d, const float *M_rgb,
+                          const float *intr_rgb, bool deintegrate) {
+  int rc = ensure_view_depth(e, v);
+  if (rc) return rc;
+  IntegrateParams ip;
+  // (fill_params only takes the list pointer and the counter block from the render state)
+  dslam_render_state list_view;
+  list_view.visible_ids = const_cast<int *>(ids);
+  list_view.counters = reinterpret_cast<RenderCounters *>(const_cast<void *>(count_header));
+  fill_params(ip, e, s, v, &list_view, M_d, intr_d, M_rgb, intr_rgb);
+  ip.expect_pos = expect_pos;
+  ip.masks = s->masks; ip.last_seen = s->last_seen; ip.push_words = 0; ip.push_ring = 0; ip.push_bit = 0; ip.push_frame = 0;
+  return launch_integrate_params(e, ip, deintegrate);
+}
+
+// the render state's visible list, with the block position of every entry, into a keyframe's list slot
+__global__ __launch_bounds__(256) void k_store_visible_list(const int *__restrict__ ids, const RenderCounters *rc,
+                                                            const HashEntry *__restrict__ hash, RenderCounters *header,
+                                                            int *__restrict__ out_ids, short4 *__restrict__ out_pos, int capacity) {
+  int n = rc->no_visible;
+  n = n < capacity ? n : capacity;
+  if (blockIdx.x == 0 && threadIdx.x == 0) { RenderCounters h = {}; h.no_visible = n; *header = h; }
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+    const int t = ids[i];
+    const HashEntry e = load_entry(hash, t);
+    out_ids[i] = t;
+    out_pos[i] = make_short4(e.pos[0], e.pos[1], e.pos[2], 0);
+  }
+}
+
+int launch_store_visible_list(dslam_engine *e, const dslam_scene *s, const dslam_render_state *r, void *header, int *ids,
+                              short4 *pos, int capacity) {
+  hipLaunchKernelGGL(k_store_visible_list, dim3(64), dim3(256), 0, e->stream, r->visible_ids, r->counters, s->hash,
+                     reinterpret_cast<RenderCounters *>(header), ids, pos, capacity);
   DSLAM_HIP(hipGetLastError());
   return DSLAM_OK;
 }

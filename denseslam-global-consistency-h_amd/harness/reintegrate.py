@@ -29,8 +29,8 @@ BLOCK_BYTES = 512 * 8
 
 
 class Batch:
-    """The corrected keyframes: frames (("dev", rgba_ptr, depth_ptr) or ("host", rgba, depth_mm)) plus old / new
-    world->camera poses and the intrinsics."""
+    """The corrected keyframes: frames (("dev", rgba_ptr, depth_ptr), ("host", rgba, depth_mm) or ("store", frame_store,
+    slot)) plus old / new world->camera poses and the intrinsics."""
 
     def __init__(self, frames, old_poses, new_poses, intr):
         self.frames, self.old_poses, self.new_poses, self.intr = frames, old_poses, new_poses, intr
@@ -42,14 +42,19 @@ class Batch:
 def _update_view(api, view, frame, ts):
     if frame[0] == "dev":
         api.view_update_device(view, frame[1], frame[2], timestamp=ts)
+    elif frame[0] == "store":
+        api.view_update_from_store(view, frame[1], frame[2], timestamp=ts)
     else:
         api.view_update(view, frame[1], frame[2], timestamp=ts)
 
 
 def reintegrate(api, scene, view, rs, batch, rank=0, world=1, chunk_blocks=64, all_gather=None, timers=None,
-                force_collective=False):
+                force_collective=False, stored_lists=False):
     """Run the batch on this rank; `all_gather(counts)` performs pack -> collective -> unpack for the per-shard dirty
-    block counts (None when world == 1; force_collective runs it even for a single rank, as a plumbing check)."""
+    block counts (None when world == 1; force_collective runs it even for a single rank, as a plumbing check).
+    stored_lists: the frames are ("store", frame_store, slot) keyframes whose fusion-time visible lists sit in the
+    store; de-integration then skips its allocation pass (dslam_deprocess_frame_stored) -- the part of the batch that
+    every rank would otherwise repeat -- and the list of the re-fusion replaces the stored one."""
     t0 = time.perf_counter()
     collective = (world > 1 or force_collective) and all_gather is not None
     if collective:
@@ -58,8 +63,13 @@ def reintegrate(api, scene, view, rs, batch, rank=0, world=1, chunk_blocks=64, a
         api.set_shard(scene, rank, world, chunk_blocks)
     for k in range(len(batch)):
         _update_view(api, view, batch.frames[k], float(k))
-        api.deprocess_frame(scene, view, rs, batch.old_poses[k], batch.intr)  # DenseSlam.cpp:390-393
+        if stored_lists:
+            api.deprocess_frame_stored(scene, view, batch.frames[k][1], batch.frames[k][2], batch.old_poses[k], batch.intr)
+        else:
+            api.deprocess_frame(scene, view, rs, batch.old_poses[k], batch.intr)  # DenseSlam.cpp:390-393
         api.process_frame(scene, view, rs, batch.new_poses[k], batch.intr, is_defusion=True)  # DenseSlam.cpp:401-403
+        if stored_lists:
+            api.frame_store_put_visible_list(batch.frames[k][1], batch.frames[k][2], scene, rs)
     api.stats(scene, rs)  # synchronises
     t1 = time.perf_counter()
     counts = None

@@ -249,6 +249,26 @@ int dslam_frame_store_device_ptrs(const dslam_frame_store *fs, int slot, void **
 int dslam_view_update_from_store(dslam_engine *e, dslam_view *v, const dslam_frame_store *fs, int slot,
                                  float affine_a, float affine_b, double timestamp, int use_bilateral_filter);
 
+/* The blocks a keyframe was fused into, kept with it (optional).  DeProcessFrame as the reference calls it has only the
+ * frame and its old pose, so it first has to find the blocks again: a visible-list-only allocation pass at that pose (two
+ * kernel launches over the depth image and the table) -- which in a re-integration batch is work every GPU repeats.  With
+ * the list stored at fusion time, de-integration goes straight to the integration kernel:
+ *   dslam_frame_store_enable_lists(e, fs, scene)            room for one list of num_local_blocks entries per slot
+ *   dslam_frame_store_put_visible_list(e, fs, slot, s, r)   after ProcessFrame of that keyframe (fusion or re-fusion): the
+ *                                                           render state's visible list with each entry's block position
+ *   dslam_deprocess_frame_stored(e, s, v, fs, slot, M_d, ...)   the inverse update of DeProcessFrame on exactly those
+ *                                                           blocks: an entry that no longer holds the same block (released
+ *                                                           by decay / the window since, or re-used) is skipped
+ * Semantics differ from dslam_deprocess_frame in WHICH blocks are visited (the keyframe's own, instead of whatever an
+ * allocation pass at the old pose finds today, previous-list carry-over included), and the render state is left alone.
+ * The view must hold the keyframe's images (dslam_view_update_from_store). */
+int dslam_frame_store_enable_lists(dslam_engine *e, dslam_frame_store *fs, const dslam_scene *s);
+int dslam_frame_store_put_visible_list(dslam_engine *e, dslam_frame_store *fs, int slot, const dslam_scene *s,
+                                       const dslam_render_state *r);
+int dslam_deprocess_frame_stored(dslam_engine *e, dslam_scene *s, const dslam_view *v, const dslam_frame_store *fs, int slot,
+                                 const float M_d[16], const float intrinsics_d[4], const float M_rgb[16],
+                                 const float intrinsics_rgb[4]);
+
 /* DenseSlam::depthPostProcessing's pixel loop (DenseSlam.cpp:488-529): blanks (sets to 0) every pixel of the
  * current keyframe's depth whose reprojection into the previous keyframe disagrees with that keyframe's depth by
  * more than `filter_threshold` (relative) and which lies below row `filter_area * rows`

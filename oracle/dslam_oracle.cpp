@@ -759,10 +759,16 @@ struct oracle_frame_store {
   int w_rgb, h_rgb, w_d, h_d, capacity;
   std::vector<std::vector<uint8_t>> rgba;
   std::vector<std::vector<int16_t>> depth;
+  // optional: the visible list of each keyframe's fusion, with the block position every entry held
+  bool lists_enabled = false;
+  std::vector<std::vector<int32_t>> list_ids;
+  std::vector<std::vector<S4>> list_pos;
+  std::vector<uint8_t> has_list;
 };
 extern "C" int oracle_frame_store_create(oracle_engine *, int w_rgb, int h_rgb, int w_d, int h_d, int capacity, oracle_frame_store **out) {
   if (capacity <= 0 || w_rgb <= 0 || h_rgb <= 0 || w_d <= 0 || h_d <= 0) return DSLAM_ERR_INVALID;
-  oracle_frame_store *fs = new oracle_frame_store{w_rgb, h_rgb, w_d, h_d, capacity, {}, {}};
+  oracle_frame_store *fs = new oracle_frame_store();
+  fs->w_rgb = w_rgb; fs->h_rgb = h_rgb; fs->w_d = w_d; fs->h_d = h_d; fs->capacity = capacity;
   fs->rgba.assign(capacity, std::vector<uint8_t>((size_t)w_rgb * h_rgb * 4, 0));
   fs->depth.assign(capacity, std::vector<int16_t>((size_t)w_d * h_d, 0));
   *out = fs;
@@ -1187,6 +1193,48 @@ extern "C" int oracle_deprocess_frame(oracle_engine *e, oracle_scene *s, const o
                            const float *M_d, const float *intr_d, const float *M_rgb, const float *intr_rgb) {
   oracle_allocate_scene_from_depth(e, s, v, r, M_d, intr_d, 1);
   integrate_impl<true>(e, s, v, r, M_d, intr_d, M_rgb, intr_rgb);
+  return 0;
+}
+
+// The blocks a keyframe was fused into, kept with it (same contract as dslam_frame_store_enable_lists /
+// dslam_frame_store_put_visible_list / dslam_deprocess_frame_stored): de-integration visits exactly the listed entries
+// that still hold the block they held at fusion time, and leaves the render state alone.
+extern "C" int oracle_frame_store_enable_lists(oracle_engine *, oracle_frame_store *fs, const oracle_scene *) {
+  if (!fs->lists_enabled) {
+    fs->list_ids.assign(fs->capacity, {});
+    fs->list_pos.assign(fs->capacity, {});
+    fs->has_list.assign(fs->capacity, 0);
+    fs->lists_enabled = true;
+  }
+  return 0;
+}
+extern "C" int oracle_frame_store_put_visible_list(oracle_engine *, oracle_frame_store *fs, int slot, const oracle_scene *s,
+                                                   const oracle_render_state *r) {
+  if (!fs->lists_enabled || slot < 0 || slot >= fs->capacity) return DSLAM_ERR_INVALID;
+  fs->list_ids[slot].assign(r->visible_ids.begin(), r->visible_ids.begin() + r->no_visible);
+  fs->list_pos[slot].resize(r->no_visible);
+  for (int i = 0; i < r->no_visible; i++) {
+    const dslam_hash_entry &he = s->hash[r->visible_ids[i]];
+    fs->list_pos[slot][i] = S4{he.pos[0], he.pos[1], he.pos[2], 0};
+  }
+  fs->has_list[slot] = 1;
+  return 0;
+}
+extern "C" int oracle_deprocess_frame_stored(oracle_engine *e, oracle_scene *s, const oracle_view *v, const oracle_frame_store *fs,
+                                             int slot, const float *M_d, const float *intr_d, const float *M_rgb,
+                                             const float *intr_rgb) {
+  if (!fs->lists_enabled || slot < 0 || slot >= fs->capacity || !fs->has_list[slot]) return DSLAM_ERR_INVALID;
+  oracle_render_state tmp;
+  tmp.no_visible = 0;
+  for (size_t i = 0; i < fs->list_ids[slot].size(); i++) {
+    const int t = fs->list_ids[slot][i];
+    const dslam_hash_entry &he = s->hash[t];
+    const S4 &ep = fs->list_pos[slot][i];
+    if (he.pos[0] != ep.x || he.pos[1] != ep.y || he.pos[2] != ep.z) continue;  // the entry holds another block now
+    tmp.visible_ids.push_back(t);
+    tmp.no_visible++;
+  }
+  integrate_impl<true>(e, s, v, &tmp, M_d, intr_d, M_rgb, intr_rgb);
   return 0;
 }
 

@@ -98,3 +98,51 @@ def degenerate_pose_scenario(api, pkg, wl, params):
     api.integrate_into_scene(scene, view, rs, M, wl.intr, M_rgb=np.zeros((4, 4), np.float32), intr_rgb=wl.intr)
     after_nan_rgb = api.download_voxel_blocks(scene)
     return base, after_denormal, after_nan_rgb
+
+
+def stored_list_scenario(api, pkg, synth, wl, params, maintenance):
+    """DenseSlam's keyframe database with each keyframe's fusion-time visible list kept next to its images
+    (dslam_frame_store_put_visible_list), then an OnlineCorrection-style batch (reference DenseSlam.cpp:390-403) whose
+    de-integrations use the stored lists (dslam_deprocess_frame_stored).  Returns the states along the way."""
+    n_frames = 10
+    scene = api.create_scene(params)
+    rs, view = api.create_render_state(scene, wl.W, wl.H), api.create_view(wl.W, wl.H)
+    store = api.create_frame_store(wl.W, wl.H, n_frames)
+    api.frame_store_enable_lists(store, scene)
+    poses = {}
+    out = {}
+    for i in range(n_frames):
+        rgba, mm, M = wl.frame(i)
+        api.view_update(view, rgba, mm, timestamp=float(i))
+        api.frame_store_put_view(store, i, view)
+        api.process_frame(scene, view, rs, M, wl.intr)
+        api.frame_store_put_visible_list(store, i, scene, rs)
+        poses[i] = M
+        if maintenance:
+            if api.stats(scene, rs)["fusion_fifo_len"] > 4:
+                api.slide_window(scene, rs, 4)
+            api.decay(scene, rs, 1, 2, True)
+    out["fused"] = full_state(api, scene, rs)
+    rs_before = (api.download_visible_ids(rs), api.download_visible_types(rs))
+    for n, i in enumerate((7, 9, 8, 2)):  # (keyframe 2 has left the window when `maintenance`: most of its blocks are gone)
+        new_M = synth.world_to_camera(wl.pose(i) @ synth.pose_matrix(synth.look_rotation(0.003 * (n + 1), -0.002), [0.004, 0.001 * n, -0.003]))
+        api.view_update_from_store(view, store, i, timestamp=float(i))
+        api.deprocess_frame_stored(scene, view, store, i, poses[i], wl.intr)
+        if n == 0:  # the stored-list de-integration leaves the render state alone
+            out["rs_untouched"] = (np.array_equal(api.download_visible_ids(rs), rs_before[0]) and
+                                   np.array_equal(api.download_visible_types(rs), rs_before[1]))
+            out["after_first_deintegration"] = full_state(api, scene, rs)
+        api.process_frame(scene, view, rs, new_M, wl.intr, is_defusion=True)
+        api.frame_store_put_visible_list(store, i, scene, rs)  # the keyframe now lives in the blocks of its re-fusion
+        poses[i] = new_M
+    out["corrected"] = full_state(api, scene, rs)
+    # a keyframe that was never given a list cannot be de-integrated this way
+    store2 = api.create_frame_store(wl.W, wl.H, 2)
+    api.frame_store_enable_lists(store2, scene)
+    api.frame_store_put_view(store2, 0, view)
+    try:
+        api.deprocess_frame_stored(scene, view, store2, 0, poses[0], wl.intr)
+        out["missing_list_refused"] = False
+    except pkg.DslamError:
+        out["missing_list_refused"] = True
+    return out

@@ -146,3 +146,17 @@ def test_visible_list_replaced_between_allocation_passes(pkg, synth, gpu, oracle
             snaps[name] = util.snapshot(api, s, rs)
         util.assert_same_state(snaps["gpu"], snaps["oracle"], f"frame {i}")
     assert len(snaps["gpu"]["visible_ids"]) > 200
+
+
+@pytest.mark.parametrize("maintenance", [False, True])
+def test_stored_visible_list_deintegration_parity(pkg, synth, gpu, oracle, maintenance):
+    """dslam_frame_store_put_visible_list / dslam_deprocess_frame_stored against the oracle: an OnlineCorrection-style
+    batch whose de-integrations go straight to the integration kernel with the keyframe's own block list (entries that
+    hold another block by now are skipped), on a plain map and on a decayed + slid one."""
+    wl = synth.s_tiny()
+    p = util.small_params(pkg, wl)
+    g = scenarios.stored_list_scenario(gpu, pkg, synth, wl, p, maintenance)
+    o = scenarios.stored_list_scenario(oracle, pkg, synth, wl, p, maintenance)
+    for stage in ("fused", "after_first_deintegration", "corrected"):
+        scenarios.assert_same_full_state(g[stage], o[stage], f"{stage} (maintenance={maintenance})")
+    assert g["rs_untouched"] and g["missing_list_refused"]

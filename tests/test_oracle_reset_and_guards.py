@@ -75,3 +75,39 @@ def test_weight_params_are_validated(pkg, oracle):
         with pytest.raises(pkg.DslamError):
             oracle.set_fusion_weight_params(*bad)
     oracle.set_fusion_weight_params(False, 1, 1.0)
+
+
+def test_deintegration_from_the_stored_visible_list(pkg, synth, oracle):
+    """dslam_deprocess_frame_stored: fuse a keyframe into an empty map, keep its visible list, de-integrate from the list
+    -> empty map again, without an allocation pass and without touching the render state."""
+    wl = synth.s_tiny()
+    p = util.small_params(pkg, wl)
+    s = oracle.create_scene(p)
+    rs, v = oracle.create_render_state(s, wl.W, wl.H), oracle.create_view(wl.W, wl.H)
+    store = oracle.create_frame_store(wl.W, wl.H, 2)
+    oracle.frame_store_enable_lists(store, s)
+    rgba, mm, M = wl.frame(0)
+    oracle.view_update(v, rgba, mm)
+    oracle.process_frame(s, v, rs, M, wl.intr)
+    oracle.frame_store_put_visible_list(store, 0, s, rs)
+    ids = oracle.download_visible_ids(rs)
+    assert (oracle.download_voxel_blocks(s)["w_depth"] > 0).sum() > 10000
+    oracle.deprocess_frame_stored(s, v, store, 0, M, wl.intr)
+    vox = oracle.download_voxel_blocks(s)
+    assert (vox["w_depth"] == 0).all() and (vox["sdf"] == 32767).all() and (vox["w_color"] == 0).all()
+    assert np.array_equal(oracle.download_visible_ids(rs), ids)
+
+
+@pytest.mark.parametrize("maintenance", [False, True])
+def test_stored_list_correction_batch(pkg, synth, oracle, maintenance):
+    wl = synth.s_tiny()
+    p = util.small_params(pkg, wl)
+    out = scenarios.stored_list_scenario(oracle, pkg, synth, wl, p, maintenance)
+    assert out["rs_untouched"] and out["missing_list_refused"]
+    a, b, c = out["fused"]["voxels"], out["after_first_deintegration"]["voxels"], out["corrected"]["voxels"]
+    n1 = int((a.view(np.uint64) != b.view(np.uint64)).any(axis=1).sum())
+    n2 = int((a.view(np.uint64) != c.view(np.uint64)).any(axis=1).sum())
+    assert n1 > 100 and n2 > 100
+    # de-integration only ever lowers weights
+    assert (b["w_depth"].astype(int) <= a["w_depth"].astype(int)).all()
+    util.check_invariants(out["corrected"], p)
