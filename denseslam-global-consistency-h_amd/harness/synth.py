@@ -129,8 +129,11 @@ class Workload:
     """A named scene + camera + trajectory + ITMSceneParams.  frame(i) -> (rgba, depth_mm, M_d)."""
 
     def __init__(self, name, W, H, intr, prims, traj, scene_kwargs, kitti_depth=False, max_depth=None,
-                 cull_z=None):
+                 cull_z=None, stereo_noise_px=0.0, stereo_baseline_m=0.54, outlier_frac=0.0):
         self.name, self.W, self.H = name, W, H
+        # stereo-matching noise: the depth a KITTI pipeline hands over comes from a disparity d = fx * b / z that is
+        # wrong by a fraction of a pixel (sigma_z grows with z^2) and, for a few pixels, wrong altogether
+        self.stereo_noise_px, self.stereo_baseline_m, self.outlier_frac = stereo_noise_px, stereo_baseline_m, outlier_frac
         self.cull_z = cull_z  # (behind, ahead) metres along world z: only nearby primitives are ray-cast
         self.intr = np.asarray(intr, np.float32)
         self.prims, self.traj, self.scene_kwargs = prims, traj, scene_kwargs
@@ -146,6 +149,15 @@ class Workload:
             cz = T_wc[2, 3]
             prims = [p for p in prims if p.hi[2] >= cz - self.cull_z[0] and p.lo[2] <= cz + self.cull_z[1]]
         z, rgba = render(prims, self.intr.astype(np.float64), self.W, self.H, T_wc)
+        if self.stereo_noise_px > 0.0 or self.outlier_frac > 0.0:
+            rng = np.random.RandomState(1234 + 7919 * i)  # per frame, the same on every machine
+            fb = float(self.intr[0]) * self.stereo_baseline_m
+            with np.errstate(divide="ignore", invalid="ignore"):
+                disp = fb / z + self.stereo_noise_px * rng.standard_normal(z.shape)
+                if self.outlier_frac > 0.0:  # mismatches: a disparity from anywhere in the search range
+                    bad = rng.random_sample(z.shape) < self.outlier_frac
+                    disp = np.where(bad, rng.uniform(fb / 40.0, fb / 2.0, z.shape), disp)
+                z = np.where(np.isfinite(z) & (disp > 0), fb / disp, np.inf)
         if self.kitti_depth:
             mm = depth_to_mm_kitti(z, self.max_depth or 40.0)
         else:
@@ -169,7 +181,7 @@ def s_room(W=640, H=480, scale=1.0):
                     dict(voxel_size=0.005 * scale, mu=0.02 * scale, max_w=100, frustum_min=0.2, frustum_max=3.0))
 
 
-def s_street(W=640, H=480, n_cars=20, loop_at=None):
+def s_street(W=640, H=480, n_cars=20, loop_at=None, stereo_noise_px=0.0, outlier_frac=0.0):
     """KITTI-like street (BASELINE configs 1, 2, 4 stand-in): ground plane 1.65 m below the camera, two
     facades at x = +-8 m with 3 m-period relief, parked-car boxes; camera drives forward 1 m/frame with a
     slow yaw.  5 cm voxels, mu 0.2 m, frustum 0.5-40 m (the fork's own defaults are not knowable; these give
@@ -201,7 +213,7 @@ def s_street(W=640, H=480, n_cars=20, loop_at=None):
 
     return Workload("S-street", W, H, intr, prims, traj,
                     dict(voxel_size=0.05, mu=0.2, max_w=100, frustum_min=0.5, frustum_max=40.0), kitti_depth=True,
-                    max_depth=40.0, cull_z=(5.0, 48.0))
+                    max_depth=40.0, cull_z=(5.0, 48.0), stereo_noise_px=stereo_noise_px, outlier_frac=outlier_frac)
 
 
 def s_tiny(W=64, H=48):
