@@ -92,6 +92,7 @@ int ensure_scratch(dslam_engine *e, int entries, int local_blocks) {
   free_dev(e->order_keys); free_dev(e->alloc_type); free_dev(e->block_coords); free_dev(e->tile_counts); free_dev(e->tile_offsets);
   free_dev(e->list_a); free_dev(e->list_b); free_dev(e->list_c); free_dev(e->list_d); free_dev(e->pos_scratch);
   free_dev(e->req_list); free_dev(e->req_count); free_dev(e->agg);
+  free_dev(e->rem_flags); free_dev(e->freed_flags); free_dev(e->rem_cand); free_dev(e->maint_flags);
   // order keys and allocType: cleared here once, kept clean by the allocation passes (scenes of different sizes share
   // them, so both start at fixed addresses: a pass only ever touches [0, its entry count) of each)
   DSLAM_HIP(hipMalloc(&e->order_keys, (size_t)N * 4));
@@ -102,7 +103,7 @@ int ensure_scratch(dslam_engine *e, int entries, int local_blocks) {
   DSLAM_HIP(hipMalloc(&e->req_list, (size_t)N * sizeof(int)));
   DSLAM_HIP(hipMalloc(&e->req_count, sizeof(int)));
   DSLAM_HIP(hipMemsetAsync(e->req_count, 0, sizeof(int), e->stream));
-  const int tiles = num_tiles(N);
+  const int tiles = num_tiles(N > L ? N : L);
   DSLAM_HIP(hipMalloc(&e->agg, (size_t)tiles * 3 * sizeof(unsigned long long)));
   DSLAM_HIP(hipMemsetAsync(e->agg, 0, (size_t)tiles * 3 * sizeof(unsigned long long), e->stream));
   e->agg_tiles = tiles;
@@ -114,6 +115,14 @@ int ensure_scratch(dslam_engine *e, int entries, int local_blocks) {
   DSLAM_HIP(hipMalloc(&e->list_c, list_len * sizeof(int)));
   DSLAM_HIP(hipMalloc(&e->list_d, list_len * sizeof(int)));
   DSLAM_HIP(hipMalloc(&e->pos_scratch, (size_t)L * sizeof(short4)));
+  DSLAM_HIP(hipMalloc(&e->rem_flags, (size_t)N));
+  DSLAM_HIP(hipMalloc(&e->freed_flags, (size_t)N));
+  DSLAM_HIP(hipMalloc(&e->rem_cand, (size_t)L + 16));
+  DSLAM_HIP(hipMalloc(&e->maint_flags, 4 * sizeof(int)));
+  DSLAM_HIP(hipMemsetAsync(e->rem_flags, 0, (size_t)N, e->stream));
+  DSLAM_HIP(hipMemsetAsync(e->freed_flags, 0, (size_t)N, e->stream));
+  DSLAM_HIP(hipMemsetAsync(e->rem_cand, 0, (size_t)L + 16, e->stream));
+  DSLAM_HIP(hipMemsetAsync(e->maint_flags, 0, 4 * sizeof(int), e->stream));
   DSLAM_HIP(hipStreamSynchronize(e->stream));
   e->scratch_entries = N;
   e->scratch_local_blocks = L;
@@ -181,6 +190,7 @@ int dslam_engine_destroy(dslam_engine *e) {
   free_dev(e->order_keys); free_dev(e->alloc_type); free_dev(e->block_coords); free_dev(e->tile_counts); free_dev(e->tile_offsets);
   free_dev(e->list_a); free_dev(e->list_b); free_dev(e->list_c); free_dev(e->list_d); free_dev(e->pos_scratch);
   free_dev(e->req_list); free_dev(e->req_count); free_dev(e->agg);
+  free_dev(e->rem_flags); free_dev(e->freed_flags); free_dev(e->rem_cand); free_dev(e->maint_flags);
   if (e->staging_dev) (void)hipFree(e->staging_dev);
   if (e->staging_host) (void)hipHostFree(e->staging_host);
   if (e->pinned) (void)hipHostFree(e->pinned);

@@ -57,6 +57,12 @@ struct dslam_engine {
   unsigned epoch = 0;
   int sweep_grid_cap = 0;             // workgroups of the sweep kernels that are certainly co-resident on this device
   int *list_d = nullptr;              // [max(local_blocks, entries)] general purpose scratch (bucket leaders, live flags)
+  // release pipeline (decay / sliding window): flags that are ALL ZERO between passes (the kernels that consume a flag
+  // clear it), so no pass starts with a memset
+  unsigned char *rem_flags = nullptr;    // [entries] entry is being released
+  unsigned char *freed_flags = nullptr;  // [entries] excess slot came free
+  unsigned char *rem_cand = nullptr;     // [local_blocks] candidate i of the decay pass lost its last measured voxel
+  int *maint_flags = nullptr;            // device [4]: [0] the pass took something out of a visible list
   int *tile_counts = nullptr;         // [2 * tiles] per-tile counts of the ordered compactions
   int *tile_offsets = nullptr;        // [2 * tiles]
   int *list_a = nullptr;              // [max(local_blocks, entries)] general purpose int lists

@@ -10,11 +10,19 @@
 // index) followed by one-wave-per-block streaming kernels, so results are deterministic and equal to the
 // sequential oracle:
 //   candidates  entries whose block carries the ring bit of the list being decayed / popped (or is old enough)
-//   decay       wave per candidate block: reset voxels with 0 < w <= maxWeight, wave-ballot "any measured voxel left"
-//   release     removal list (ascending entry index): reset block, push slot r-th onto the free stack, clear rings
+//   decay       wave per candidate block: reset voxels with 0 < w <= maxWeight, wave-ballot "any measured voxel left";
+//               the removal list is compacted from the CANDIDATE list (a few hundred to a few thousand items), not from
+//               the table
+//   release     removal list (ascending entry index): reset block, push slot r-th onto the free stack, clear rings;
+//               the same launch finds, for every removal, whether it is the first one of its bucket chain
 //   unlink      one lane per affected bucket rewrites the chain once (survivors keep order, first survivor moves
-//               into a released head); freed excess slots are flagged and pushed in ascending slot order
-//   rebuild     visible list of the render state from visibleType (ordered compaction)
+//               into a released head); freed excess slots are flagged
+//   push        the freed excess slots go back in ascending slot order (single-pass ordered compaction with in-launch
+//               look-back), the same launch folds the pass into the pool counters
+//   rebuild     visible list of the render state from visibleType -- only if the pass took an entry out of it
+// Every flag array of this pipeline is all zero between passes: the kernel that consumes a flag clears it, so no pass
+// starts with a memset.  Round 1 spent 16 (decay) + 13 (window pop) launches per keyframe on this path; now 8 + 6, all of
+// which return at once when their device-side count is zero.
 #include "dslam_internal.h"
 
 #pragma clang fp contract(off)
@@ -74,7 +82,8 @@ __global__ __launch_bounds__(256) void k_select(const HashEntry *__restrict__ ha
 // ---- decay: one wavefront per candidate block ---------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_decay_blocks(const int *__restrict__ cand, const int *count_ptr,
                                                       const HashEntry *__restrict__ hash, uint4 *voxels16,
-                                                      int max_weight, unsigned char *remove_flags, int mark_empty) {
+                                                      int max_weight, unsigned char *remove_flags,
+                                                      unsigned char *remove_cand, int mark_empty) {
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane((int)((blockIdx.x * 256 + threadIdx.x) >> 6));
   const int n_waves = gridDim.x * 4;
@@ -95,41 +104,83 @@ __global__ __launch_bounds__(256) void k_decay_blocks(const int *__restrict__ ca
       if (ch) blk[j * 64 + lane] = v;
     }
     const bool any = __ballot(measured) != 0ull;
-    if (!any && mark_empty && lane == 0) remove_flags[t] = 1;
+    if (!any && mark_empty && lane == 0) { remove_flags[t] = 1; remove_cand[i] = 1; }
   }
 }
 
-// ---- release: removal list -> pool -----------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_release_blocks(const int *__restrict__ rem, const SceneCounters *cnt,
-                                                        const HashEntry *__restrict__ hash, uint4 *voxels16,
-                                                        int *alloc_list, unsigned long long *masks, int *last_seen,
-                                                        int words) {
-  const int lane = threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane((int)((blockIdx.x * 256 + threadIdx.x) >> 6));
-  const int n_waves = gridDim.x * 4;
-  const int n = cnt->remove_count;
-  const int base = cnt->last_free;
-  const uint4 empty2 = make_uint4(kEmptyVoxelLo, kEmptyVoxelHi, kEmptyVoxelLo, kEmptyVoxelHi);
-  for (int r = wave; r < n; r += n_waves) {
-    const int ptr = hash[rem[r]].ptr;
-    uint4 *blk = voxels16 + (size_t)ptr * (kBlock3 / 2);
+// ---- removal list of a decay pass: ordered compaction over the CANDIDATE list -----------------------------------------
+// cand[0..n) ascending in entry index; flag[i] = 1 for the candidates to release.  One launch: tiles of kSweepTile
+// candidates, counts exchanged in-launch (dslam_device.h look-back).  The grid covers the largest possible list; tiles
+// past the end publish zero and leave.  Consumes (clears) the flags.
+__global__ __launch_bounds__(256) void k_compact_candidates(const int *__restrict__ cand, const int *count_ptr,
+                                                            unsigned char *flag, int *__restrict__ out, int *total_out,
+                                                            unsigned long long *agg, unsigned epoch, int n_tiles) {
+  __shared__ int red[8];
+  const int n = *count_ptr;
+  for (int b = blockIdx.x; b < n_tiles; b += gridDim.x) {
+    const int i0 = b * kSweepTile + threadIdx.x * kSweepPer;
+    unsigned m = 0;
+    if (i0 < n) {
 #pragma unroll
-    for (int j = 0; j < 4; j++) blk[j * 64 + lane] = empty2;
-    if (lane < 2 * words) masks[(size_t)ptr * 2 * words + lane] = 0ull;
-    if (lane == 0) {
-      alloc_list[base + 1 + r] = ptr;
-      last_seen[ptr] = -1;
+      for (int q = 0; q < kSweepPer / 4; q++) {
+        if (i0 + q * 4 >= n) break;  // (the flag array is a multiple of 16 long)
+        const unsigned w = *reinterpret_cast<const unsigned *>(flag + i0 + q * 4);
+        if (w) {
+          *reinterpret_cast<unsigned *>(flag + i0 + q * 4) = 0u;
+          for (int k = 0; k < 4; k++)
+            if ((w >> (8 * k)) & 0xffu) m |= 1u << (q * 4 + k);
+        }
+      }
+    }
+    int tot;
+    int r = block_excl_scan<4>(__popc(m), red, tot);
+    if (threadIdx.x == 0) publish(agg, b, epoch, tot >> 12, tot & 0xfff);
+    const bool last = b == n_tiles - 1;
+    if (tot > 0 || last) {
+      int hi, lo;
+      lookback(agg, b, epoch, red, hi, lo);
+      const int offset = hi * 4096 + lo;
+      if (last && threadIdx.x == 0) *total_out = offset + tot;
+      r += offset;
+      for (; m; m &= m - 1) out[r++] = cand[i0 + __ffs((int)m) - 1];
     }
   }
 }
 
-// one lane per removal: am I the first released entry of my bucket chain (chain still unmodified)?
-__global__ __launch_bounds__(256) void k_find_leaders(const int *__restrict__ rem, const SceneCounters *cnt,
-                                                      const HashEntry *__restrict__ hash, int num_buckets,
-                                                      unsigned mask, const unsigned char *__restrict__ remove_flags,
-                                                      int *__restrict__ leader_bucket) {
+// ---- release: removal list -> pool; and the first removal of every affected bucket chain ------------------------------
+// Two independent jobs in one launch: workgroups [0, kReleaseWgs) stream the released blocks (reset, slot back to the
+// pool, rings cleared), the others decide for every removal whether it is the first released entry of its chain (the
+// chain is still unmodified): those lead the rewrite in k_unlink.
+constexpr int kReleaseWgs = 1024, kLeaderWgs = 64;
+
+__global__ __launch_bounds__(256) void k_release_and_leaders(const int *__restrict__ rem, const SceneCounters *cnt,
+                                                             const HashEntry *__restrict__ hash, uint4 *voxels16,
+                                                             int *alloc_list, unsigned long long *masks, int *last_seen,
+                                                             int words, int num_buckets, unsigned mask,
+                                                             const unsigned char *__restrict__ remove_flags,
+                                                             int *__restrict__ leader_bucket) {
   const int n = cnt->remove_count;
-  for (int r = blockIdx.x * blockDim.x + threadIdx.x; r < n; r += gridDim.x * blockDim.x) {
+  if (n == 0) return;
+  if (blockIdx.x < kReleaseWgs) {
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)((blockIdx.x * 256 + threadIdx.x) >> 6));
+    const int n_waves = kReleaseWgs * 4;
+    const int base = cnt->last_free;
+    const uint4 empty2 = make_uint4(kEmptyVoxelLo, kEmptyVoxelHi, kEmptyVoxelLo, kEmptyVoxelHi);
+    for (int r = wave; r < n; r += n_waves) {
+      const int ptr = hash[rem[r]].ptr;
+      uint4 *blk = voxels16 + (size_t)ptr * (kBlock3 / 2);
+#pragma unroll
+      for (int j = 0; j < 4; j++) blk[j * 64 + lane] = empty2;
+      if (lane < 2 * words) masks[(size_t)ptr * 2 * words + lane] = 0ull;
+      if (lane == 0) {
+        alloc_list[base + 1 + r] = ptr;
+        last_seen[ptr] = -1;
+      }
+    }
+    return;
+  }
+  for (int r = (blockIdx.x - kReleaseWgs) * 256 + threadIdx.x; r < n; r += kLeaderWgs * 256) {
     const int t = rem[r];
     int bucket = t;
     if (t >= num_buckets) {
@@ -146,12 +197,12 @@ __global__ __launch_bounds__(256) void k_find_leaders(const int *__restrict__ re
   }
 }
 
-// leaders rewrite their bucket chain once (DESIGN.md "batch release")
+// leaders rewrite their bucket chain once (DESIGN.md "batch release"); consumes (clears) the removal flags
 __global__ __launch_bounds__(256) void k_unlink(const int *__restrict__ leader_bucket, const SceneCounters *cnt,
-                                                HashEntry *hash, int num_buckets,
-                                                const unsigned char *__restrict__ remove_flags,
-                                                unsigned char *freed_flags, unsigned char *vis_type) {
+                                                HashEntry *hash, int num_buckets, unsigned char *remove_flags,
+                                                unsigned char *freed_flags, unsigned char *vis_type, int *maint_flags) {
   const int n = cnt->remove_count;
+  bool touched_visible = false;
   for (int r = blockIdx.x * blockDim.x + threadIdx.x; r < n; r += gridDim.x * blockDim.x) {
     const int head = leader_bucket[r];
     if (head < 0) continue;
@@ -160,15 +211,16 @@ __global__ __launch_bounds__(256) void k_unlink(const int *__restrict__ leader_b
       const HashEntry e = load_entry(hash, c);
       const int next = (e.offset >= 1) ? num_buckets + e.offset - 1 : -1;
       if (remove_flags[c]) {
+        remove_flags[c] = 0;
         if (c != head) freed_flags[c - num_buckets] = 1;
         store_entry(hash, c, 0, 0, 0, 0, -2);
-        if (vis_type) vis_type[c] = 0;
+        if (vis_type) { touched_visible |= vis_type[c] != 0; vis_type[c] = 0; }
       } else {
         int cur = c;
         if (prev == -1) {
           if (c != head) {  // first survivor moves into the released bucket head
             store_entry(hash, head, e.pos[0], e.pos[1], e.pos[2], e.offset, e.ptr);
-            if (vis_type) { vis_type[head] = vis_type[c]; vis_type[c] = 0; }
+            if (vis_type) { touched_visible |= vis_type[c] != 0; vis_type[head] = vis_type[c]; vis_type[c] = 0; }
             store_entry(hash, c, 0, 0, 0, 0, -2);
             freed_flags[c - num_buckets] = 1;
             cur = head;
@@ -182,59 +234,131 @@ __global__ __launch_bounds__(256) void k_unlink(const int *__restrict__ leader_b
     }
     if (prev >= 0) hash[prev].offset = 0;
   }
+  if (__ballot(touched_visible) && (threadIdx.x & 63) == 0) maint_flags[0] = 1;  // (a visible list has to be rebuilt)
 }
 
-// push freed excess slots in ascending slot order
-__global__ __launch_bounds__(256) void k_push_freed(const unsigned char *__restrict__ freed_flags, int n_excess,
-                                                    const int *__restrict__ tile_offsets, int *excess_list,
-                                                    const SceneCounters *cnt) {
-  __shared__ int red[4];
-  const int t0 = blockIdx.x * kTileEntries + threadIdx.x * 4;
-  unsigned char f[4] = {0, 0, 0, 0};
-  if (t0 < n_excess) {
-    const uchar4 v = *reinterpret_cast<const uchar4 *>(freed_flags + t0);
-    f[0] = v.x; f[1] = v.y; f[2] = v.z; f[3] = v.w;
-  }
-  const int c = (f[0] > 0) + (f[1] > 0) + (f[2] > 0) + (f[3] > 0);
-  int tot;
-  int r = block_excl_scan<4>(c, red, tot);
-  if (tot == 0) return;
-  r += tile_offsets[blockIdx.x] + cnt->last_free_ex + 1;
+// Freed excess slots back onto the excess free list in ascending slot order (single-pass ordered compaction: tile counts
+// exchanged in-launch), flags consumed; the last tile folds the whole removal pass into the pool counters.
+__global__ __launch_bounds__(256) void k_push_freed_finalize(unsigned char *freed_flags, int n_excess, int *excess_list,
+                                                             SceneCounters *cnt, int count_as_slid, unsigned long long *agg,
+                                                             unsigned epoch, int n_tiles) {
+  __shared__ int red[8];
+  const int removed = cnt->remove_count;
+  if (removed == 0) return;  // (nothing was released, so no slot came free and no flag is set)
+  const int base_ex = cnt->last_free_ex;  // (only the last tile, after everything else, changes it)
+  for (int b = blockIdx.x; b < n_tiles; b += gridDim.x) {
+    const int i0 = b * kSweepTile + threadIdx.x * kSweepPer;
+    unsigned m = 0;
+    if (i0 < n_excess) {
 #pragma unroll
-  for (int k = 0; k < 4; k++)
-    if (f[k] > 0) excess_list[r++] = t0 + k;
+      for (int q = 0; q < kSweepPer / 4; q++) {
+        if (i0 + q * 4 >= n_excess) break;
+        const unsigned w = *reinterpret_cast<const unsigned *>(freed_flags + i0 + q * 4);
+        if (w) {
+          *reinterpret_cast<unsigned *>(freed_flags + i0 + q * 4) = 0u;
+          for (int k = 0; k < 4; k++)
+            if (((w >> (8 * k)) & 0xffu) && i0 + q * 4 + k < n_excess) m |= 1u << (q * 4 + k);
+        }
+      }
+    }
+    int tot;
+    int r = block_excl_scan<4>(__popc(m), red, tot);
+    if (threadIdx.x == 0) publish(agg, b, epoch, tot >> 12, tot & 0xfff);
+    const bool last = b == n_tiles - 1;
+    if (tot > 0 || last) {
+      int hi, lo;
+      lookback(agg, b, epoch, red, hi, lo);
+      const int offset = hi * 4096 + lo;
+      r += offset + base_ex + 1;
+      for (; m; m &= m - 1) excess_list[r++] = i0 + __ffs((int)m) - 1;
+      if (last) {
+        // every other tile's pushes target slots above the old top and do not read the counters again
+        __syncthreads();
+        if (threadIdx.x == 0) {
+          cnt->last_free += removed;
+          cnt->last_free_ex = base_ex + offset + tot;
+          if (count_as_slid) cnt->slid_blocks += removed; else cnt->decayed_blocks += removed;
+          cnt->remove_count = 0;
+          cnt->freed_excess = 0;
+        }
+      }
+    }
+  }
 }
 
-__global__ void k_finalize_removal(SceneCounters *cnt, int count_as_slid) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
-  const int n = cnt->remove_count;
-  cnt->last_free += n;
-  cnt->last_free_ex += cnt->freed_excess;
-  if (count_as_slid) cnt->slid_blocks += n; else cnt->decayed_blocks += n;
-  cnt->remove_count = 0;
-  cnt->freed_excess = 0;
+// rebuild of a render state's visible list from its types, only when the pass took an entry out of it: single-pass
+// ordered compaction over the type bytes (4096-entry tiles)
+__global__ __launch_bounds__(256) void k_rebuild_visible(const unsigned char *__restrict__ vis_type, int n_entries, int *ids,
+                                                         int capacity, RenderCounters *rc, int *maint_flags,
+                                                         unsigned long long *agg, unsigned epoch, int n_tiles) {
+  __shared__ int red[8];
+  if (maint_flags[0] == 0) return;
+  for (int b = blockIdx.x; b < n_tiles; b += gridDim.x) {
+    const int t0 = b * kSweepTile + threadIdx.x * kSweepPer;
+    unsigned m = 0;
+    if (t0 < n_entries) {
+#pragma unroll
+      for (int q = 0; q < kSweepPer / 4; q++) {
+        const unsigned w = *reinterpret_cast<const unsigned *>(vis_type + t0 + q * 4);
+        for (int k = 0; k < 4; k++)
+          if ((w >> (8 * k)) & 0xffu) m |= 1u << (q * 4 + k);
+      }
+    }
+    int tot;
+    int r = block_excl_scan<4>(__popc(m), red, tot);
+    if (threadIdx.x == 0) publish(agg, b, epoch, tot >> 12, tot & 0xfff);
+    const bool last = b == n_tiles - 1;
+    if (tot > 0 || last) {
+      int hi, lo;
+      lookback(agg, b, epoch, red, hi, lo);
+      const int offset = hi * 4096 + lo;
+      if (last && threadIdx.x == 0) {
+        rc->no_visible = (offset + tot) < capacity ? (offset + tot) : capacity;
+        // every other tile has read the flag by now (the last tile has just seen all their counts): re-arm it
+        maint_flags[0] = 0;
+      }
+      r += offset;
+      for (; m; m &= m - 1) {
+        if (r < capacity) ids[r] = t0 + __ffs((int)m) - 1;
+        r++;
+      }
+    }
+  }
 }
 
-// scratch carving (engine->list_c holds >= 4*N bytes): candidate flags, removal flags, freed-excess flags
+// scratch: candidate flags (table sized, overwritten whole by every selection), the lists
 struct MaintScratch {
-  unsigned char *cand_flags, *rem_flags, *freed_flags;
+  unsigned char *cand_flags, *rem_flags, *freed_flags, *rem_cand;
   int *cand_list, *rem_list, *leaders;
 };
 static MaintScratch carve(dslam_engine *e, int N) {
   MaintScratch m;
-  unsigned char *b = reinterpret_cast<unsigned char *>(e->list_c);
-  m.cand_flags = b;
-  m.rem_flags = b + N;
-  m.freed_flags = b + 2 * (size_t)N;
+  m.cand_flags = reinterpret_cast<unsigned char *>(e->list_c);
+  m.rem_flags = e->rem_flags;
+  m.freed_flags = e->freed_flags;
+  m.rem_cand = e->rem_cand;
   m.cand_list = e->list_a;
   m.rem_list = e->list_b;
   m.leaders = e->list_d;
+  (void)N;
   return m;
 }
 
+static unsigned next_epoch(dslam_engine *e) {
+  if (++e->epoch == 0) e->epoch = 1;
+  return e->epoch;
+}
+
+// grid of the single-pass compaction kernels: all tiles resident together (they wait for each other's counts); tiles
+// are taken in ascending order, so fewer workgroups than tiles is fine as well
+static int lookback_grid(dslam_engine *e, int n_tiles) {
+  const int cap = (e->sm_count > 0 ? e->sm_count : 1) * 2;
+  return n_tiles < cap ? (n_tiles > 0 ? n_tiles : 1) : cap;
+}
+
 static int rebuild_visible_list(dslam_engine *e, dslam_render_state *r) {
+  // (the swapping paths call this directly after they have changed types themselves)
   const int N = r->n_entries, n_tiles = num_tiles(N);
-  // (each apply workgroup sums the preceding tile counts itself: no scan launch in between)
   hipLaunchKernelGGL(k_flag_count, dim3(n_tiles), dim3(256), 0, e->stream, r->visible_type, N, e->tile_counts);
   hipLaunchKernelGGL(k_compact_apply_fused, dim3(n_tiles), dim3(256), 0, e->stream, r->visible_type, N, e->tile_counts,
                      r->visible_ids, r->n_local, &r->counters->no_visible);
@@ -242,30 +366,23 @@ static int rebuild_visible_list(dslam_engine *e, dslam_render_state *r) {
   return DSLAM_OK;
 }
 
-// removal flags (entry-indexed) -> removal list -> release + unlink + free-list pushes + visible-list rebuild
-static int release_flagged(dslam_engine *e, dslam_scene *s, dslam_render_state *r, const MaintScratch &m,
-                           const unsigned char *rem_flags, int count_as_slid) {
-  const int N = s->n_entries, n_tiles = num_tiles(N);
-  const int x_tiles = num_tiles(s->p.num_excess);
-  hipLaunchKernelGGL(k_flag_count, dim3(n_tiles), dim3(256), 0, e->stream, rem_flags, N, e->tile_counts);
-  hipLaunchKernelGGL(k_compact_apply_fused, dim3(n_tiles), dim3(256), 0, e->stream, rem_flags, N, e->tile_counts, m.rem_list,
-                     s->p.num_local_blocks, &s->counters->remove_count);
-  hipLaunchKernelGGL(k_release_blocks, dim3(1024), dim3(256), 0, e->stream, m.rem_list, s->counters, s->hash,
-                     reinterpret_cast<uint4 *>(s->voxels), s->alloc_list, s->masks, s->last_seen, s->history_words);
-  hipLaunchKernelGGL(k_find_leaders, dim3(256), dim3(256), 0, e->stream, m.rem_list, s->counters, s->hash,
-                     s->p.num_buckets, (unsigned)(s->p.num_buckets - 1), rem_flags, m.leaders);
-  DSLAM_HIP(hipMemsetAsync(m.freed_flags, 0, (size_t)x_tiles * kTileEntries, e->stream));
+// the tail of a removal pass: m.rem_list[0 .. remove_count) (ascending entry index, flags set in m.rem_flags) ->
+// release + leaders, unlink, free-list pushes + counters, visible-list rebuild if a visible entry went
+static int release_listed(dslam_engine *e, dslam_scene *s, dslam_render_state *r, const MaintScratch &m, int count_as_slid) {
+  hipLaunchKernelGGL(k_release_and_leaders, dim3(kReleaseWgs + kLeaderWgs), dim3(256), 0, e->stream, m.rem_list, s->counters,
+                     s->hash, reinterpret_cast<uint4 *>(s->voxels), s->alloc_list, s->masks, s->last_seen, s->history_words,
+                     s->p.num_buckets, (unsigned)(s->p.num_buckets - 1), m.rem_flags, m.leaders);
   hipLaunchKernelGGL(k_unlink, dim3(256), dim3(256), 0, e->stream, m.leaders, s->counters, s->hash, s->p.num_buckets,
-                     rem_flags, m.freed_flags, r ? r->visible_type : (unsigned char *)nullptr);
-  hipLaunchKernelGGL(k_flag_count, dim3(x_tiles), dim3(256), 0, e->stream, m.freed_flags, s->p.num_excess,
-                     e->tile_counts);
-  hipLaunchKernelGGL(k_scan_count, dim3(1), dim3(1024), 0, e->stream, e->tile_counts, e->tile_offsets, x_tiles,
-                     &s->counters->freed_excess, s->p.num_excess);
-  hipLaunchKernelGGL(k_push_freed, dim3(x_tiles), dim3(256), 0, e->stream, m.freed_flags, s->p.num_excess,
-                     e->tile_offsets, s->excess_list, s->counters);
-  hipLaunchKernelGGL(k_finalize_removal, dim3(1), dim3(64), 0, e->stream, s->counters, count_as_slid);
+                     m.rem_flags, m.freed_flags, r ? r->visible_type : (unsigned char *)nullptr, e->maint_flags);
+  const int x_tiles = (s->p.num_excess + kSweepTile - 1) / kSweepTile;
+  hipLaunchKernelGGL(k_push_freed_finalize, dim3(lookback_grid(e, x_tiles)), dim3(256), 0, e->stream, m.freed_flags,
+                     s->p.num_excess, s->excess_list, s->counters, count_as_slid, e->agg, next_epoch(e), x_tiles);
+  if (r) {
+    const int v_tiles = (r->n_entries + kSweepTile - 1) / kSweepTile;
+    hipLaunchKernelGGL(k_rebuild_visible, dim3(lookback_grid(e, v_tiles)), dim3(256), 0, e->stream, r->visible_type,
+                       r->n_entries, r->visible_ids, r->n_local, r->counters, e->maint_flags, e->agg, next_epoch(e), v_tiles);
+  }
   DSLAM_HIP(hipGetLastError());
-  if (r) return rebuild_visible_list(e, r);
   return DSLAM_OK;
 }
 
@@ -275,12 +392,14 @@ static int decay_candidates(dslam_engine *e, dslam_scene *s, dslam_render_state 
   const int N = s->n_entries, n_tiles = num_tiles(N);
   hipLaunchKernelGGL(k_compact_apply_fused, dim3(n_tiles), dim3(256), 0, e->stream, m.cand_flags, N, e->tile_counts,
                      m.cand_list, s->p.num_local_blocks, &s->counters->swap_count);  // swap_count doubles as candidate count
-  DSLAM_HIP(hipMemsetAsync(m.rem_flags, 0, N, e->stream));
   hipLaunchKernelGGL(k_decay_blocks, dim3(1024), dim3(256), 0, e->stream, m.cand_list, &s->counters->swap_count, s->hash,
-                     reinterpret_cast<uint4 *>(s->voxels), max_weight, m.rem_flags, s->p.use_swapping ? 0 : 1);
+                     reinterpret_cast<uint4 *>(s->voxels), max_weight, m.rem_flags, m.rem_cand, s->p.use_swapping ? 0 : 1);
   DSLAM_HIP(hipGetLastError());
   if (s->p.use_swapping) return DSLAM_OK;  // entries of a swapping scene are never unlinked (ITMGlobalCache keys)
-  return release_flagged(e, s, r, m, m.rem_flags, 0);
+  const int c_tiles = (s->p.num_local_blocks + kSweepTile - 1) / kSweepTile;
+  hipLaunchKernelGGL(k_compact_candidates, dim3(lookback_grid(e, c_tiles)), dim3(256), 0, e->stream, m.cand_list,
+                     &s->counters->swap_count, m.rem_cand, m.rem_list, &s->counters->remove_count, e->agg, next_epoch(e), c_tiles);
+  return release_listed(e, s, r, m, 0);
 }
 
 int launch_decay(dslam_engine *e, dslam_scene *s, dslam_render_state *r, int max_weight, int min_age, int force_all,
@@ -672,16 +791,23 @@ int launch_slide_pop(dslam_engine *e, dslam_scene *s, dslam_render_state *r, int
   const int bits = 64 * s->history_words;
   const int bit = (s->ring_head[q]++) % bits;
   if (s->decay_cursor[q] < s->ring_head[q]) s->decay_cursor[q] = s->ring_head[q];
-  // rem_flags[t] = 1 for blocks whose rings are empty after clearing this list's bit
+  // leave[t] = 1 for blocks whose rings are empty after clearing this list's bit (the selection writes every entry's
+  // flag).  A scene without swapping releases them: the release pipeline's own flag array (it clears what it consumes);
+  // a scene with swapping parks them on the host and needs the flags for several batches: scratch of its own
+  unsigned char *leave = s->p.use_swapping ? reinterpret_cast<unsigned char *>(e->list_d) : m.rem_flags;
   hipLaunchKernelGGL(k_select<1>, dim3(n_tiles), dim3(256), 0, e->stream, s->hash, N, s->masks, s->history_words, q, bit,
-                     s->last_seen, 0, m.rem_flags, e->tile_counts);
+                     s->last_seen, 0, leave, e->tile_counts);
   DSLAM_HIP(hipGetLastError());
-  if (!s->p.use_swapping) return release_flagged(e, s, r, m, m.rem_flags, 1);
+  if (!s->p.use_swapping) {
+    hipLaunchKernelGGL(k_compact_apply_fused, dim3(n_tiles), dim3(256), 0, e->stream, leave, N, e->tile_counts, m.rem_list,
+                       s->p.num_local_blocks, &s->counters->remove_count);
+    return release_listed(e, s, r, m, 1);
+  }
 
   // scene with swapping: the blocks move to the host store, their entries stay (ptr = -1)
   int total = 0;
   // (1) leaving blocks whose host copy was never merged (state != 2): merge it first
-  hipLaunchKernelGGL(k_slide_split, dim3(n_tiles), dim3(256), 0, e->stream, m.rem_flags, N, s->swap_state, m.cand_flags,
+  hipLaunchKernelGGL(k_slide_split, dim3(n_tiles), dim3(256), 0, e->stream, leave, N, s->swap_state, m.cand_flags,
                      e->tile_counts);
   hipLaunchKernelGGL(k_scan_count, dim3(1), dim3(1024), 0, e->stream, e->tile_counts, e->tile_offsets, n_tiles,
                      &s->counters->swap_count, s->p.num_local_blocks);
@@ -698,10 +824,10 @@ int launch_slide_pop(dslam_engine *e, dslam_scene *s, dslam_render_state *r, int
     // tile scan of cand_flags is unchanged by the merge; keep going
   }
   // (2) pack every leaving block to the host in batches
-  if ((rc = flags_to_host_batches(e, s, m.rem_flags, m, &total))) return rc;
+  if ((rc = flags_to_host_batches(e, s, leave, m, &total))) return rc;
   for (int done = 0; done < total; done += kTransferBlocks) {
     const int n = (total - done) < kTransferBlocks ? (total - done) : kTransferBlocks;
-    if ((rc = batch_ids_to_host(e, s, m.rem_flags, m, done, n))) return rc;
+    if ((rc = batch_ids_to_host(e, s, leave, m, done, n))) return rc;
     if ((rc = pack_to_host(e, s, r ? r->visible_type : nullptr, m, n, 1))) return rc;
   }
   if (r && total > 0) return rebuild_visible_list(e, r);

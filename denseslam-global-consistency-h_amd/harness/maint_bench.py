@@ -195,7 +195,7 @@ def main():
             eng.view_update(view, c, mm, timestamp=float(i))
             eng.process_frame(sc, view, r1, M_i, wl.intr)
             if window:
-                if eng.stats(sc, r1)["fusion_fifo_len"] > 50:
+                if i + 1 > 50:  # mfusionFrameDataBase.size() > max_age (DenseSlam.cpp:215): the caller counts keyframes
                     eng.slide_window(sc, r1, 50)
                 eng.decay(sc, r1, 3, 30, True)
             eng.get_image(sc, r2, M_i, wl.intr, pkg.IMAGE_DEPTH, download=False)
