@@ -25,6 +25,10 @@
 #ifndef DSLAM_PACKED
 #define DSLAM_PACKED 1
 #endif
+// -DDSLAM_COLOUR_QUEUE=0: the colour update inline in every lane's voxel loop (the form the queued one must match; A/B timing)
+#ifndef DSLAM_COLOUR_QUEUE
+#define DSLAM_COLOUR_QUEUE 1
+#endif
 
 namespace dslam {
 
@@ -305,10 +309,30 @@ __device__ __forceinline__ bool fuse_colour(unsigned &lo, unsigned &hi, float u,
   return true;
 }
 
+// The colour path is what a wavefront pays most for: only voxels in the narrow band |eta / mu| <= 0.25 take it (about
+// one in eight of the updated ones), but a wave64 executes it whenever ANY of its lanes does -- eight sparse executions of
+// ~70 instructions per block.  So the one-camera fusion kernel queues the band voxels of a half block in LDS (projection
+// + old colour, 16 bytes each), runs the colour update densely over the queue -- one voxel per lane, usually one pass --
+// and hands every result back through the same slot.  Same arithmetic per voxel, same bits.
+// colour word: clr0 | clr1 << 8 | clr2 << 16 | w_color << 24
+__device__ __forceinline__ unsigned fuse_colour_word(unsigned pack, float u, float w, const IntegrateParams &p,
+                                                     const float *inv_tab) {
+  unsigned lo = pack << 24, hi = pack >> 8;
+  const Vec4 unused = {0.0f, 0.0f, 0.0f, 1.0f};
+  fuse_colour<true>(lo, hi, u, w, unused, p, inv_tab);
+  return (lo >> 24) | ((hi & 0xffffffu) << 8);
+}
+
+constexpr int kColQueue = 256;  // one slot per voxel of a half block
+
 // ComputeUpdatedVoxelInfo<hasColor>::compute for the two voxels of one chunk: (vv.x, vv.y) at x, (vv.z, vv.w) at x + 1
-template <bool SAME_CAM>
+// QUEUE: the colour update is not done here; `cmask` (bit h: voxel h is inside the narrow band) and the projections come
+// back so that the caller can run the colour updates of a half block densely (see k_integrate)
+template <bool SAME_CAM, bool QUEUE = false>
 __device__ __forceinline__ bool fuse_pair(uint4 &vv, f2 pcx, f2 pcy, f2 pcz, const Vec4 &pm0, const Vec4 &pm1,
-                                          const IntegrateParams &p, const float *inv_tab) {
+                                          const IntegrateParams &p, const float *inv_tab, unsigned *cmask = nullptr,
+                                          f2 *u_out = nullptr, f2 *w_out = nullptr) {
+  if constexpr (QUEUE) *cmask = 0;
   bool act0 = pcz.x >= kMinCamZ, act1 = pcz.y >= kMinCamZ;
   if (p.stop_max) {
     act0 = act0 && (int)((vv.x >> 16) & 0xffu) != p.max_w;
@@ -364,8 +388,16 @@ __device__ __forceinline__ bool fuse_pair(uint4 &vv, f2 pcx, f2 pcy, f2 pcz, con
   if (act0) vv.x = (vv.x & 0xff000000u) | ((unsigned)nW0 << 16) | (unsigned)(unsigned short)(short)sf.x;
   if (act1) vv.z = (vv.z & 0xff000000u) | ((unsigned)nW1 << 16) | (unsigned)(unsigned short)(short)sf.y;
   // colour: only inside the narrow band around the surface
-  if (act0 && !((eta.x > p.mu) || (fabsf(eta_mu.x) > 0.25f))) fuse_colour<SAME_CAM>(vv.x, vv.y, u.x, w.x, pm0, p, inv_tab);
-  if (act1 && !((eta.y > p.mu) || (fabsf(eta_mu.y) > 0.25f))) fuse_colour<SAME_CAM>(vv.z, vv.w, u.y, w.y, pm1, p, inv_tab);
+  const bool col0 = act0 && !((eta.x > p.mu) || (fabsf(eta_mu.x) > 0.25f));
+  const bool col1 = act1 && !((eta.y > p.mu) || (fabsf(eta_mu.y) > 0.25f));
+  if constexpr (QUEUE) {
+    *cmask = (col0 ? 1u : 0u) | (col1 ? 2u : 0u);
+    *u_out = u;
+    *w_out = w;
+  } else {
+    if (col0) fuse_colour<SAME_CAM>(vv.x, vv.y, u.x, w.x, pm0, p, inv_tab);
+    if (col1) fuse_colour<SAME_CAM>(vv.z, vv.w, u.y, w.y, pm1, p, inv_tab);
+  }
   return true;
 }
 
@@ -377,6 +409,9 @@ constexpr int kMaxGroup = 8;
 template <bool DEINT, bool SAME_CAM>
 __global__ __launch_bounds__(256, 8) void k_integrate(IntegrateParams p) {
   __shared__ float inv_tab[kInvTab];
+  // the one-camera fusion variant runs its colour updates densely from a per-wave LDS queue (fuse_colour_word)
+  constexpr bool kQueueColour = !DEINT && SAME_CAM && DSLAM_PACKED && DSLAM_COLOUR_QUEUE;
+  __shared__ uint4 col_q[kQueueColour ? 4 : 1][kQueueColour ? kColQueue : 1];
   for (int i = threadIdx.x; i < kInvTab; i += 256) inv_tab[i] = 1.0f / (float)i;  // IEEE division: RN(1/i)
   __syncthreads();
   const int lane = threadIdx.x & 63;
@@ -436,6 +471,10 @@ __global__ __launch_bounds__(256, 8) void k_integrate(IntegrateParams p) {
       uint4 v[2];
       v[0] = blk[(half * 2) * 64 + lane];
       v[1] = blk[(half * 2 + 1) * 64 + lane];
+      bool chs[2] = {false, false};
+      [[maybe_unused]] int q_n = 0;          // queued colour updates of this half (wave-uniform)
+      [[maybe_unused]] unsigned q_slots = 0; // this lane's slots, 8 bits per (chunk, voxel); q_mine: which of the four it has
+      [[maybe_unused]] unsigned q_mine = 0;
 #pragma unroll
       for (int jj = 0; jj < 2; jj++) {
         const int j = half * 2 + jj;
@@ -448,7 +487,28 @@ __global__ __launch_bounds__(256, 8) void k_integrate(IntegrateParams p) {
           const f2 t0 = {p.M_d.m[12], p.M_d.m[12]}, t1 = {p.M_d.m[13], p.M_d.m[13]}, t2 = {p.M_d.m[14], p.M_d.m[14]};
           const f2 px = {pxy[0][0], pxy[1][0]}, py = {pxy[0][1], pxy[1][1]}, pz = {pxy[0][2], pxy[1][2]};
           const Vec4 pm0 = {fxv[0], fy, fz, 1.0f}, pm1 = {fxv[1], fy, fz, 1.0f};
-          ch = fuse_pair<SAME_CAM>(v[jj], (px + a0) + t0, (py + a1) + t1, (pz + a2) + t2, pm0, pm1, p, inv_tab);
+          if constexpr (kQueueColour) {
+            unsigned cm;
+            f2 uo, wo;
+            ch = fuse_pair<SAME_CAM, true>(v[jj], (px + a0) + t0, (py + a1) + t1, (pz + a2) + t2, pm0, pm1, p, inv_tab, &cm, &uo, &wo);
+            if (__ballot(cm != 0u))  // (most chunks of a block far from the surface queue nothing)
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+              const bool c = (cm >> h) & 1u;
+              const unsigned long long bm = __ballot(c);
+              if (c) {
+                const unsigned lo = h ? v[jj].z : v[jj].x, hi = h ? v[jj].w : v[jj].y;
+                const int slot = q_n + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(bm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bm, 0u));
+                col_q[threadIdx.x >> 6][slot] = make_uint4(__float_as_uint(h ? uo.y : uo.x), __float_as_uint(h ? wo.y : wo.x),
+                                                           (lo >> 24) | ((hi & 0xffffffu) << 8), 0u);
+                q_slots |= (unsigned)slot << (8 * (jj * 2 + h));
+                q_mine |= 1u << (jj * 2 + h);
+              }
+              q_n += __popcll(bm);
+            }
+          } else {
+            ch = fuse_pair<SAME_CAM>(v[jj], (px + a0) + t0, (py + a1) + t1, (pz + a2) + t2, pm0, pm1, p, inv_tab);
+          }
         } else {
 #pragma unroll
           for (int h = 0; h < 2; h++) {
@@ -463,8 +523,30 @@ __global__ __launch_bounds__(256, 8) void k_integrate(IntegrateParams p) {
             ch |= update_voxel<DEINT, SAME_CAM>(lo, hi, pc, pm, p, inv_tab);
           }
         }
-        if (ch) blk[j * 64 + lane] = v[jj];
+        chs[jj] = ch;
       }
+      if constexpr (kQueueColour) {
+        // the queued colour updates, one per lane; the result replaces the old colour word in the entry's slot
+        uint4 *q = col_q[threadIdx.x >> 6];
+        for (int i = lane; i < q_n; i += 64) {
+          const uint4 en = q[i];
+          q[i].z = fuse_colour_word(en.z, __uint_as_float(en.x), __uint_as_float(en.y), p, inv_tab);
+        }
+#pragma unroll
+        for (int jj = 0; jj < 2; jj++)
+#pragma unroll
+          for (int h = 0; h < 2; h++)
+            if ((q_mine >> (jj * 2 + h)) & 1u) {
+              const unsigned word = q[(q_slots >> (8 * (jj * 2 + h))) & 0xffu].z;
+              unsigned &lo = h ? v[jj].z : v[jj].x;
+              unsigned &hi = h ? v[jj].w : v[jj].y;
+              lo = (lo & 0x00ffffffu) | (word << 24);
+              hi = (hi & 0xff000000u) | (word >> 8);
+            }
+      }
+#pragma unroll
+      for (int jj = 0; jj < 2; jj++)
+        if (chs[jj]) blk[(half * 2 + jj) * 64 + lane] = v[jj];
       }
     }
   }
