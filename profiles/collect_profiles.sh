@@ -1,16 +1,27 @@
-# collects the judged artifacts: default bench line, kernel stats, PMC passes (all the same bench command)
+# collects the judged artifacts of a round (run ON the GPU box via gpurun; outputs under gpurun_out/, condensed into
+# profiles/<tag>_* by profiles/make_profiles.py):  bash profiles/collect_profiles.sh
 export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 cd $R
+mkdir -p gpurun_out
 python bench.py > gpurun_out/final_bench.json 2> gpurun_out/final_bench.err; echo bench rc=$?
+BENCH_FAST="--steps 100 --warmup 10 --no-cpu-baseline --no-stress --no-extra-rates --reint 0"
 cd /tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/final_stats -- python3 $R/bench.py --steps 100 --warmup 10 --no-cpu-baseline --reint 0 > $R/gpurun_out/final_stats.log 2>&1; echo stats rc=$?
-rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $R/gpurun_out/final_fetch -- python3 $R/bench.py --steps 30 --warmup 5 --no-cpu-baseline --reint 0 > $R/gpurun_out/final_fetch.log 2>&1; echo fetch rc=$?
-rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $R/gpurun_out/final_write -- python3 $R/bench.py --steps 30 --warmup 5 --no-cpu-baseline --reint 0 > $R/gpurun_out/final_write.log 2>&1; echo write rc=$?
+# per-kernel times of the default (PCIe-inclusive, pipelined) loop and of the device-resident loop
+rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/final_stats -- python3 $R/bench.py $BENCH_FAST > $R/gpurun_out/final_stats.log 2>&1; echo stats rc=$?
+rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/final_stats_device -- python3 $R/bench.py $BENCH_FAST --mode device > $R/gpurun_out/final_stats_device.log 2>&1; echo stats_device rc=$?
+# HBM traffic of k_integrate: two separate counter passes (MI355X_MICROARCH.md, HBM / rocprofv3)
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $R/gpurun_out/final_fetch -- python3 $R/bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-stress --no-extra-rates --reint 0 --mode device > $R/gpurun_out/final_fetch.log 2>&1; echo fetch rc=$?
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $R/gpurun_out/final_write -- python3 $R/bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-stress --no-extra-rates --reint 0 --mode device > $R/gpurun_out/final_write.log 2>&1; echo write rc=$?
+# instruction counters of k_integrate (VALU instructions per block-wave)
+rocprofv3 --pmc SQ_INSTS_VALU SQ_WAVES --kernel-trace --output-format csv -d $R/gpurun_out/final_sq -- python3 $R/bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-stress --no-extra-rates --reint 0 --mode device > $R/gpurun_out/final_sq.log 2>&1; echo sq rc=$?
 cd $R
+# per-wave dump of the ray march and per-tile timeline of the allocation sweep (diagnostic instantiations)
+DSLAM_DBG_WAVETIME=gpurun_out/final_wavetime.bin DSLAM_DBG_SWEEP=gpurun_out/final_sweep.bin python bench.py $BENCH_FAST --mode device > /dev/null 2>&1; ls -la gpurun_out/final_wavetime.bin gpurun_out/final_sweep.bin
+python bench.py --mode sync --steps 100 --warmup 10 --no-cpu-baseline --no-stress --no-extra-rates --reint 0 > gpurun_out/final_bench_sync.json 2>/dev/null
 python denseslam-global-consistency-h_amd/harness/stress.py 64 > gpurun_out/final_stress.json; cat gpurun_out/final_stress.json
-python bench.py --sync --steps 100 --warmup 10 --no-cpu-baseline --reint 0 > gpurun_out/final_bench_sync.json 2>/dev/null; grep -o '"value": [0-9.]*' gpurun_out/final_bench_sync.json
-python denseslam-global-consistency-h_amd/harness/side_bench.py 50 > gpurun_out/final_side_bench.json 2>gpurun_out/final_side_bench.err; cat gpurun_out/final_side_bench.json
-python bench.py --host-io --steps 100 --warmup 10 --no-cpu-baseline --reint 0 > gpurun_out/final_bench_hostio.json 2>/dev/null; grep -o "\"value\": [0-9.]*" gpurun_out/final_bench_hostio.json
-python denseslam-global-consistency-h_amd/harness/quality.py 40 > gpurun_out/final_quality.json 2>gpurun_out/final_quality.err; cat gpurun_out/final_quality.json
-python denseslam-global-consistency-h_amd/harness/maint_bench.py > gpurun_out/final_maintenance.json 2>gpurun_out/final_maintenance.err; cat gpurun_out/final_maintenance.json
+python profiles/experiments/pipeline_breakdown.py 100 > gpurun_out/final_pipeline.json 2>/dev/null; cat gpurun_out/final_pipeline.json
+python denseslam-global-consistency-h_amd/harness/side_bench.py 50 > gpurun_out/final_side_bench.json 2>gpurun_out/final_side_bench.err; tail -c 300 gpurun_out/final_side_bench.json
+python denseslam-global-consistency-h_amd/harness/quality.py 40 > gpurun_out/final_quality.json 2>gpurun_out/final_quality.err; tail -c 300 gpurun_out/final_quality.json
+python denseslam-global-consistency-h_amd/harness/maint_bench.py > gpurun_out/final_maintenance.json 2>gpurun_out/final_maintenance.err; tail -c 400 gpurun_out/final_maintenance.json
+python denseslam-global-consistency-h_amd/harness/shard_emulation.py 120 32 > gpurun_out/final_shard_emulation.json 2>/dev/null; tail -c 300 gpurun_out/final_shard_emulation.json

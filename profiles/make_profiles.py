@@ -1,31 +1,37 @@
 #!/usr/bin/env python3
-"""Turn the raw outputs of scratch/collect_profiles.sh (run on the GPU box, merged back under gpurun_out/) into the
-per-round files of this directory.  Usage: python profiles/make_profiles.py r01
+"""Turn the raw outputs of profiles/collect_profiles.sh (run on the GPU box, merged back under gpurun_out/) into the
+per-round files of this directory.  Usage: python profiles/make_profiles.py r02
 
-gpurun_out/final_bench.json         <- python bench.py
-gpurun_out/final_bench_sync.json    <- python bench.py --sync --steps 100 --warmup 10 --no-cpu-baseline --reint 0
-gpurun_out/final_stats/             <- rocprofv3 --kernel-trace --stats ... bench.py --steps 100 --warmup 10 --no-cpu-baseline --reint 0
-gpurun_out/final_fetch|final_write/ <- rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --kernel-trace ... bench.py --steps 30 --warmup 5
-gpurun_out/final_stress.json        <- python denseslam-global-consistency-h_amd/harness/stress.py 64
-gpurun_out/final_side_bench.json    <- python denseslam-global-consistency-h_amd/harness/side_bench.py 50
-gpurun_out/final_quality.json       <- python denseslam-global-consistency-h_amd/harness/quality.py 40
+gpurun_out/final_bench.json              <- python bench.py                      (the driver's command)
+gpurun_out/final_bench_sync.json         <- python bench.py --mode sync ...
+gpurun_out/final_stats[_device]/         <- rocprofv3 --kernel-trace --stats ... bench.py [--mode device]
+gpurun_out/final_fetch|final_write/      <- rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --kernel-trace ... bench.py --mode device
+gpurun_out/final_sq/                     <- rocprofv3 --pmc SQ_INSTS_VALU SQ_WAVES --kernel-trace ... bench.py --mode device
+gpurun_out/final_wavetime.bin            <- DSLAM_DBG_WAVETIME dump of k_render (per wave: cycles, march length, ...)
+gpurun_out/final_sweep.bin               <- DSLAM_DBG_SWEEP dump of k_alloc_sweep (per tile: 8 timestamps)
+gpurun_out/final_{stress,pipeline,side_bench,quality,maintenance,shard_emulation}.json
 """
 import csv
 import glob
 import json
 import os
 import shutil
+import subprocess
 import sys
+
+import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 OUT = os.path.join(ROOT, "gpurun_out")
 HERE = os.path.join(ROOT, "profiles")
 
 
-def newest(pattern):
+def newest(pattern, required=True):
     files = sorted(glob.glob(os.path.join(OUT, pattern)), key=os.path.getmtime)
     if not files:
-        sys.exit(f"missing {pattern} under gpurun_out/")
+        if required:
+            sys.exit(f"missing {pattern} under gpurun_out/")
+        return None
     return files[-1]
 
 
@@ -37,58 +43,83 @@ def last_json_line(path):
     sys.exit(f"no JSON line in {path}")
 
 
-def counter_mean(dirname, counter, skip):
-    rows = [r for r in csv.DictReader(open(newest(f"{dirname}/*/*counter_collection.csv")))
-            if r["Counter_Name"] == counter and "k_integrate" in r["Kernel_Name"]]
-    vals = [float(r["Counter_Value"]) for r in rows][skip:]
-    return sum(vals) / len(vals), len(vals)
+def counter_rows(dirname, counter, kernel):
+    return [float(r["Counter_Value"]) for r in csv.DictReader(open(newest(f"{dirname}/*/*counter_collection.csv")))
+            if r["Counter_Name"] == counter and kernel in r["Kernel_Name"]]
+
+
+def copy_json(src, dst):
+    p = os.path.join(OUT, src)
+    if os.path.exists(p) and os.path.getsize(p) > 2:
+        json.dump(last_json_line(p), open(os.path.join(HERE, dst), "w"), indent=1)
 
 
 def main():
-    tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+    tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
     bench = last_json_line(os.path.join(OUT, "final_bench.json"))
     json.dump(bench, open(os.path.join(HERE, f"{tag}_bench_default.json"), "w"), indent=1)
-    json.dump(last_json_line(os.path.join(OUT, "final_bench_sync.json")),
-              open(os.path.join(HERE, f"{tag}_bench_sync.json"), "w"), indent=1)
+    copy_json("final_bench_sync.json", f"{tag}_bench_sync.json")
     shutil.copy(newest("final_stats/*/*kernel_stats.csv"), os.path.join(HERE, f"{tag}_bench_steps100_kernel_stats.csv"))
-    json.dump(last_json_line(os.path.join(OUT, "final_stress.json")),
-              open(os.path.join(HERE, f"{tag}_stress_integrate.json"), "w"), indent=1)
-    hostio = os.path.join(OUT, "final_bench_hostio.json")
-    if os.path.exists(hostio):
-        json.dump(last_json_line(hostio), open(os.path.join(HERE, f"{tag}_bench_hostio.json"), "w"), indent=1)
-    side = os.path.join(OUT, "final_side_bench.json")
-    if os.path.exists(side):
-        json.dump(last_json_line(side), open(os.path.join(HERE, f"{tag}_side_bench.json"), "w"), indent=1)
-    maint = os.path.join(OUT, "final_maintenance.json")
-    if os.path.exists(maint):
-        json.dump(last_json_line(maint), open(os.path.join(HERE, f"{tag}_maintenance.json"), "w"), indent=1)
-    quality = os.path.join(OUT, "final_quality.json")
-    if os.path.exists(quality):
-        json.dump(last_json_line(quality), open(os.path.join(HERE, f"{tag}_quality.json"), "w"), indent=1)
+    dev = newest("final_stats_device/*/*kernel_stats.csv", required=False)
+    if dev:
+        shutil.copy(dev, os.path.join(HERE, f"{tag}_bench_device_steps100_kernel_stats.csv"))
+    for src, dst in (("final_stress.json", "stress_integrate"), ("final_pipeline.json", "pipeline_breakdown"),
+                     ("final_side_bench.json", "side_bench"), ("final_maintenance.json", "maintenance"),
+                     ("final_quality.json", "quality"), ("final_shard_emulation.json", "shard_emulation")):
+        copy_json(src, f"{tag}_{dst}.json")
 
     # HBM traffic of k_integrate from the two PMC passes (MI355X_MICROARCH.md, "HBM / rocprofv3"): counters are in KiB;
     # on gfx950 FETCH_SIZE counts wide (16 B per lane) streaming reads at half their size -> doubled; WRITE_SIZE is exact.
     warm = 5
     run = last_json_line(os.path.join(OUT, "final_fetch.log"))
-    fetch, n = counter_mean("final_fetch", "FETCH_SIZE", warm)
-    write, n2 = counter_mean("final_write", "WRITE_SIZE", warm)
+    fetch = counter_rows("final_fetch", "FETCH_SIZE", "k_integrate")[warm:]
+    write = counter_rows("final_write", "WRITE_SIZE", "k_integrate")[warm:]
     vis = run["config"]["visible_blocks_per_frame"]
-    traffic = (2.0 * fetch + write) * 1024.0
+    fetch_m, write_m = sum(fetch) / len(fetch), sum(write) / len(write)
+    traffic = (2.0 * fetch_m + write_m) * 1024.0
     algo = 8212.0 * vis + 8.0 * 640 * 480
-    json.dump({
+    pmc = {
         "kernel": "k_integrate<false,true>",
-        "command": "rocprofv3 --pmc {FETCH_SIZE|WRITE_SIZE} --kernel-trace --output-format csv -- python3 bench.py "
-                   "--steps 30 --warmup 5 --no-cpu-baseline --reint 0 (two separate passes; the 30 timed launches)",
-        "launches": min(n, n2),
-        "FETCH_SIZE_KiB_mean": fetch,
-        "WRITE_SIZE_KiB_mean": write,
+        "command": "rocprofv3 --pmc {FETCH_SIZE|WRITE_SIZE} --kernel-trace --output-format csv -- python3 bench.py --steps 30 "
+                   "--warmup 5 --no-cpu-baseline --no-stress --no-extra-rates --reint 0 --mode device (two separate passes; the 30 timed launches)",
+        "launches": min(len(fetch), len(write)), "FETCH_SIZE_KiB_mean": fetch_m, "WRITE_SIZE_KiB_mean": write_m,
         "visible_blocks_per_launch": vis,
-        "correction": "gfx950: FETCH_SIZE reports 1/2 of wide (16 B/lane) streaming reads -> doubled "
-                      "(MI355X_MICROARCH.md, HBM); WRITE_SIZE exact",
-        "traffic_bytes_per_launch": traffic,
-        "traffic_bytes_per_visible_block": traffic / vis,
+        "correction": "gfx950: FETCH_SIZE reports 1/2 of wide (16 B/lane) streaming reads -> doubled (MI355X_MICROARCH.md, HBM); WRITE_SIZE exact",
+        "traffic_bytes_per_launch": traffic, "traffic_bytes_per_visible_block": traffic / vis,
         "algorithmic_bytes_per_launch": algo,
-    }, open(os.path.join(HERE, f"{tag}_integrate_pmc.json"), "w"), indent=1)
+    }
+    # instruction counters: VALU instructions per wavefront of the launch = per voxel block (one block per wave at this V)
+    if newest("final_sq/*/*counter_collection.csv", required=False):
+        valu = counter_rows("final_sq", "SQ_INSTS_VALU", "k_integrate")[warm:]
+        waves = counter_rows("final_sq", "SQ_WAVES", "k_integrate")[warm:]
+        if valu and waves:
+            pmc["SQ_INSTS_VALU_mean"] = sum(valu) / len(valu)
+            pmc["SQ_WAVES_mean"] = sum(waves) / len(waves)
+            pmc["valu_instructions_per_visible_block"] = (sum(valu) / len(valu)) / vis
+            pmc["sq_command"] = "rocprofv3 --pmc SQ_INSTS_VALU SQ_WAVES --kernel-trace ... (same bench command, its own pass)"
+    json.dump(pmc, open(os.path.join(HERE, f"{tag}_integrate_pmc.json"), "w"), indent=1)
+
+    # per-wave dump of the ray march: 6 u64 per single-wave workgroup {cycles, longest march of its lanes, iterations in
+    # which a lane read a straddling cell, their cycles, setup cycles, refinement cycles}
+    wt = os.path.join(OUT, "final_wavetime.bin")
+    if os.path.exists(wt):
+        d = np.fromfile(wt, dtype=np.uint64).reshape(-1, 6).astype(np.float64)
+        d = d[d[:, 0] > 0]
+        us = d[:, 0] / 2400.0
+        json.dump({
+            "kernel": "k_render<1,false,DIAG>", "source": "DSLAM_DBG_WAVETIME dump of the 30th launch (shader clock, 2.4 ticks per ns)",
+            "waves": int(len(d)), "simds_on_chip": 1024,
+            "march_steps_longest_lane": {"mean": float(d[:, 1].mean()), "p50": float(np.median(d[:, 1])), "p99": float(np.percentile(d[:, 1], 99)), "max": float(d[:, 1].max())},
+            "wave_lifetime_us": {"mean": float(us.mean()), "p99": float(np.percentile(us, 99)), "max": float(us.max())},
+            "sum_of_lifetimes_over_simds_us": float(us.sum() / 1024.0),
+            "iterations_with_a_straddling_cell_frac": float(d[:, 2].sum() / max(1.0, d[:, 1].sum())),
+            "cycles_per_plain_iteration": float((d[:, 0] - d[:, 3] - d[:, 4] - d[:, 5]).sum() / max(1.0, (d[:, 1] - d[:, 2]).sum())),
+            "cycles_per_straddling_iteration": float(d[:, 3].sum() / max(1.0, d[:, 2].sum())),
+        }, open(os.path.join(HERE, f"{tag}_render_wave_dump.json"), "w"), indent=1)
+    sw = os.path.join(OUT, "final_sweep.bin")
+    if os.path.exists(sw):
+        subprocess.run([sys.executable, os.path.join(HERE, "experiments", "sweep_timeline.py"), sw,
+                        os.path.join(HERE, f"{tag}_sweep_timeline.json")], stdout=subprocess.DEVNULL, check=True)
     print(f"{tag}: {bench['value']:.0f} frames/s, roofline frac {bench['roofline']['frac']:.3f}, "
           f"traffic/algorithmic {traffic / algo:.3f}")
 
