@@ -23,7 +23,7 @@ oracle.lib.oracle_raycast_trace_buffer(None, C.c_int(0))
 t = buf.reshape(wl.H // 8, 8, wl.W // 8, 8, L).transpose(0, 2, 1, 3, 4).reshape(-1, 64, L)  # [tile, lane, iter]
 # cost model per wave step (cycles): RT = 1000, instr: plain 180*4, slow adds ~ (5780-2730-2000)
 RT = 1000
-def cost(t, use_cache):
+def cost(t, use_cache, merged=False, merged_extra_instr=0):
     active = t > 0
     miss = (t == 1); probe = (t == 3) | (t == 6) | (t == 7) | (t == 1)
     slow_new = (t == 4) | (t == 6); slow_same = (t == 5) | (t == 7)
@@ -35,6 +35,11 @@ def cost(t, use_cache):
     need_resolve = (slow_new.any(1)) if use_cache else any_slow
     rts = any_probe * 1 + any_found * 1 + any_slow * 1 + need_resolve * 1
     instr = any_active * 400 + any_found * 320 + any_slow * 1050
+    if merged:  # SDF shadow addressed by hash-entry index: the bucket-head probe and the nearest-voxel read of a lane share
+        # one round trip (the read is speculative on "the head is the block", true for every found block off the excess
+        # lists); the union path of a wave step then has ONE round trip where it had probe -> read
+        rts = (any_probe | any_found) * 1 + any_slow * 1 + need_resolve * 1
+        instr = instr + any_probe * merged_extra_instr
     return (rts * RT + instr) * any_active
 c0 = cost(t, False).sum(1); c1 = cost(t, True).sum(1)
 iters = (t > 0).any(1).sum(1)
@@ -49,6 +54,10 @@ for k in order[:3]:
     slow_new = ((tt == 4) | (tt == 6)).any(0)[:n]; slow_any = (tt >= 4).any(0)[:n]
     print('   slow wave-steps', slow_any.sum(), 'of which need resolve with cache', slow_new.sum())
 print('model kernel time now %.1f us, with cache %.1f us (2.4 GHz)' % (c0.max() / 2400, c1.max() / 2400))
+for extra in (0, 80, 160):
+    cm = cost(t, False, merged=True, merged_extra_instr=extra * 4).sum(1)
+    print('merged probe+read round trip (+%d instructions on a probing step): model kernel time %.1f us (%.0f %% of now); sum over tiles %.3g vs %.3g'
+          % (extra, cm.max() / 2400, 100.0 * cm.max() / c0.max(), cm.sum(), c0.sum()))
 print('--- wave shapes (model) ---')
 img = buf.reshape(wl.H, wl.W, L)
 for tw, th in ((8, 8), (16, 4), (32, 2), (64, 1), (4, 16), (2, 32)):
@@ -60,3 +69,15 @@ for tw, th in ((8, 8), (16, 4), (32, 2), (64, 1), (4, 16), (2, 32)):
 one = img.reshape(-1, 1, L)
 c = cost(one, False).sum(1)
 print('lone ray bound: %.1f us' % (c.max() / 2400))
+
+# --- transitions per wave step (for the by-entry experiment: speculative tap loads are warm only where the entry holds a
+# block; a lane that steps from a block into empty space sends them to a cold bucket, and the wave waits for them)
+prev = np.concatenate([np.zeros_like(t[:, :, :1]), t[:, :, :-1]], axis=2)
+found_now = t >= 2; miss_now = t == 1; found_prev = prev >= 2; miss_prev = (prev == 1) | (prev == 0)
+probe_now = (t == 1) | (t == 3) | (t == 6) | (t == 7)
+f2m = (found_prev & miss_now).any(1); m2f = (miss_prev & found_now).any(1); f2f = (found_prev & found_now & probe_now).any(1)
+m2m = (miss_prev & miss_now).any(1)
+for k in order[:5]:
+    n = int((t[k] > 0).any(0).sum())
+    print('tile %d: %d wave-steps; some lane block->empty in %d, empty->block in %d, block->other block in %d, empty->empty in %d'
+          % (k, n, f2m[k, :n].sum(), m2f[k, :n].sum(), f2f[k, :n].sum(), m2m[k, :n].sum()))
