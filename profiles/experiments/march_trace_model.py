@@ -81,3 +81,23 @@ for k in order[:5]:
     n = int((t[k] > 0).any(0).sum())
     print('tile %d: %d wave-steps; some lane block->empty in %d, empty->block in %d, block->other block in %d, empty->empty in %d'
           % (k, n, f2m[k, :n].sum(), m2f[k, :n].sum(), f2f[k, :n].sum(), m2m[k, :n].sum()))
+
+# --- two-phase march with regrouping (priced only): every tile marches at most S1 steps; rays still going are queued
+# with their state and continued by waves that hold only g of them (less union-path cost per step: a ray alone pays one
+# round trip on most steps, 64 together pay two on nearly all).  Total = longest phase-1 tile + hand-over + longest group.
+print('--- two-phase march, regrouped tails (model; hand-over = one launch boundary + state store/load = 14000 cycles) ---')
+HAND = 14000
+for S1 in (8, 12, 16, 24, 32):
+    c_head = cost(t[:, :, :S1], False).sum(1)
+    alive = t[:, :, S1] > 0 if S1 < L else np.zeros(t.shape[:2], bool)
+    line = 'S1 = %2d: phase 1 %.1f us, %d rays (%.1f %%) continue;' % (S1, c_head.max() / 2400, alive.sum(), 100.0 * alive.mean())
+    for g in (4, 8, 16, 32, 64):
+        worst = 0; groups = 0
+        for k in np.nonzero(alive.any(1))[0]:
+            lanes = np.nonzero(alive[k])[0]
+            for a in range(0, len(lanes), g):
+                sub = t[k][lanes[a:a + g], S1:][None]
+                worst = max(worst, int(cost(sub, False).sum()))
+                groups += 1
+        line += '  g=%d: %d waves, total %.1f us' % (g, groups, (c_head.max() + HAND + worst) / 2400)
+    print(line)
