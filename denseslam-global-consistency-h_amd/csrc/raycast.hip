@@ -695,7 +695,10 @@ struct RenderParams {
   int type;  // dslam_image_type, or -1: raycast only
   unsigned long long *dbg_waves;  // diagnostics only (env DSLAM_DBG_WAVETIME=<file>): per wave {cycles, max iterations, straddling iterations, their cycles, setup cycles, refinement cycles}
   int dbg_flags;  // diagnostics only (env DSLAM_DBG_FLAGS: 8 = 16x16 workgroups)
+  float split_len;  // > 0: tiles with a longer depth range (voxels) are marched by two wavefronts; the grid is (W/8, 2 H/8)
 };
+
+constexpr float kSplitLen = 175.0f;  // voxels of depth range above which a tile is marched by two wavefronts (150-200 measure the same)
 
 // DIAG instantiation only: wave-level split of the march (single-wave workgroups): iterations in which some lane took
 // the straddling-cell path, and the cycles of those iterations
@@ -837,7 +840,20 @@ __global__ __launch_bounds__(WAVES * 64, 5) void k_render(RenderParams p) {
   // (measured: dealing each XCD a contiguous band of tiles for L2 locality is slower, 104 vs 100 us -- the long
   // rays of one image region then pile up on one XCD; the march is bound by its longest dependent-load chain)
   const int x = (WAVES == 4) ? blockIdx.x * 16 + (wave & 1) * 8 + (lane & 7) : blockIdx.x * 8 + (lane & 7);
-  const int y = (WAVES == 4) ? blockIdx.y * 16 + (wave >> 1) * 8 + (lane >> 3) : blockIdx.y * 8 + (lane >> 3);
+  int y = (WAVES == 4) ? blockIdx.y * 16 + (wave >> 1) * 8 + (lane >> 3) : blockIdx.y * 8 + (lane >> 3);
+  if (WAVES == 1 && p.split_len > 0.0f) {
+    // The launch ends when its longest wavefront ends, and a step of a wavefront costs the union of what its rays do
+    // (measured: the first 32 steps of the longest tile, all 64 rays alive, take twice as long as its last 36).  So a
+    // tile whose rays have far to go -- depth range of its cell of the range image, in voxels -- is marched by TWO
+    // wavefronts of 32 rays (upper / lower four rows): 78 -> 70 us on the bench scene.  Splitting every tile loses
+    // (throughput: 9600 half-empty waves), 16 rays per wave loses; the grid has two workgroups per tile and the second
+    // one of an unsplit tile leaves at once.  Rays are independent: the images do not change.
+    const int ty = blockIdx.y >> 1, sub = blockIdx.y & 1;
+    const float2 mm = p.range[(int)blockIdx.x + ty * p.W];
+    const bool split = (mm.y - mm.x) * p.one_over_vs > p.split_len;
+    if (split ? (lane >= 32) : (sub != 0)) return;
+    y = ty * 8 + (split ? sub * 4 : 0) + (lane >> 3);
+  }
   if (x >= p.W || y >= p.H) return;
   const int loc = x + y * p.W;
   const int loc2 = (int)floorf((float)x / 8.0f) + (int)floorf((float)y / 8.0f) * p.W;
@@ -922,8 +938,15 @@ static int fill_render_params(RenderParams &rp, const dslam_scene *s, dslam_rend
   rp.range = r->range; rp.raycast = r->raycast; rp.out_rgba = r->image_rgba; rp.out_float = r->image_float;
   rp.type = type;
   static const int dbg_flags = getenv("DSLAM_DBG_FLAGS") ? atoi(getenv("DSLAM_DBG_FLAGS")) : 0;
-  rp.dbg_flags = dbg_flags; rp.dbg_waves = nullptr;
+  rp.dbg_flags = dbg_flags; rp.dbg_waves = nullptr; rp.split_len = 0.0f;
   return DSLAM_OK;
+}
+
+// grid of the single-wave march kernels; `split`: long tiles get two wavefronts (see k_render)
+static dim3 march_grid(RenderParams &rp, const dslam_render_state *r, bool split) {
+  static const float split_len = getenv("DSLAM_RENDER_SPLIT") ? (float)atof(getenv("DSLAM_RENDER_SPLIT")) : kSplitLen;
+  rp.split_len = split ? split_len : 0.0f;
+  return dim3((r->w + 7) / 8, ((r->h + 7) / 8) * (rp.split_len > 0.0f ? 2 : 1));
 }
 
 int launch_render(dslam_engine *e, const dslam_scene *s, dslam_render_state *r, const float *M, const float *intr,
@@ -937,14 +960,14 @@ int launch_render(dslam_engine *e, const dslam_scene *s, dslam_render_state *r, 
   }
   static const char *dbg_file = getenv("DSLAM_DBG_WAVETIME");
   static int dbg_calls = 0;
-  const int n_waves = ((r->w + 7) / 8) * ((r->h + 7) / 8);
+  const int n_waves = ((r->w + 7) / 8) * ((r->h + 7) / 8) * 2;
   unsigned long long *dbg_host = nullptr;
   if (dbg_file && ++dbg_calls == 30) {  // one snapshot, well into the run
     DSLAM_HIP(hipHostMalloc((void **)&dbg_host, (size_t)n_waves * 48, hipHostMallocDefault));
     memset(dbg_host, 0, (size_t)n_waves * 48);
     rp.dbg_waves = dbg_host;
   }
-  const dim3 grid1((r->w + 7) / 8, (r->h + 7) / 8);
+  const dim3 grid1 = march_grid(rp, r, !reuse_raycast);
   if (reuse_raycast) {
     if (type == DSLAM_IMAGE_DEPTH || type < 0) hipLaunchKernelGGL((k_render<1, false, false, true>), grid1, dim3(64), 0, e->stream, rp);
     else hipLaunchKernelGGL((k_render<1, true, false, true>), grid1, dim3(64), 0, e->stream, rp);
@@ -1031,7 +1054,7 @@ int launch_icp_maps(dslam_engine *e, const dslam_scene *s, dslam_render_state *r
   int rc = fill_render_params(rp, s, r, M, intr, -1);
   if (rc) return rc;
   const dim3 grid((r->w + 15) / 16, (r->h + 15) / 16);
-  hipLaunchKernelGGL((k_render<1, false>), dim3((r->w + 7) / 8, (r->h + 7) / 8), dim3(64), 0, e->stream, rp);
+  hipLaunchKernelGGL((k_render<1, false>), march_grid(rp, r, true), dim3(64), 0, e->stream, rp);
   hipLaunchKernelGGL(k_icp_maps, grid, dim3(256), 0, e->stream, r->raycast, r->w, r->h, s->p.voxel_size, -rp.invM.m[8],
                      -rp.invM.m[9], -rp.invM.m[10], r->icp_points, r->icp_normals, r->raycast_image);
   DSLAM_HIP(hipGetLastError());

@@ -101,3 +101,9 @@ for S1 in (8, 12, 16, 24, 32):
                 groups += 1
         line += '  g=%d: %d waves, total %.1f us' % (g, groups, (c_head.max() + HAND + worst) / 2400)
     print(line)
+
+print('--- waves that hold fewer rays (half-empty wave64s; model) ---')
+for tw, th in ((8, 8), (8, 4), (4, 8), (4, 4), (8, 2), (2, 2)):
+    tt = img.reshape(wl.H // th, th, wl.W // tw, tw, L).transpose(0, 2, 1, 3, 4).reshape(-1, tw * th, L)
+    c = cost(tt, False).sum(1)
+    print('%dx%d (%d rays per wave, %d waves): longest %.1f us, sum of wave costs / 1024 SIMDs %.1f us' % (tw, th, tw * th, len(c), c.max() / 2400, c.sum() / 2400 / 1024))
