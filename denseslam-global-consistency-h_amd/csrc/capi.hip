@@ -199,6 +199,7 @@ int dslam_engine_destroy(dslam_engine *e) {
   free_dev(e->mesh_positions); free_dev(e->mesh_colours);
   if (e->icp_partials_host) (void)hipHostFree(e->icp_partials_host);  // (icp_partials is its device alias)
   for (auto ev : e->ev_pool) (void)hipEventDestroy(ev);
+  for (auto ev : e->retired_events) (void)hipEventDestroy(ev);
   if (e->stream) (void)hipStreamDestroy(e->stream);
   delete e;
   return DSLAM_OK;
@@ -245,7 +246,11 @@ int dslam_fence_create(dslam_engine *e, dslam_fence **out) {
 }
 int dslam_fence_destroy(dslam_fence *f) {
   if (!f) return DSLAM_OK;
-  if (f->ev) (void)hipEventDestroy(f->ev);
+  if (f->engine && f->engine->last_fence == f) f->engine->last_fence = nullptr;
+  if (f->ev) {
+    if (f->lent && f->engine) f->engine->retired_events.push_back(f->ev);  // destroyed with the engine
+    else (void)hipEventDestroy(f->ev);
+  }
   delete f;
   return DSLAM_OK;
 }
@@ -253,6 +258,8 @@ int dslam_fence_record(dslam_engine *e, dslam_fence *f) {
   DSLAM_REQUIRE(e && f && f->engine == e, "fence belongs to a different engine");
   DSLAM_HIP(hipEventRecord(f->ev, e->stream));
   f->recorded = true;
+  f->view_reads_at_record = e->view_reads;
+  e->last_fence = f;
   return DSLAM_OK;
 }
 int dslam_fence_wait(dslam_fence *f) {
@@ -588,10 +595,20 @@ static int upload_view_pipelined(dslam_engine *e, dslam_view *v, const uint8_t *
   }
   const int b = v->up_next;
   v->up_next ^= 1;
-  if (v->up_used[b ^ 1]) DSLAM_HIP(hipEventRecord(v->up_consumed[b ^ 1], e->stream));
+  if (v->up_used[b ^ 1]) {
+    dslam_fence *f = e->last_fence;
+    if (f && f->recorded && f->view_reads_at_record == e->view_reads) {
+      // the caller's fence sits behind every kernel that read buffer b ^ 1 (no view was read since it was recorded)
+      f->lent = true;
+      v->up_consumed_by[b ^ 1] = f->ev;
+    } else {
+      DSLAM_HIP(hipEventRecord(v->up_consumed[b ^ 1], e->stream));
+      v->up_consumed_by[b ^ 1] = v->up_consumed[b ^ 1];
+    }
+  }
   if (v->up_used[b]) {
-    if (stream_waits) DSLAM_HIP(hipStreamWaitEvent(e->copy_stream, v->up_consumed[b], 0));
-    else DSLAM_HIP(hipEventSynchronize(v->up_consumed[b]));
+    if (stream_waits) DSLAM_HIP(hipStreamWaitEvent(e->copy_stream, v->up_consumed_by[b], 0));
+    else DSLAM_HIP(hipEventSynchronize(v->up_consumed_by[b]));
   }
   if (reinterpret_cast<const uint8_t *>(depth_host) == rgba_host + c_bytes) {
     DSLAM_HIP(hipMemcpyAsync(v->up_rgba[b], rgba_host, c_bytes + d_bytes, hipMemcpyHostToDevice, e->copy_stream));
@@ -684,6 +701,7 @@ int dslam_view_update_dataset(dslam_engine *e, dslam_view *v, const uint8_t *col
 
 int dslam_download_view_raw_depth(dslam_engine *e, const dslam_view *v, int16_t *out) {
   DSLAM_REQUIRE(e && v && out, "null argument");
+  e->view_reads++;  // (see dslam_engine::last_fence)
   DSLAM_HIP(hipMemcpyAsync(out, v->raw_src, (size_t)v->w_d * v->h_d * 2, hipMemcpyDeviceToHost, e->stream));
   DSLAM_HIP(hipStreamSynchronize(e->stream));
   return DSLAM_OK;
@@ -691,6 +709,7 @@ int dslam_download_view_raw_depth(dslam_engine *e, const dslam_view *v, int16_t 
 
 int dslam_download_view_rgba(dslam_engine *e, const dslam_view *v, uint8_t *out) {
   DSLAM_REQUIRE(e && v && out, "null argument");
+  e->view_reads++;  // (see dslam_engine::last_fence)
   DSLAM_HIP(hipMemcpyAsync(out, v->rgba_src, (size_t)v->w_rgb * v->h_rgb * 4, hipMemcpyDeviceToHost, e->stream));
   DSLAM_HIP(hipStreamSynchronize(e->stream));
   return DSLAM_OK;
@@ -757,6 +776,7 @@ int dslam_frame_store_put_view(dslam_engine *e, dslam_frame_store *fs, int slot,
   int rc = store_slot_ok(e, fs, slot);
   if (rc) return rc;
   DSLAM_REQUIRE(v && v->engine == e, "null argument");
+  e->view_reads++;  // (see dslam_engine::last_fence)
   DSLAM_REQUIRE(v->w_rgb == fs->w_rgb && v->h_rgb == fs->h_rgb && v->w_d == fs->w_d && v->h_d == fs->h_d, "view and frame store sizes differ");
   DSLAM_HIP(hipMemcpyAsync(fs->rgba + fs->rgba_bytes * slot, v->rgba_src, (size_t)fs->w_rgb * fs->h_rgb * 4, hipMemcpyDeviceToDevice, e->stream));
   DSLAM_HIP(hipMemcpyAsync(fs->depth + fs->depth_bytes * slot, v->raw_src, (size_t)fs->w_d * fs->h_d * 2, hipMemcpyDeviceToDevice, e->stream));
@@ -824,6 +844,7 @@ int dslam_deprocess_frame_stored(dslam_engine *e, dslam_scene *s, const dslam_vi
   int rc = store_slot_ok(e, fs, slot);
   if (rc) return rc;
   DSLAM_REQUIRE(s && v && M_d && intr_d && s->engine == e && v->engine == e, "bad argument");
+  e->view_reads++;  // (see dslam_engine::last_fence)
   DSLAM_REQUIRE(fs->lists && fs->has_list[slot], "no visible list was stored for this keyframe slot");
   s->version = next_map_version();  // the map changes: GetImage memos of this scene are stale
   const unsigned char *base = list_slot(fs, slot);
@@ -895,6 +916,7 @@ static int check_frame_args(dslam_engine *e, dslam_scene *s, const dslam_view *v
                             const float *M, const float *intr) {
   DSLAM_REQUIRE(e && s && v && r && M && intr, "null argument");
   DSLAM_REQUIRE(s->engine == e && v->engine == e && r->engine == e, "objects belong to a different engine");
+  e->view_reads++;  // (see dslam_engine::last_fence)
   return DSLAM_OK;
 }
 
@@ -952,6 +974,7 @@ int dslam_track_camera(dslam_engine *e, const dslam_view *v, dslam_render_state 
                        float pose_M[16], const float intr[4], const dslam_tracker_params *params,
                        dslam_tracker_result *result) {
   DSLAM_REQUIRE(e && v && r && scene_pose_M && pose_M && intr && params, "null argument");
+  e->view_reads++;  // (see dslam_engine::last_fence)
   DSLAM_REQUIRE(v->engine == e && r->engine == e, "objects belong to a different engine");
   return launch_track_camera(e, v, r, scene_pose_M, pose_M, intr, params, result);
 }
@@ -1263,6 +1286,7 @@ int dslam_download_raycast_result(dslam_engine *e, const dslam_render_state *r, 
 }
 int dslam_download_view_depth(dslam_engine *e, const dslam_view *v, float *out) {
   DSLAM_REQUIRE(e && v && out, "null argument");
+  e->view_reads++;  // (see dslam_engine::last_fence)
   int rc = ensure_view_depth(e, v);
   if (rc) return rc;
   return d2h(e, out, v->depth, (size_t)v->w_d * v->h_d * sizeof(float));
@@ -1349,6 +1373,7 @@ int dslam_time_integrate(dslam_engine *e, dslam_scene *s, const dslam_view *v, c
   if (rc) return rc;
   s->version = next_map_version();  // the map may change: GetImage memos of this scene are stale
   DSLAM_REQUIRE(iterations > 0 && out_ms, "bad argument");
+  e->view_reads++;  // (see dslam_engine::last_fence)
   hipEvent_t a, b;
   DSLAM_HIP(hipEventCreate(&a));
   DSLAM_HIP(hipEventCreate(&b));

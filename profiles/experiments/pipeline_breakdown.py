@@ -41,7 +41,8 @@ def main():
     fences = [eng.fence_create() for _ in range(R)]
     cs, ds = wl.W * wl.H * 4, wl.W * wl.H * 2
     out = {}
-    for name, host_in, host_out in (("dev_in/dev_out", 0, 0), ("host_in/dev_out", 1, 0), ("dev_in/host_out", 0, 1), ("host_in/host_out", 1, 1)):
+    for name, host_in, host_out in (("dev_in/dev_out", 0, 0), ("dev_in/dev_out + 1 event record per frame", 0, 2), ("dev_in/dev_out + 2 event records per frame", 0, 3),
+                                    ("host_in/dev_out", 1, 0), ("dev_in/host_out", 0, 1), ("host_in/host_out", 1, 1)):
         eng.set_async(False)
         eng.reset_scene(scene)
         rs, free = eng.create_render_state(scene, wl.W, wl.H), eng.create_render_state(scene, wl.W, wl.H)
@@ -49,18 +50,20 @@ def main():
 
         def step(i):
             slot = i % R
-            if host_out:
+            if host_out == 1:
                 eng.fence_wait(fences[slot])
             if host_in:
                 eng.view_update(view, rgba_p[i], depth_p[i], timestamp=float(i))
             else:
                 eng.view_update_device(view, rgba_d.data_ptr() + i * cs, depth_d.data_ptr() + i * ds, timestamp=float(i))
             eng.process_frame(scene, view, rs, Ms[i], wl.intr)
-            if host_out:
+            if host_out == 1:
                 eng.get_image(scene, free, Ms[i], wl.intr, pkg.IMAGE_DEPTH, out=image_p[slot])
                 eng.fence_record(fences[slot])
             else:
                 eng.get_image(scene, free, Ms[i], wl.intr, pkg.IMAGE_DEPTH, download=False)
+                for k in range(host_out - 1 if host_out > 1 else 0):  # (what an event record costs the stream, by itself)
+                    eng.fence_record(fences[(slot + k) % R])
 
         for i in range(Wm):
             step(i)

@@ -69,3 +69,63 @@ def test_fence_that_was_never_recorded_has_passed(gpu):
     gpu.fence_wait(f)
     assert gpu.fence_query(f)
     f.close()
+
+
+@pytest.mark.parametrize("pattern", ["fence_destroyed_while_lent", "view_read_after_the_fence", "one_fence_for_all"])
+def test_callers_fence_as_consumed_mark(pkg, synth, gpu, pattern):
+    """The pipelined upload takes a caller's fence recorded behind the last view-reading call as the landing buffer's
+    "consumed" mark instead of recording an event of its own (dslam_engine::last_fence).  Call patterns around that:
+    the fence is destroyed while a view still waits on its event; a call reads the view AFTER the fence was recorded
+    (the fence then says nothing about that read); one fence re-recorded every frame."""
+    wl = synth.s_tiny()
+    p = util.small_params(pkg, wl)
+    n_frames = 12
+    frames = [wl.frame(i) for i in range(n_frames)]
+    s0 = gpu.create_scene(p)
+    rs0, v0 = gpu.create_render_state(s0, wl.W, wl.H), gpu.create_view(wl.W, wl.H)
+    for i, (rgba, mm, M) in enumerate(frames):
+        gpu.view_update(v0, rgba, mm, timestamp=float(i))
+        gpu.process_frame(s0, v0, rs0, M, wl.intr)
+    ref = util.snapshot(gpu, s0, rs0)
+
+    s1 = gpu.create_scene(p)
+    rs1, v1 = gpu.create_render_state(s1, wl.W, wl.H), gpu.create_view(wl.W, wl.H)
+    store = gpu.create_frame_store(wl.W, wl.H, n_frames)
+    rgba_p = gpu.host_alloc((n_frames, wl.H, wl.W, 4), np.uint8)
+    mm_p = gpu.host_alloc((n_frames, wl.H, wl.W), np.int16)
+    for i, (rgba, mm, M) in enumerate(frames):
+        rgba_p[i], mm_p[i] = rgba, mm
+    one = gpu.fence_create()
+    gpu.set_async(True)
+    try:
+        for i, (rgba, mm, M) in enumerate(frames):
+            gpu.view_update(v1, rgba_p[i], mm_p[i], timestamp=float(i))
+            gpu.process_frame(s1, v1, rs1, M, wl.intr)
+            if pattern == "fence_destroyed_while_lent":
+                f = gpu.fence_create()
+                gpu.fence_record(f)
+                if i % 2:  # destroyed right away on odd frames, after the next upload borrowed it on even ones
+                    f.close()
+                else:
+                    if i + 1 < n_frames:
+                        gpu.view_update(v1, rgba_p[i], mm_p[i], timestamp=float(i))  # (same frame again: borrows f)
+                    f.close()
+            elif pattern == "view_read_after_the_fence":
+                gpu.fence_record(one)
+                gpu.frame_store_put_view(store, i, v1)  # reads the landing buffer behind the fence
+            else:
+                gpu.fence_record(one)
+        gpu.synchronize()
+    finally:
+        gpu.set_async(False)
+    util.assert_same_state(util.snapshot(gpu, s1, rs1), ref, pattern)
+    if pattern == "view_read_after_the_fence":
+        v2 = gpu.create_view(wl.W, wl.H)
+        for i in (0, n_frames // 2, n_frames - 1):
+            gpu.view_update_from_store(v2, store, i)
+            assert np.array_equal(gpu.download_view_raw_depth(v2), frames[i][1]), f"stored depth image {i}"
+            assert np.array_equal(gpu.download_view_rgba(v2), frames[i][0]), f"stored colour image {i}"
+    one.close()
+    store.close()
+    for a in (rgba_p, mm_p):
+        gpu.host_free(a)
