@@ -642,9 +642,10 @@ __global__ __launch_bounds__(256) void k_types_rearm(const int *__restrict__ ids
 // hash-index order succeeds iff r < available
 __global__ __launch_bounds__(256) void k_realloc_count(const unsigned char *__restrict__ vis_type,
                                                        const HashEntry *__restrict__ hash, int n_entries,
-                                                       int *__restrict__ tile_counts) {
+                                                       int *__restrict__ tile_counts, SceneCounters *cnt) {
   __shared__ int red[4];
   const int t0 = blockIdx.x * kTileEntries + threadIdx.x * 4;
+  if (blockIdx.x == 0 && threadIdx.x == 0) cnt->base_free = cnt->last_free;  // (nothing moves the top before the apply pass ends)
   int c = 0;
   if (t0 < n_entries) {
     const uchar4 v = *reinterpret_cast<const uchar4 *>(vis_type + t0);
@@ -658,21 +659,11 @@ __global__ __launch_bounds__(256) void k_realloc_count(const unsigned char *__re
   if (threadIdx.x == 0) tile_counts[blockIdx.x] = tot;
 }
 
-__global__ __launch_bounds__(1024) void k_realloc_scan(const int *tile_counts, int *tile_offsets, int n_tiles,
-                                                       SceneCounters *cnt) {
-  int totals[1];
-  scan_tiles<1>(tile_counts, tile_offsets, n_tiles, totals);
-  if (threadIdx.x == 0) {
-    cnt->base_free = cnt->last_free;
-    const int avail = cnt->last_free + 1;
-    const int got = totals[0] < avail ? totals[0] : avail;
-    cnt->last_free -= got;
-  }
-}
-
+// the tile's exclusive offset is the sum of the preceding tile counts, computed here; the last tile takes the slots
+// off the pool top (every tile reads the top as it was from base_free)
 __global__ __launch_bounds__(256) void k_realloc_apply(const unsigned char *__restrict__ vis_type, HashEntry *hash,
-                                                       int n_entries, const int *__restrict__ tile_offsets,
-                                                       const int *__restrict__ alloc_list, const SceneCounters *cnt) {
+                                                       int n_entries, const int *__restrict__ tile_counts,
+                                                       const int *__restrict__ alloc_list, SceneCounters *cnt) {
   __shared__ int red[4];
   const int t0 = blockIdx.x * kTileEntries + threadIdx.x * 4;
   bool need[4] = {false, false, false, false};
@@ -688,9 +679,15 @@ __global__ __launch_bounds__(256) void k_realloc_apply(const unsigned char *__re
   }
   int tot;
   int r = block_excl_scan<4>(c, red, tot);
-  if (tot == 0) return;
-  r += tile_offsets[blockIdx.x];
+  const bool last = blockIdx.x == gridDim.x - 1;
+  if (tot == 0 && !last) return;
+  const int offset = block_sum_strided(tile_counts, blockIdx.x, 1, red);
   const int base_free = cnt->base_free;
+  if (last && threadIdx.x == 0) {
+    const int total = offset + tot, avail = base_free + 1;
+    cnt->last_free = base_free - (total < avail ? total : avail);
+  }
+  r += offset;
 #pragma unroll
   for (int k = 0; k < 4; k++)
     if (need[k]) {
@@ -796,11 +793,9 @@ int launch_allocate(dslam_engine *e, dslam_scene *s, const dslam_view *v, dslam_
   if (s->p.use_swapping) {
     const int r_tiles = num_tiles(N);
     hipLaunchKernelGGL(k_realloc_count, dim3(r_tiles), dim3(256), 0, e->stream, r->visible_type, s->hash, N,
-                       e->tile_counts);
-    hipLaunchKernelGGL(k_realloc_scan, dim3(1), dim3(1024), 0, e->stream, e->tile_counts, e->tile_offsets, r_tiles,
-                       s->counters);
+                       e->tile_counts, s->counters);
     hipLaunchKernelGGL(k_realloc_apply, dim3(r_tiles), dim3(256), 0, e->stream, r->visible_type, s->hash, N,
-                       e->tile_offsets, s->alloc_list, s->counters);
+                       e->tile_counts, s->alloc_list, s->counters);
   }
   DSLAM_HIP(hipGetLastError());
   if (dbg_host) {

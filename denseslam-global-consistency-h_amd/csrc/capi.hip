@@ -298,11 +298,11 @@ static int scene_allocate(dslam_engine *e, dslam_scene *s, void *ext_voxels) {
   DSLAM_HIP(hipMalloc(&s->counters, sizeof(SceneCounters)));
   if (s->p.use_swapping) {
     DSLAM_HIP(hipMalloc(&s->swap_state, s->n_entries));
-    s->slot_host = (int *)malloc((size_t)s->n_entries * sizeof(int));
-    if (!s->slot_host) { set_last_error("host global cache allocation failed"); return DSLAM_ERR_INVALID; }
-    for (int i = 0; i < s->n_entries; i++) s->slot_host[i] = -1;
+    DSLAM_HIP(hipMalloc(&s->slot_dev, (size_t)s->n_entries * sizeof(int)));
+    DSLAM_HIP(hipMemsetAsync(s->slot_dev, 0xff, (size_t)s->n_entries * sizeof(int), e->stream));  // -1 everywhere
+    DSLAM_HIP(hipHostMalloc((void **)&s->next_slot_host, 64, hipHostMallocDefault));
+    *s->next_slot_host = 0;
     DSLAM_HIP(hipMalloc(&s->slab_ptrs_dev, (size_t)kMaxSlabs * sizeof(uint4 *)));
-    DSLAM_HIP(hipHostMalloc((void **)&s->transfer_ids_host, (size_t)kTransferBlocks * sizeof(int) * 2, hipHostMallocDefault));
   }
   int rc = ensure_scratch(e, s->n_entries, s->p.num_local_blocks);
   if (rc) return rc;
@@ -349,8 +349,8 @@ int dslam_scene_destroy(dslam_scene *s) {
   free_dev(s->swap_state); free_dev(s->slab_ptrs_dev);
   free_dev(s->dirty); free_dev(s->dirty_list); free_dev(s->dirty_counts);
   for (uint4 *slab : s->slabs) (void)hipHostFree(slab);
-  if (s->transfer_ids_host) (void)hipHostFree(s->transfer_ids_host);
-  free(s->slot_host);
+  if (s->next_slot_host) (void)hipHostFree(s->next_slot_host);
+  free_dev(s->slot_dev);
   delete s;
   return DSLAM_OK;
 }
@@ -362,11 +362,11 @@ int dslam_scene_reset(dslam_engine *e, dslam_scene *s) {
   if (rc) return rc;
   for (int q = 0; q < 2; q++) { s->ring_head[q] = 0; s->ring_next[q] = 0; s->decay_cursor[q] = 0; }
   s->frame_counter = 0;
-  s->last_swapped_in = s->last_swapped_out = 0;
-  if (s->slot_host) {  // the slabs stay; their slots are dealt again from the start
+  if (s->slot_dev) {  // the slabs stay; their slots are dealt again from the start (the counters were just zeroed)
+    DSLAM_HIP(hipMemsetAsync(s->slot_dev, 0xff, (size_t)s->n_entries * sizeof(int), e->stream));
     DSLAM_HIP(hipStreamSynchronize(e->stream));
-    for (int i = 0; i < s->n_entries; i++) s->slot_host[i] = -1;
-    s->next_slot = 0;
+    *s->next_slot_host = 0;
+    s->slot_bound = 0;
   }
   return finish_call(e);
 }
@@ -1224,8 +1224,8 @@ int dslam_get_stats(dslam_engine *e, const dslam_scene *s, const dslam_render_st
   out->fusion_fifo_len = s->ring_next[0] - s->ring_head[0];
   out->defusion_fifo_len = s->ring_next[1] - s->ring_head[1];
   out->alloc_failures = sc->alloc_failures;
-  out->last_swapped_in = s->last_swapped_in;
-  out->last_swapped_out = s->last_swapped_out;
+  out->last_swapped_in = sc->swapped_in;
+  out->last_swapped_out = sc->swapped_out;
   if (sc->error_flags & 1) {
     set_last_error("allocation ray needed more steps than the order key encodes (non-rigid pose or mu/voxel_size changed?)");
     return DSLAM_ERR_UNSUPPORTED;
@@ -1300,9 +1300,10 @@ int dslam_download_last_seen(dslam_engine *e, const dslam_scene *s, int32_t *out
   return d2h(e, out, s->last_seen, (size_t)s->p.num_local_blocks * sizeof(int));
 }
 int dslam_download_stored_block(dslam_engine *e, const dslam_scene *s, int entry, dslam_voxel *out) {
-  DSLAM_REQUIRE(e && s && s->slot_host && entry >= 0 && entry < s->n_entries, "bad entry / no global cache");
-  DSLAM_HIP(hipStreamSynchronize(e->stream));  // the swap kernels write the host slabs directly
-  const int slot = s->slot_host[entry];
+  DSLAM_REQUIRE(e && s && s->slot_dev && entry >= 0 && entry < s->n_entries, "bad entry / no global cache");
+  int slot = -1;  // (d2h waits for the stream: the swap kernels write the host slabs directly)
+  int rc = d2h(e, &slot, s->slot_dev + entry, sizeof(int));
+  if (rc) return rc;
   if (out) {
     if (slot >= 0) memcpy(out, s->slabs[slot >> kSlabShift] + (size_t)(slot & (kSlabBlocks - 1)) * (kBlock3 / 2), kBlock3 * sizeof(dslam_voxel));
     else memset(out, 0, kBlock3 * sizeof(dslam_voxel));

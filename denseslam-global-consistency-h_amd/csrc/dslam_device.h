@@ -56,7 +56,10 @@ struct SceneCounters {
   int swap_count;       // entries selected by the current swap pass
   long long decayed_blocks;
   long long slid_blocks;
-  int pad[2];
+  int next_slot;        // host store (swapping): slots handed out so far
+  int swapped_in;       // blocks merged from / written to the host store by the last swap-in / swap-out
+  int swapped_out;
+  int pad;
 };
 
 struct RenderCounters {

@@ -122,13 +122,14 @@ struct dslam_scene {
   // ITMGlobalCache
   unsigned char *swap_state = nullptr;  // device [entries]
   // host store of swapped-out blocks: page-locked slabs the kernels read and write directly over PCIe (no staging
-  // copy, no host memcpy); an entry's block lives in slot slot_host[entry], slots are dealt in swap-out order
+  // copy, no host memcpy); an entry's block lives in slot slot_dev[entry]; slots are handed out by an atomic counter
   std::vector<uint4 *> slabs;           // pinned, kSlabBlocks blocks each, allocated as the store grows
   uint4 **slab_ptrs_dev = nullptr;      // device [kMaxSlabs]: the same pointers for the kernels
-  int *slot_host = nullptr;             // host   [entries]: slot of the entry's stored block, -1 = none
-  int next_slot = 0;
-  int *transfer_ids_host = nullptr;     // pinned [2 * kTransferBlocks]: entry ids of a batch, then their slots
-  int last_swapped_in = 0, last_swapped_out = 0;
+  int *slot_dev = nullptr;              // device [entries]: slot of the entry's stored block, -1 = none.  The table and
+                                        // the slot counter (SceneCounters::next_slot) live on the device: a swap batch
+                                        // needs no host round trip (round 1: two per ProcessFrame)
+  int *next_slot_host = nullptr;        // pinned: copy of next_slot queued behind every batch that may hand out slots
+  long long slot_bound = 0;             // upper bound of next_slot the host can prove (slabs exist for all of it)
   int shard = 0, num_shards = 1, chunk_blocks = 256;
   unsigned long long version = 0;       // bumped by every call that can change the map (GetImage memo key)
   int shard_first = 0, shard_count = -1;  // contiguous slot range (count < 0: off)

@@ -427,35 +427,29 @@ __global__ __launch_bounds__(256, 8) void k_integrate(IntegrateParams p) {
 
   for (int base = wave * G; base < nvis; base += n_waves * G) {
     // lanes 0..G-1 gather the group's hash entries (one 16-byte load each) and do everything that concerns a block as a
-    // whole -- ring push, dirty mark, shard test -- so that none of those kernel arguments is live across the voxel
-    // loop below (the kernel is short of scalar registers: 80 at 8 waves per SIMD, the rest spills to VGPR lanes)
+    // whole -- ring push, dirty mark, shard test -- so that none of those kernel arguments is used inside the voxel
+    // loop below: the kernel is short of scalar registers (80 at 8 waves per SIMD, the rest spills to VGPR lanes), and
+    // this way the spill code sits in the per-block prologue instead of in every 16-byte chunk (23.0 -> 22.1 us).
+    // (Reading these arguments with vector loads from the argument segment, so that they need no scalar registers at
+    // all, leaves 28 spills instead of 72 and is SLOWER, 22.8 us: the loads sit on every wave's critical path.)
     int e_ptr = -2, e_px = 0, e_py = 0, e_pz = 0;
     if (lane < G && base + lane < nvis) {
       const HashEntry e = load_entry(p.hash, p.visible_ids[base + lane]);
       e_ptr = e.ptr; e_px = e.pos[0]; e_py = e.pos[1]; e_pz = e.pos[2];
-      // (these arguments are read from the kernel-argument segment with VECTOR loads, by the lanes that use them, so
-      // that they never occupy scalar registers: `q` is the argument block behind a pointer the compiler cannot see through)
-      const IntegrateParams *q = static_cast<const IntegrateParams *>(__builtin_amdgcn_kernarg_segment_ptr());
-      asm volatile("" : "+v"(q));
-      const short4 *expect_pos = q->expect_pos;
-      if (expect_pos) {  // a list stored with a keyframe: the entry must still hold the block it held then
-        const short4 ep = expect_pos[base + lane];
+      if (p.expect_pos) {  // a list stored with a keyframe: the entry must still hold the block it held then
+        const short4 ep = p.expect_pos[base + lane];
         if (ep.x != e.pos[0] || ep.y != e.pos[1] || ep.z != e.pos[2]) e_ptr = -2;
       }
       if (e_ptr >= 0) {
         const int ptr = e_ptr;
-        const int push_words = q->push_words;
-        if (push_words) {  // queue this block on the visible-list ring (one lane per block: no race)
-          const int push_bit = q->push_bit;
-          q->masks[((size_t)ptr * 2 + q->push_ring) * push_words + (push_bit >> 6)] |= 1ull << (push_bit & 63);
-          q->last_seen[ptr] = q->push_frame;
+        if (p.push_words) {  // queue this block on the visible-list ring (one lane per block: no race)
+          p.masks[((size_t)ptr * 2 + p.push_ring) * p.push_words + (p.push_bit >> 6)] |= 1ull << (p.push_bit & 63);
+          p.last_seen[ptr] = p.push_frame;
         }
         // (before the shard test: every rank of a sharded batch ends up with the same set of marks)
-        unsigned char *dirty = q->dirty;
-        if (dirty) dirty[ptr] = 1;
-        const int num_shards = q->num_shards, shard_count = q->shard_count;
-        if (num_shards > 1 && ((ptr / q->chunk_blocks) % num_shards) != q->shard) e_ptr = -3;
-        if (shard_count >= 0 && (ptr < q->shard_first || ptr >= q->shard_first + shard_count)) e_ptr = -3;
+        if (p.dirty) p.dirty[ptr] = 1;
+        if (p.num_shards > 1 && ((ptr / p.chunk_blocks) % p.num_shards) != p.shard) e_ptr = -3;
+        if (p.shard_count >= 0 && (ptr < p.shard_first || ptr >= p.shard_first + p.shard_count)) e_ptr = -3;
       }
     }
     for (int k = 0; k < G; k++) {

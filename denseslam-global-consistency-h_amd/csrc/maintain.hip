@@ -429,8 +429,10 @@ int launch_decay(dslam_engine *e, dslam_scene *s, dslam_render_state *r, int max
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// swapping (ITMSwappingEngine + ITMGlobalCache).  Host involvement (the global cache lives in host
-// memory) makes these calls synchronous.
+// swapping (ITMSwappingEngine + ITMGlobalCache).  The global cache lives in page-locked host memory that the
+// kernels read and write directly; the entry -> slot table and the slot counter live on the DEVICE, so the two swap
+// steps of a ProcessFrame are kernels only (the host's part is to keep enough slabs mapped, ensure_slots).  The flush
+// (SaveToGlobalMemory) and the window pop of a swapping scene still loop on host-read counts.
 // ---------------------------------------------------------------------------------------------------------------
 // MODE 0: swap state == 1 (needs the host copy merged)     -- IntegrateGlobalIntoLocal
 // MODE 1: resident with state 0 (never visible since allocation) -- flush promotion
@@ -506,18 +508,21 @@ __device__ __forceinline__ uint4 *stored_block(uint4 *const *slabs, int slot) {
 }
 
 // merge the host copies of ids[0..n) into their (re-allocated) blocks; the stored blocks are read straight from the
-// host slabs over PCIe (slot < 0: the entry has no host copy)
-__global__ __launch_bounds__(256) void k_swap_merge(const int *__restrict__ ids, const int *__restrict__ slots,
-                                                    int n, const HashEntry *__restrict__ hash, uint4 *voxels16,
+// host slabs over PCIe (no slot: the entry has no host copy).  n = *n_dev (a count only the device knows) or n_host.
+__global__ __launch_bounds__(256) void k_swap_merge(const int *__restrict__ ids, const int *__restrict__ slot_of_entry,
+                                                    const int *__restrict__ n_dev, int n_host,
+                                                    const HashEntry *__restrict__ hash, uint4 *voxels16,
                                                     uint4 *const *__restrict__ slabs, unsigned char *swap_state,
-                                                    int maxW) {
+                                                    int maxW, SceneCounters *stats) {
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane((int)((blockIdx.x * 256 + threadIdx.x) >> 6));
   const int n_waves = gridDim.x * 4;
+  const int n = n_dev ? *n_dev : n_host;
+  if (stats && blockIdx.x == 0 && threadIdx.x == 0) stats->swapped_in = n;
   for (int i = wave; i < n; i += n_waves) {
     const int t = ids[i];
     const int ptr = hash[t].ptr;
-    const int slot = slots[i];
+    const int slot = slot_of_entry[t];
     if (slot >= 0 && ptr >= 0) {
       uint4 *blk = voxels16 + (size_t)ptr * (kBlock3 / 2);
       const uint4 *src = stored_block(slabs, slot);
@@ -537,22 +542,34 @@ __global__ __launch_bounds__(256) void k_swap_merge(const int *__restrict__ ids,
 }
 
 // write selected blocks to their host slots (over PCIe, straight from the kernel), reset them, give their voxel-block
-// slots back, mark the entries swapped out
-__global__ __launch_bounds__(256) void k_swap_pack(const int *__restrict__ ids, const int *__restrict__ slots, int n,
-                                                   HashEntry *hash, uint4 *voxels16, uint4 *const *__restrict__ slabs,
-                                                   int *alloc_list, unsigned long long *masks,
-                                                   int *last_seen, int words, unsigned char *swap_state,
-                                                   unsigned char *vis_type, SceneCounters *cnt) {
+// slots back, mark the entries swapped out.  An entry that has no host slot yet takes the next one from the device-side
+// counter (which slot an entry gets is not observable; that every entry keeps the one it got is what matters).
+__global__ __launch_bounds__(256) void k_swap_pack(const int *__restrict__ ids, int *slot_of_entry,
+                                                   const int *__restrict__ n_dev, int n_host, HashEntry *hash,
+                                                   uint4 *voxels16, uint4 *const *__restrict__ slabs, int *alloc_list,
+                                                   unsigned long long *masks, int *last_seen, int words,
+                                                   unsigned char *swap_state, unsigned char *vis_type,
+                                                   SceneCounters *cnt) {
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane((int)((blockIdx.x * 256 + threadIdx.x) >> 6));
   const int n_waves = gridDim.x * 4;
+  const int n = n_dev ? *n_dev : n_host;
   const int base = cnt->last_free;
   const uint4 empty2 = make_uint4(kEmptyVoxelLo, kEmptyVoxelHi, kEmptyVoxelLo, kEmptyVoxelHi);
   for (int i = wave; i < n; i += n_waves) {
     const int t = ids[i];
     const int ptr = hash[t].ptr;
+    int slot = 0;
+    if (lane == 0) {
+      slot = slot_of_entry[t];
+      if (slot < 0) {
+        slot = atomicAdd(&cnt->next_slot, 1);
+        slot_of_entry[t] = slot;
+      }
+    }
+    slot = __builtin_amdgcn_readfirstlane(slot);
     uint4 *blk = voxels16 + (size_t)ptr * (kBlock3 / 2);
-    uint4 *dst = stored_block(slabs, slots[i]);
+    uint4 *dst = stored_block(slabs, slot);
 #pragma unroll
     for (int j = 0; j < 4; j++) {
       dst[j * 64 + lane] = blk[j * 64 + lane];
@@ -569,30 +586,38 @@ __global__ __launch_bounds__(256) void k_swap_pack(const int *__restrict__ ids, 
   }
 }
 
-__global__ void k_add_last_free(SceneCounters *cnt, int n, int add_slid) {
+__global__ void k_add_last_free(SceneCounters *cnt, const int *n_dev, int n_host, int add_slid, int set_stats) {
   if (threadIdx.x == 0 && blockIdx.x == 0) {
+    const int n = n_dev ? *n_dev : n_host;
     cnt->last_free += n;
     if (add_slid) cnt->slid_blocks += n;
+    if (set_stats) cnt->swapped_out = n;
   }
 }
 
-// select (ordered, capped at the transfer-buffer size) and bring ids + count to the host
+__global__ void k_set_swap_stats(SceneCounters *cnt, int in, int out) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) { cnt->swapped_in = in; cnt->swapped_out = out; }
+}
+
+// select (ordered, capped at the transfer size): the list in m.cand_list, its length in counters->swap_count
 template <int MODE>
-static int swap_select_to_host(dslam_engine *e, dslam_scene *s, const unsigned char *vis_type, const MaintScratch &m,
-                               int *out_count) {
+static int swap_select(dslam_engine *e, dslam_scene *s, const unsigned char *vis_type, const MaintScratch &m) {
   const int N = s->n_entries, n_tiles = num_tiles(N);
   hipLaunchKernelGGL(k_swap_select<MODE>, dim3(n_tiles), dim3(256), 0, e->stream, s->hash, N, s->swap_state, vis_type,
                      m.cand_flags, e->tile_counts);
-  hipLaunchKernelGGL(k_scan_count, dim3(1), dim3(1024), 0, e->stream, e->tile_counts, e->tile_offsets, n_tiles,
-                     &s->counters->swap_count, kTransferBlocks);
-  hipLaunchKernelGGL(k_compact_apply, dim3(n_tiles), dim3(256), 0, e->stream, m.cand_flags, N, e->tile_offsets,
-                     m.cand_list, kTransferBlocks);
+  hipLaunchKernelGGL(k_compact_apply_fused, dim3(n_tiles), dim3(256), 0, e->stream, m.cand_flags, N, e->tile_counts,
+                     m.cand_list, kTransferBlocks, &s->counters->swap_count);
   DSLAM_HIP(hipGetLastError());
-  // count and ids travel together (16 KiB at most): one wait instead of two
+  return DSLAM_OK;
+}
+// the same, and the length brought to the host (the flush loops until nothing is selected)
+template <int MODE>
+static int swap_select_to_host(dslam_engine *e, dslam_scene *s, const unsigned char *vis_type, const MaintScratch &m,
+                               int *out_count) {
+  int rc = swap_select<MODE>(e, s, vis_type, m);
+  if (rc) return rc;
   int *host_count = reinterpret_cast<int *>(e->pinned) + 48;
   DSLAM_HIP(hipMemcpyAsync(host_count, &s->counters->swap_count, sizeof(int), hipMemcpyDeviceToHost, e->stream));
-  DSLAM_HIP(hipMemcpyAsync(s->transfer_ids_host, m.cand_list, (size_t)kTransferBlocks * sizeof(int), hipMemcpyDeviceToHost,
-                           e->stream));
   DSLAM_HIP(hipStreamSynchronize(e->stream));
   *out_count = *host_count;
   return DSLAM_OK;
@@ -610,74 +635,64 @@ static int add_slab(dslam_engine *e, dslam_scene *s) {
   return DSLAM_OK;
 }
 
-// slots of ids[0..n) into the second half of the pinned id buffer and on to the device; `assign`: entries without a
-// host copy get the next free slot (swap-out), otherwise they keep -1 (swap-in of an entry that was never stored)
-static int batch_slots_to_device(dslam_engine *e, dslam_scene *s, int n, bool assign, int *slots_dev) {
-  const int *ids = s->transfer_ids_host;
-  int *slots = s->transfer_ids_host + kTransferBlocks;
-  for (int i = 0; i < n; i++) {
-    int slot = s->slot_host[ids[i]];
-    if (slot < 0 && assign) {
-      slot = s->next_slot++;
-      while ((slot >> kSlabShift) >= (int)s->slabs.size()) {
-        int rc = add_slab(e, s);
-        if (rc) return rc;
-      }
-      s->slot_host[ids[i]] = slot;
-    }
-    slots[i] = slot;
+// Slabs for every slot the batch about to be queued may hand out (`need` at most).  The slot counter lives on the device;
+// a copy of it is queued behind every packing batch, so whenever the stream has drained (always, between synchronous
+// calls) the host knows it exactly; in between it counts with the upper bound and only waits when that bound runs
+// into the end of the slabs.
+static int ensure_slots(dslam_engine *e, dslam_scene *s, int need) {
+  if (hipStreamQuery(e->stream) == hipSuccess) s->slot_bound = *s->next_slot_host;
+  (void)hipGetLastError();  // (hipErrorNotReady is an answer, not a failure)
+  while (s->slot_bound + need > (long long)s->slabs.size() * kSlabBlocks) {
+    DSLAM_HIP(hipStreamSynchronize(e->stream));
+    if (*s->next_slot_host < s->slot_bound) { s->slot_bound = *s->next_slot_host; continue; }
+    int rc = add_slab(e, s);
+    if (rc) return rc;
   }
-  DSLAM_HIP(hipMemcpyAsync(slots_dev, slots, (size_t)n * sizeof(int), hipMemcpyHostToDevice, e->stream));
   return DSLAM_OK;
 }
 
-// merge the host copies of ids[0..n) (ids in m.cand_list and in the pinned id buffer) into the map
-static int merge_from_host(dslam_engine *e, dslam_scene *s, const MaintScratch &m, int n) {
-  int *slots_dev = m.rem_list;  // free int scratch
-  int rc = batch_slots_to_device(e, s, n, false, slots_dev);
-  if (rc) return rc;
-  hipLaunchKernelGGL(k_swap_merge, dim3(1024), dim3(256), 0, e->stream, m.cand_list, slots_dev, n, s->hash,
-                     reinterpret_cast<uint4 *>(s->voxels), s->slab_ptrs_dev, s->swap_state, s->p.max_w);
+// merge the host copies of the listed entries (m.cand_list) into the map; n_dev: length on the device, else n_host
+static int merge_from_host(dslam_engine *e, dslam_scene *s, const MaintScratch &m, const int *n_dev, int n_host,
+                           bool set_stats) {
+  hipLaunchKernelGGL(k_swap_merge, dim3(1024), dim3(256), 0, e->stream, m.cand_list, s->slot_dev, n_dev, n_host, s->hash,
+                     reinterpret_cast<uint4 *>(s->voxels), s->slab_ptrs_dev, s->swap_state, s->p.max_w,
+                     set_stats ? s->counters : nullptr);
   DSLAM_HIP(hipGetLastError());
-  // no wait here: the pinned id / slot buffer is next written by the host only after the next selection's wait, and
-  // by the device only in stream order
   return DSLAM_OK;
 }
 
-// write ids[0..n) (in m.cand_list and in the pinned id buffer) to the host store and release their voxel blocks
-static int pack_to_host(dslam_engine *e, dslam_scene *s, unsigned char *vis_type, const MaintScratch &m, int n,
-                        int add_slid) {
-  int *slots_dev = m.rem_list;
-  int rc = batch_slots_to_device(e, s, n, true, slots_dev);
+// write the listed entries' blocks to the host store and release their voxel blocks (at most `upper` of them)
+static int pack_to_host(dslam_engine *e, dslam_scene *s, unsigned char *vis_type, const MaintScratch &m, const int *n_dev,
+                        int n_host, int upper, int add_slid, bool set_stats) {
+  int rc = ensure_slots(e, s, upper);
   if (rc) return rc;
-  hipLaunchKernelGGL(k_swap_pack, dim3(1024), dim3(256), 0, e->stream, m.cand_list, slots_dev, n, s->hash,
+  hipLaunchKernelGGL(k_swap_pack, dim3(1024), dim3(256), 0, e->stream, m.cand_list, s->slot_dev, n_dev, n_host, s->hash,
                      reinterpret_cast<uint4 *>(s->voxels), s->slab_ptrs_dev, s->alloc_list, s->masks,
                      s->last_seen, s->history_words, s->swap_state, vis_type, s->counters);
-  hipLaunchKernelGGL(k_add_last_free, dim3(1), dim3(64), 0, e->stream, s->counters, n, add_slid);
+  hipLaunchKernelGGL(k_add_last_free, dim3(1), dim3(64), 0, e->stream, s->counters, n_dev, n_host, add_slid,
+                     set_stats ? 1 : 0);
   DSLAM_HIP(hipGetLastError());
-  return DSLAM_OK;  // (no wait: see merge_from_host; readers of the host store synchronise first)
+  DSLAM_HIP(hipMemcpyAsync(s->next_slot_host, &s->counters->next_slot, sizeof(int), hipMemcpyDeviceToHost, e->stream));
+  s->slot_bound += upper;
+  return DSLAM_OK;  // (no wait: readers of the host store synchronise first)
 }
 
+// ProcessFrame's two swap steps run entirely on the device: selection, list, slots, transfer -- no host round trip
+// (round 1 brought the ids to the host and the slots back, twice per keyframe)
 int launch_swap_in(dslam_engine *e, dslam_scene *s, dslam_render_state *) {
   int rc = ensure_scratch(e, s->n_entries, s->p.num_local_blocks);
   if (rc) return rc;
   const MaintScratch m = carve(e, s->n_entries);
-  int n = 0;
-  if ((rc = swap_select_to_host<0>(e, s, nullptr, m, &n))) return rc;
-  if (n > 0 && (rc = merge_from_host(e, s, m, n))) return rc;
-  s->last_swapped_in = n;
-  return DSLAM_OK;
+  if ((rc = swap_select<0>(e, s, nullptr, m))) return rc;
+  return merge_from_host(e, s, m, &s->counters->swap_count, 0, true);
 }
 
 int launch_swap_out(dslam_engine *e, dslam_scene *s, dslam_render_state *r, bool ignore_visibility) {
   int rc = ensure_scratch(e, s->n_entries, s->p.num_local_blocks);
   if (rc) return rc;
   const MaintScratch m = carve(e, s->n_entries);
-  int n = 0;
-  if ((rc = swap_select_to_host<2>(e, s, ignore_visibility ? nullptr : r->visible_type, m, &n))) return rc;
-  if (n > 0 && (rc = pack_to_host(e, s, nullptr, m, n, 0))) return rc;
-  s->last_swapped_out = n;
-  return DSLAM_OK;
+  if ((rc = swap_select<2>(e, s, ignore_visibility ? nullptr : r->visible_type, m))) return rc;
+  return pack_to_host(e, s, nullptr, m, &s->counters->swap_count, 0, kTransferBlocks, 0, true);
 }
 
 // Hansry's SaveToGlobalMemory(scene): merge everything pending, promote never-visible resident blocks, flush all
@@ -689,22 +704,22 @@ int launch_save_to_global(dslam_engine *e, dslam_scene *s) {
   while (true) {
     if ((rc = swap_select_to_host<0>(e, s, nullptr, m, &n))) return rc;
     if (n == 0) break;
-    if ((rc = merge_from_host(e, s, m, n))) return rc;
+    if ((rc = merge_from_host(e, s, m, nullptr, n, false))) return rc;
   }
-  s->last_swapped_in = 0;
   while (true) {
     if ((rc = swap_select_to_host<1>(e, s, nullptr, m, &n))) return rc;
     if (n == 0) break;
-    if ((rc = merge_from_host(e, s, m, n))) return rc;
+    if ((rc = merge_from_host(e, s, m, nullptr, n, false))) return rc;
   }
   int total = 0;
   while (true) {
     if ((rc = swap_select_to_host<2>(e, s, nullptr, m, &n))) return rc;
     if (n == 0) break;
-    if ((rc = pack_to_host(e, s, nullptr, m, n, 0))) return rc;
+    if ((rc = pack_to_host(e, s, nullptr, m, nullptr, n, n, 0, false))) return rc;
     total += n;
   }
-  s->last_swapped_out = total;
+  hipLaunchKernelGGL(k_set_swap_stats, dim3(1), dim3(64), 0, e->stream, s->counters, 0, total);
+  DSLAM_HIP(hipGetLastError());
   return DSLAM_OK;
 }
 
@@ -771,14 +786,12 @@ static int flags_to_host_batches(dslam_engine *e, dslam_scene *s, const unsigned
   return DSLAM_OK;
 }
 
-static int batch_ids_to_host(dslam_engine *e, dslam_scene *s, const unsigned char *flags, const MaintScratch &m, int skip,
-                             int n) {
+// the next batch of the flagged entries (hits skip .. skip + kTransferBlocks) into m.cand_list
+static int batch_ids(dslam_engine *e, dslam_scene *s, const unsigned char *flags, const MaintScratch &m, int skip) {
   const int N = s->n_entries, n_tiles = num_tiles(N);
   hipLaunchKernelGGL(k_compact_window, dim3(n_tiles), dim3(256), 0, e->stream, flags, N, e->tile_offsets, m.cand_list, skip,
                      kTransferBlocks);
   DSLAM_HIP(hipGetLastError());
-  DSLAM_HIP(hipMemcpyAsync(s->transfer_ids_host, m.cand_list, (size_t)n * sizeof(int), hipMemcpyDeviceToHost, e->stream));
-  DSLAM_HIP(hipStreamSynchronize(e->stream));
   return DSLAM_OK;
 }
 
@@ -819,16 +832,16 @@ int launch_slide_pop(dslam_engine *e, dslam_scene *s, dslam_render_state *r, int
   for (int done = 0; done < total; done += kTransferBlocks) {
     const int n = (total - done) < kTransferBlocks ? (total - done) : kTransferBlocks;
     // tile_offsets still hold the scan of the need-merge flags
-    if ((rc = batch_ids_to_host(e, s, m.cand_flags, m, done, n))) return rc;
-    if ((rc = merge_from_host(e, s, m, n))) return rc;
+    if ((rc = batch_ids(e, s, m.cand_flags, m, done))) return rc;
+    if ((rc = merge_from_host(e, s, m, nullptr, n, false))) return rc;
     // tile scan of cand_flags is unchanged by the merge; keep going
   }
   // (2) pack every leaving block to the host in batches
   if ((rc = flags_to_host_batches(e, s, leave, m, &total))) return rc;
   for (int done = 0; done < total; done += kTransferBlocks) {
     const int n = (total - done) < kTransferBlocks ? (total - done) : kTransferBlocks;
-    if ((rc = batch_ids_to_host(e, s, leave, m, done, n))) return rc;
-    if ((rc = pack_to_host(e, s, r ? r->visible_type : nullptr, m, n, 1))) return rc;
+    if ((rc = batch_ids(e, s, leave, m, done))) return rc;
+    if ((rc = pack_to_host(e, s, r ? r->visible_type : nullptr, m, nullptr, n, n, 1, false))) return rc;
   }
   if (r && total > 0) return rebuild_visible_list(e, r);
   return DSLAM_OK;
