@@ -153,6 +153,31 @@ __device__ __forceinline__ int new_weight(const IntegrateParams &p, float depth_
   return w < 1 ? 1 : (w > p.max_new_w ? p.max_new_w : w);
 }
 
+// The depth and colour images are read through buffer resources on the packed fusion path: a lane addresses its pixel
+// with a 32-bit byte offset (pixel indices are < 2^24: one 24-bit multiply and one add-shift instead of 64-bit address
+// arithmetic), and an offset outside the image -- only a lane whose voxel already failed a test can produce one --
+// reads 0 instead of having to be replaced by a safe index first.  Worth 0.5 us of a 21 us launch (and it is what
+// makes requesting the depth pixels of two chunks ahead of either update cheap, see pair_project).
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t image_rsrc(const void *base, int W, int H) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), 0, W * H * 4, 0x00020000);
+}
+__device__ __forceinline__ unsigned pixel_offset(int x, int y, int W) { return ((unsigned)__mul24(y, W) + (unsigned)x) << 2; }
+
+// bilinear_rgb below with its four texels fetched through `rs` (same arithmetic, same order)
+__device__ __forceinline__ void bilinear_rgb_buf(__amdgpu_buffer_rsrc_t rs, float px, float py, int W, float out[3]) {
+  const int ix = (int)floorf(px), iy = (int)floorf(py);
+  const float dx = px - (float)ix, dy = py - (float)iy;
+  const unsigned o = pixel_offset(ix, iy, W), o2 = o + ((unsigned)W << 2);
+  const unsigned a = __builtin_amdgcn_raw_buffer_load_b32(rs, o, 0, 0), b = __builtin_amdgcn_raw_buffer_load_b32(rs, o + 4u, 0, 0);
+  const unsigned c = __builtin_amdgcn_raw_buffer_load_b32(rs, o2, 0, 0), d = __builtin_amdgcn_raw_buffer_load_b32(rs, o2 + 4u, 0, 0);
+#pragma unroll
+  for (int k = 0; k < 3; k++) {
+    const float fa = (float)((a >> (8 * k)) & 0xffu), fb = (float)((b >> (8 * k)) & 0xffu);
+    const float fc = (float)((c >> (8 * k)) & 0xffu), fd = (float)((d >> (8 * k)) & 0xffu);
+    out[k] = (fa * (1.0f - dx) * (1.0f - dy) + fb * dx * (1.0f - dy) + fc * (1.0f - dx) * dy + fd * dx * dy);
+  }
+}
+
 __device__ __forceinline__ void bilinear_rgb(const uchar4 *__restrict__ rgba, float px, float py, int W, float out[3]) {
   const int ix = (int)floorf(px), iy = (int)floorf(py);
   const float dx = px - (float)ix, dy = py - (float)iy;
@@ -278,7 +303,8 @@ __device__ __forceinline__ f2 div_exact2(f2 a, float b, f2 y) {
 }
 
 // computeUpdatedVoxelColorInfo for one voxel (fusion); u, w = its projection into the colour image
-template <bool SAME_CAM>
+// BUF: the texels come through a buffer resource (bilinear_rgb_buf)
+template <bool SAME_CAM, bool BUF = false>
 __device__ __forceinline__ bool fuse_colour(unsigned &lo, unsigned &hi, float u, float w, const Vec4 &pm,
                                             const IntegrateParams &p, const float *inv_tab) {
   if (!SAME_CAM) {
@@ -288,7 +314,8 @@ __device__ __forceinline__ bool fuse_colour(unsigned &lo, unsigned &hi, float u,
     if (!in_image(u, w, (float)(p.Wr - 2), (float)(p.Hr - 2))) return false;
   }
   float m[3];
-  bilinear_rgb(p.rgba, u, w, p.Wr, m);
+  if constexpr (BUF) bilinear_rgb_buf(image_rsrc(p.rgba, p.Wr, p.Hr), u, w, p.Wr, m);
+  else bilinear_rgb(p.rgba, u, w, p.Wr, m);
   const unsigned oc[3] = {lo >> 24, hi & 0xffu, (hi >> 8) & 0xffu};
   const unsigned wc = (hi >> 16) & 0xffu;
   const float oldW = (float)wc;
@@ -311,15 +338,16 @@ __device__ __forceinline__ bool fuse_colour(unsigned &lo, unsigned &hi, float u,
 
 // The colour path is what a wavefront pays most for: only voxels in the narrow band |eta / mu| <= 0.25 take it (about
 // one in eight of the updated ones), but a wave64 executes it whenever ANY of its lanes does -- eight sparse executions of
-// ~70 instructions per block.  So the one-camera fusion kernel queues the band voxels of a half block in LDS (projection
-// + old colour, 16 bytes each), runs the colour update densely over the queue -- one voxel per lane, usually one pass --
-// and hands every result back through the same slot.  Same arithmetic per voxel, same bits.
+// ~70 instructions per block.  So the one-camera fusion kernel queues the band voxels of a half block in LDS (ColQueue:
+// projection + old colour), runs the colour update densely over the queue -- one voxel per lane, usually one pass --
+// and hands every result back through LDS.  Same arithmetic per voxel, same bits.
 // colour word: clr0 | clr1 << 8 | clr2 << 16 | w_color << 24
+template <bool BUF>
 __device__ __forceinline__ unsigned fuse_colour_word(unsigned pack, float u, float w, const IntegrateParams &p,
                                                      const float *inv_tab) {
   unsigned lo = pack << 24, hi = pack >> 8;
   const Vec4 unused = {0.0f, 0.0f, 0.0f, 1.0f};
-  fuse_colour<true>(lo, hi, u, w, unused, p, inv_tab);
+  fuse_colour<true, BUF>(lo, hi, u, w, unused, p, inv_tab);
   return (lo >> 24) | ((hi & 0xffffffu) << 8);
 }
 
@@ -401,22 +429,106 @@ __device__ __forceinline__ bool fuse_pair(uint4 &vv, f2 pcx, f2 pcy, f2 pcz, con
   return true;
 }
 
+// ---- fuse_pair in two steps (plain one-camera fusion: weight 1, no stopIntegratingAtMaxW) --------------------------------
+// A wave's serial chain per half block used to be  project chunk 0 -> read depth -> wait -> update -> project chunk 1 ->
+// read depth -> wait -> update.  Split, both chunks are projected and BOTH pairs of depth pixels requested before
+// either update waits for its pair: one exposed round trip per half block instead of two (20.7 -> 19.9 us per launch on
+// the bench scene; the waves are parked on memory for half of their lifetime, SQ_WAIT_ANY, so the chain is what counts).
+struct PairProj {
+  f2 u, w, pcz, dm;
+  bool act0, act1;
+};
+
+// Projection of the two voxels and the request for their depth pixels.  Branch-free: a voxel that fails a test keeps
+// computing (NaN included), is masked out by act0 / act1, and its read cannot leave the buffer.
+__device__ __forceinline__ void pair_project(PairProj &q, f2 pcx, f2 pcy, f2 pcz, const IntegrateParams &p,
+                                             __amdgpu_buffer_rsrc_t depth_rs) {
+  const f2 fx2 = {p.fx_d, p.fx_d}, fy2 = {p.fy_d, p.fy_d}, cx2 = {p.cx_d, p.cx_d}, cy2 = {p.cy_d, p.cy_d};
+  q.pcz = pcz;
+  q.u = div_ieee2(fx2 * pcx, pcz) + cx2;
+  q.w = div_ieee2(fy2 * pcy, pcz) + cy2;
+  const float wmax = (float)(p.Wd - 2), hmax = (float)(p.Hd - 2);
+  q.act0 = (pcz.x >= kMinCamZ) & in_image(q.u.x, q.w.x, wmax, hmax);
+  q.act1 = (pcz.y >= kMinCamZ) & in_image(q.u.y, q.w.y, wmax, hmax);
+  const f2 half = {0.5f, 0.5f};
+  const f2 ur = q.u + half, wr = q.w + half;
+  q.dm.x = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(depth_rs, pixel_offset((int)ur.x, (int)wr.x, p.Wd), 0, 0));
+  q.dm.y = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(depth_rs, pixel_offset((int)ur.y, (int)wr.y, p.Wd), 0, 0));
+}
+
+// The depth update of the two voxels (fuse_pair from `eta` on, with newW = 1); `cmask` as fuse_pair<., QUEUE> returns it
+__device__ __forceinline__ bool pair_update(uint4 &vv, const PairProj &q, const IntegrateParams &p, const float *inv_tab,
+                                            unsigned &cmask) {
+  cmask = 0;
+  const f2 eta = q.dm - q.pcz;
+  const bool act0 = q.act0 && !(q.dm.x <= 0.0f) && !(eta.x < -p.mu);
+  const bool act1 = q.act1 && !(q.dm.y <= 0.0f) && !(eta.y < -p.mu);
+  if (!(act0 || act1)) return false;
+  const f2 mu2 = {p.mu, p.mu};
+  const f2 eta_mu = div_ieee2(eta, mu2);
+  f2 sd;
+  sd.x = (float)(short)(vv.x & 0xffffu);
+  sd.y = (float)(short)(vv.z & 0xffffu);
+  const f2 inv32767 = {p.inv_32767, p.inv_32767};
+  const f2 oldF = div_exact2(sd, 32767.0f, inv32767);
+  const int oldW0 = (int)((vv.x >> 16) & 0xffu), oldW1 = (int)((vv.z >> 16) & 0xffu);
+  f2 newF;
+  newF.x = fminf(1.0f, eta_mu.x);
+  newF.y = fminf(1.0f, eta_mu.y);
+  f2 oW;
+  oW.x = (float)oldW0; oW.y = (float)oldW1;
+  f2 nf = oW * oldF + newF;  // oldW * oldF + newW * newF with newW = 1 (that product is exact: it is newF)
+  int nW0 = oldW0 + 1, nW1 = oldW1 + 1;
+  f2 nWf, inv;
+  nWf.x = (float)nW0; nWf.y = (float)nW1;
+  inv.x = inv_tab[nW0]; inv.y = inv_tab[nW1];
+  {  // div_exact with per-component divisors
+    const f2 qq = nf * inv;
+    const f2 r = __builtin_elementwise_fma(-nWf, qq, nf);
+    nf = __builtin_elementwise_fma(r, inv, qq);
+  }
+  nW0 = nW0 < p.max_w ? nW0 : p.max_w;
+  nW1 = nW1 < p.max_w ? nW1 : p.max_w;
+  const f2 scale = {32767.0f, 32767.0f};
+  const f2 sf = nf * scale;
+  if (act0) vv.x = (vv.x & 0xff000000u) | ((unsigned)nW0 << 16) | (unsigned)(unsigned short)(short)sf.x;
+  if (act1) vv.z = (vv.z & 0xff000000u) | ((unsigned)nW1 << 16) | (unsigned)(unsigned short)(short)sf.y;
+  const bool col0 = act0 && !((eta.x > p.mu) || (fabsf(eta_mu.x) > 0.25f));
+  const bool col1 = act1 && !((eta.y > p.mu) || (fabsf(eta_mu.y) > 0.25f));
+  cmask = (col0 ? 1u : 0u) | (col1 ? 2u : 0u);
+  return true;
+}
+
 constexpr int kMaxGroup = 8;
+constexpr int kIntegrateGrid = 2048;  // workgroups of 4 waves: one full residency wave of the 256 CUs
 
 // SAME_CAM: the RGB camera is the depth camera (identity calib, as the reference sets it up): the colour update
 // reuses the depth projection, and the kernel carries one matrix instead of two (the scalar register file does not
 // hold both without spilling to VGPR lanes).
-template <bool DEINT, bool SAME_CAM>
+// PLAIN: none of the optional features is in use -- stored list, shards, dirty marks, stopIntegratingAtMaxW, depth
+// weighting -- i.e. the per-frame fusion of the reference's configuration.  Compiled without them the kernel carries
+// fewer live arguments (36 scalar registers spilled to VGPR lanes instead of 72, a shorter preamble) and can afford the
+// split update (pair_project / pair_update): 22.9 -> 21.4 us for the specialisation, -> 19.9 us with the split.
+template <bool DEINT, bool SAME_CAM, bool PLAIN = false>
 __global__ __launch_bounds__(256, 8) void k_integrate(IntegrateParams p) {
+  static_assert(!PLAIN || (!DEINT && SAME_CAM && DSLAM_PACKED && DSLAM_COLOUR_QUEUE), "PLAIN is the queued one-camera fusion");
   __shared__ float inv_tab[kInvTab];
   // the one-camera fusion variant runs its colour updates densely from a per-wave LDS queue (fuse_colour_word)
   constexpr bool kQueueColour = !DEINT && SAME_CAM && DSLAM_PACKED && DSLAM_COLOUR_QUEUE;
-  __shared__ uint4 col_q[kQueueColour ? 4 : 1][kQueueColour ? kColQueue : 1];
+  // The queue of one wave.  The data of a queued voxel sits at the voxel's OWN place (chunk-voxel k of lane l: k * 64 + l:
+  // no address arithmetic for its owner, neither to queue it nor to fetch the result), `list` holds the places in queue
+  // order, and the result comes back at the same place.  4.25 KiB per wave: 19 KiB per workgroup with the table.
+  struct ColQueue {
+    float u[kColQueue], w[kColQueue];
+    unsigned c[kColQueue], r[kColQueue];
+    unsigned char list[kColQueue];
+  };
+  __shared__ ColQueue col_q[kQueueColour ? 4 : 1];
   for (int i = threadIdx.x; i < kInvTab; i += 256) inv_tab[i] = 1.0f / (float)i;  // IEEE division: RN(1/i)
   __syncthreads();
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane((int)((blockIdx.x * 256 + threadIdx.x) >> 6));
-  const int n_waves = gridDim.x * 4;
+  constexpr int n_waves = kIntegrateGrid * 4;  // (the launch below uses exactly this grid)
   const int nvis = p.rc->no_visible;
   if (p.timer_slot && blockIdx.x == 0 && threadIdx.x == 0) *p.timer_slot = nvis;
   int G = (nvis + n_waves - 1) / n_waves;
@@ -436,7 +548,7 @@ __global__ __launch_bounds__(256, 8) void k_integrate(IntegrateParams p) {
     if (lane < G && base + lane < nvis) {
       const HashEntry e = load_entry(p.hash, p.visible_ids[base + lane]);
       e_ptr = e.ptr; e_px = e.pos[0]; e_py = e.pos[1]; e_pz = e.pos[2];
-      if (p.expect_pos) {  // a list stored with a keyframe: the entry must still hold the block it held then
+      if (!PLAIN && p.expect_pos) {  // a list stored with a keyframe: the entry must still hold the block it held then
         const short4 ep = p.expect_pos[base + lane];
         if (ep.x != e.pos[0] || ep.y != e.pos[1] || ep.z != e.pos[2]) e_ptr = -2;
       }
@@ -446,10 +558,12 @@ __global__ __launch_bounds__(256, 8) void k_integrate(IntegrateParams p) {
           p.masks[((size_t)ptr * 2 + p.push_ring) * p.push_words + (p.push_bit >> 6)] |= 1ull << (p.push_bit & 63);
           p.last_seen[ptr] = p.push_frame;
         }
-        // (before the shard test: every rank of a sharded batch ends up with the same set of marks)
-        if (p.dirty) p.dirty[ptr] = 1;
-        if (p.num_shards > 1 && ((ptr / p.chunk_blocks) % p.num_shards) != p.shard) e_ptr = -3;
-        if (p.shard_count >= 0 && (ptr < p.shard_first || ptr >= p.shard_first + p.shard_count)) e_ptr = -3;
+        if constexpr (!PLAIN) {
+          // (before the shard test: every rank of a sharded batch ends up with the same set of marks)
+          if (p.dirty) p.dirty[ptr] = 1;
+          if (p.num_shards > 1 && ((ptr / p.chunk_blocks) % p.num_shards) != p.shard) e_ptr = -3;
+          if (p.shard_count >= 0 && (ptr < p.shard_first || ptr >= p.shard_first + p.shard_count)) e_ptr = -3;
+        }
       }
     }
     for (int k = 0; k < G; k++) {
@@ -480,9 +594,49 @@ __global__ __launch_bounds__(256, 8) void k_integrate(IntegrateParams p) {
       v[0] = blk[(half * 2) * 64 + lane];
       v[1] = blk[(half * 2 + 1) * 64 + lane];
       bool chs[2] = {false, false};
-      [[maybe_unused]] int q_n = 0;          // queued colour updates of this half (wave-uniform)
-      [[maybe_unused]] unsigned q_slots = 0; // this lane's slots, 8 bits per (chunk, voxel); q_mine: which of the four it has
-      [[maybe_unused]] unsigned q_mine = 0;
+      [[maybe_unused]] int q_n = 0;                    // queued colour updates of this half (wave-uniform)
+      [[maybe_unused]] unsigned cms[2] = {0u, 0u};     // per chunk: which of the lane's two voxels are queued
+      // queue the narrow-band voxels of chunk jj (cm: bit h = voxel h) with their projections
+      [[maybe_unused]] auto queue_colour = [&](int jj, unsigned cm, f2 uo, f2 wo) {
+        cms[jj] = cm;
+        if (!__ballot(cm != 0u)) return;  // (most chunks of a block far from the surface queue nothing)
+        ColQueue &Q = col_q[threadIdx.x >> 6];
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+          const bool c = (cm >> h) & 1u;
+          const unsigned long long bm = __ballot(c);
+          if (c) {
+            const unsigned lo = h ? v[jj].z : v[jj].x, hi = h ? v[jj].w : v[jj].y;
+            const int own = (jj * 2 + h) * 64 + lane;
+            const int slot = q_n + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(bm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bm, 0u));
+            Q.u[own] = h ? uo.y : uo.x;
+            Q.w[own] = h ? wo.y : wo.x;
+            Q.c[own] = __builtin_amdgcn_perm(hi, lo, 0x06050403u);  // clr0 | clr1 << 8 | clr2 << 16 | w_color << 24
+            Q.list[slot] = (unsigned char)own;
+          }
+          q_n += __popcll(bm);
+        }
+      };
+      if constexpr (PLAIN) {
+        // both chunks projected and their depth pixels requested, then both updated (see pair_project)
+        PairProj pq[2];
+        const __amdgpu_buffer_rsrc_t depth_rs = image_rsrc(p.depth, p.Wd, p.Hd);
+#pragma unroll
+        for (int jj = 0; jj < 2; jj++) {
+          const float fz = (float)(gz + (half * 2 + jj) * 2 + vz0) * p.voxel_size;
+          const float az0 = p.M_d.m[8] * fz, az1 = p.M_d.m[9] * fz, az2 = p.M_d.m[10] * fz;
+          const f2 a0 = {az0, az0}, a1 = {az1, az1}, a2 = {az2, az2};
+          const f2 t0 = {p.M_d.m[12], p.M_d.m[12]}, t1 = {p.M_d.m[13], p.M_d.m[13]}, t2 = {p.M_d.m[14], p.M_d.m[14]};
+          const f2 px = {pxy[0][0], pxy[1][0]}, py = {pxy[0][1], pxy[1][1]}, pz = {pxy[0][2], pxy[1][2]};
+          pair_project(pq[jj], (px + a0) + t0, (py + a1) + t1, (pz + a2) + t2, p, depth_rs);
+        }
+#pragma unroll
+        for (int jj = 0; jj < 2; jj++) {
+          unsigned cm;
+          chs[jj] = pair_update(v[jj], pq[jj], p, inv_tab, cm);
+          queue_colour(jj, cm, pq[jj].u, pq[jj].w);
+        }
+      } else
 #pragma unroll
       for (int jj = 0; jj < 2; jj++) {
         const int j = half * 2 + jj;
@@ -499,21 +653,7 @@ __global__ __launch_bounds__(256, 8) void k_integrate(IntegrateParams p) {
             unsigned cm;
             f2 uo, wo;
             ch = fuse_pair<SAME_CAM, true>(v[jj], (px + a0) + t0, (py + a1) + t1, (pz + a2) + t2, pm0, pm1, p, inv_tab, &cm, &uo, &wo);
-            if (__ballot(cm != 0u))  // (most chunks of a block far from the surface queue nothing)
-#pragma unroll
-            for (int h = 0; h < 2; h++) {
-              const bool c = (cm >> h) & 1u;
-              const unsigned long long bm = __ballot(c);
-              if (c) {
-                const unsigned lo = h ? v[jj].z : v[jj].x, hi = h ? v[jj].w : v[jj].y;
-                const int slot = q_n + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(bm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bm, 0u));
-                col_q[threadIdx.x >> 6][slot] = make_uint4(__float_as_uint(h ? uo.y : uo.x), __float_as_uint(h ? wo.y : wo.x),
-                                                           (lo >> 24) | ((hi & 0xffffffu) << 8), 0u);
-                q_slots |= (unsigned)slot << (8 * (jj * 2 + h));
-                q_mine |= 1u << (jj * 2 + h);
-              }
-              q_n += __popcll(bm);
-            }
+            queue_colour(jj, cm, uo, wo);
           } else {
             ch = fuse_pair<SAME_CAM>(v[jj], (px + a0) + t0, (py + a1) + t1, (pz + a2) + t2, pm0, pm1, p, inv_tab);
           }
@@ -534,23 +674,25 @@ __global__ __launch_bounds__(256, 8) void k_integrate(IntegrateParams p) {
         chs[jj] = ch;
       }
       if constexpr (kQueueColour) {
-        // the queued colour updates, one per lane; the result replaces the old colour word in the entry's slot
-        uint4 *q = col_q[threadIdx.x >> 6];
-        for (int i = lane; i < q_n; i += 64) {
-          const uint4 en = q[i];
-          q[i].z = fuse_colour_word(en.z, __uint_as_float(en.x), __uint_as_float(en.y), p, inv_tab);
+        if (q_n > 0) {
+          // the queued colour updates, one per lane; every result goes back to the place of its voxel
+          ColQueue &Q = col_q[threadIdx.x >> 6];
+          for (int i = lane; i < q_n; i += 64) {
+            const int o = Q.list[i];
+            Q.r[o] = fuse_colour_word<PLAIN>(Q.c[o], Q.u[o], Q.w[o], p, inv_tab);  // (the general variant has no scalar registers to spare for a second buffer resource)
+          }
+#pragma unroll
+          for (int jj = 0; jj < 2; jj++)
+#pragma unroll
+            for (int h = 0; h < 2; h++)
+              if ((cms[jj] >> h) & 1u) {
+                const unsigned word = Q.r[(jj * 2 + h) * 64 + lane];
+                unsigned &lo = h ? v[jj].z : v[jj].x;
+                unsigned &hi = h ? v[jj].w : v[jj].y;
+                lo = __builtin_amdgcn_perm(word, lo, 0x04020100u);  // (lo & 0x00ffffff) | word << 24
+                hi = __builtin_amdgcn_perm(hi, word, 0x07030201u);  // (hi & 0xff000000) | word >> 8
+              }
         }
-#pragma unroll
-        for (int jj = 0; jj < 2; jj++)
-#pragma unroll
-          for (int h = 0; h < 2; h++)
-            if ((q_mine >> (jj * 2 + h)) & 1u) {
-              const unsigned word = q[(q_slots >> (8 * (jj * 2 + h))) & 0xffu].z;
-              unsigned &lo = h ? v[jj].z : v[jj].x;
-              unsigned &hi = h ? v[jj].w : v[jj].y;
-              lo = (lo & 0x00ffffffu) | (word << 24);
-              hi = (hi & 0xff000000u) | (word >> 8);
-            }
       }
 #pragma unroll
       for (int jj = 0; jj < 2; jj++)
@@ -584,8 +726,6 @@ static void fill_params(IntegrateParams &ip, dslam_engine *e, dslam_scene *s, co
   ip.expect_pos = nullptr;
 }
 
-constexpr int kIntegrateGrid = 2048;
-
 static int launch_integrate_params(dslam_engine *e, IntegrateParams &ip, bool deintegrate) {
   ip.timer_slot = nullptr;
   // Timed launches (bench roofline) attach their two events to the dispatch packet itself (hipExtLaunchKernelGGL), so
@@ -604,7 +744,10 @@ static int launch_integrate_params(dslam_engine *e, IntegrateParams &ip, bool de
     if (ip.same_cam) hipExtLaunchKernelGGL((k_integrate<true, true>), grid, block, 0, e->stream, ev0, ev1, 0, ip);
     else hipExtLaunchKernelGGL((k_integrate<true, false>), grid, block, 0, e->stream, ev0, ev1, 0, ip);
   } else {
-    if (ip.same_cam) hipExtLaunchKernelGGL((k_integrate<false, true>), grid, block, 0, e->stream, ev0, ev1, 0, ip);
+    const bool plain = DSLAM_PACKED && DSLAM_COLOUR_QUEUE && ip.same_cam && !ip.expect_pos && ip.num_shards <= 1 &&
+                       ip.shard_count < 0 && !ip.dirty && !ip.stop_max && !ip.depth_weighting;
+    if (plain) hipExtLaunchKernelGGL((k_integrate<false, true, DSLAM_PACKED && DSLAM_COLOUR_QUEUE>), grid, block, 0, e->stream, ev0, ev1, 0, ip);
+    else if (ip.same_cam) hipExtLaunchKernelGGL((k_integrate<false, true>), grid, block, 0, e->stream, ev0, ev1, 0, ip);
     else hipExtLaunchKernelGGL((k_integrate<false, false>), grid, block, 0, e->stream, ev0, ev1, 0, ip);
   }
   DSLAM_HIP(hipGetLastError());
