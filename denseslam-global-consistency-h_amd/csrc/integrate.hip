@@ -58,6 +58,7 @@ struct IntegrateParams {
   int *timer_slot;  // bench instrumentation: where to record this launch's visible-block count (or null)
   unsigned char *dirty;  // sharded re-integration: per slot "visited since tracking began" (null: not tracked)
   const short4 *expect_pos;  // stored keyframe list: the block each listed entry held at fusion time (null: a live list)
+  int spec_ids;  // the id list has a slot for every wave of the grid: a wave may read "its" id before the count is known
 };
 
 // a / b for a divisor whose correctly rounded reciprocal y = RN(1/b) is known: q = RN(a*y), r = a - b*q (exact, FMA),
@@ -96,6 +97,16 @@ __device__ __forceinline__ f2 div_ieee2(f2 a, f2 b) {
   return __builtin_elementwise_fma(t, r, q);
 }
 
+// RN(1 / i) for the integer weights of the table: the hardware reciprocal (1 ulp) and one Newton step.  Equal to the IEEE
+// quotient 1.0f / i for every i of the table -- for every i up to 65535 in fact (k_selftest_division counts the
+// differences on the device, tests/test_gpu_parity.py) -- in 3 instructions instead of the 12 of a division, at the top
+// of a kernel whose 8192 waves all start with this.
+__device__ __forceinline__ float recip_table_entry(int i) {
+  const float b = (float)i;
+  const float y = __builtin_amdgcn_rcpf(b);
+  return __fmaf_rn(__fmaf_rn(-b, y, 1.0f), y, y);
+}
+
 // random operands in the kernel's ranges: projection (|a| in 2^[-20,24], b in 2^[-10,10]) and eta / mu
 // (|a| in 2^[-30,8], b in [2^-10, 1])
 __global__ __launch_bounds__(256) void k_selftest_division(unsigned long long seed, int per_thread, unsigned long long *mismatches) {
@@ -117,6 +128,10 @@ __global__ __launch_bounds__(256) void k_selftest_division(unsigned long long se
     const float n0 = a.x / b.x, n1 = a.y / b.y;
     bad += (__float_as_uint(q.x) != __float_as_uint(n0)) + (__float_as_uint(q.y) != __float_as_uint(n1));
   }
+  // the reciprocal table of k_integrate: every entry against the IEEE division (entry 0 is never read)
+  if (blockIdx.x == 0)
+    for (int i = 1 + (int)threadIdx.x; i < 65536; i += 256)
+      bad += __float_as_uint(recip_table_entry(i)) != __float_as_uint(1.0f / (float)i);
   if (bad) atomicAdd(mismatches, (unsigned long long)bad);
 }
 
@@ -493,8 +508,10 @@ __device__ __forceinline__ bool pair_update(uint4 &vv, const PairProj &q, const 
   const f2 sf = nf * scale;
   if (act0) vv.x = (vv.x & 0xff000000u) | ((unsigned)nW0 << 16) | (unsigned)(unsigned short)(short)sf.x;
   if (act1) vv.z = (vv.z & 0xff000000u) | ((unsigned)nW1 << 16) | (unsigned)(unsigned short)(short)sf.y;
-  const bool col0 = act0 && !((eta.x > p.mu) || (fabsf(eta_mu.x) > 0.25f));
-  const bool col1 = act1 && !((eta.y > p.mu) || (fabsf(eta_mu.y) > 0.25f));
+  // upstream skips the colour when `eta > mu || fabs(eta / mu) > 0.25`.  With mu > 0, eta > mu makes the exact quotient
+  // exceed 1, so its rounding is >= 1 > 0.25: the first test never decides anything the second does not already
+  const bool col0 = act0 && !(fabsf(eta_mu.x) > 0.25f);
+  const bool col1 = act1 && !(fabsf(eta_mu.y) > 0.25f);
   cmask = (col0 ? 1u : 0u) | (col1 ? 2u : 0u);
   return true;
 }
@@ -524,11 +541,21 @@ __global__ __launch_bounds__(256, 8) void k_integrate(IntegrateParams p) {
     unsigned char list[kColQueue];
   };
   __shared__ ColQueue col_q[kQueueColour ? 4 : 1];
-  for (int i = threadIdx.x; i < kInvTab; i += 256) inv_tab[i] = 1.0f / (float)i;  // IEEE division: RN(1/i)
+  for (int i = threadIdx.x; i < kInvTab; i += 256) inv_tab[i] = recip_table_entry(i);  // = RN(1 / i)
   __syncthreads();
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane((int)((blockIdx.x * 256 + threadIdx.x) >> 6));
   constexpr int n_waves = kIntegrateGrid * 4;  // (the launch below uses exactly this grid)
+  // With at most one block per wave (G = 1: the bench's 7.9 k blocks on 8192 waves) wave w takes list entry w, so that
+  // id is requested BEFORE the list length is known and the two loads travel together.  (`zero` is opaque to the
+  // compiler: with a provably uniform address it would make this a scalar load and wait for it on the spot.)
+  // (PLAIN only: the other variants have no register to carry it in)
+  [[maybe_unused]] int id_spec = 0;
+  if (PLAIN && p.spec_ids && lane == 0) {
+    int zero;
+    asm volatile("v_mov_b32 %0, 0" : "=v"(zero));
+    id_spec = p.visible_ids[wave + zero];
+  }
   const int nvis = p.rc->no_visible;
   if (p.timer_slot && blockIdx.x == 0 && threadIdx.x == 0) *p.timer_slot = nvis;
   int G = (nvis + n_waves - 1) / n_waves;
@@ -546,7 +573,7 @@ __global__ __launch_bounds__(256, 8) void k_integrate(IntegrateParams p) {
     // all, leaves 28 spills instead of 72 and is SLOWER, 22.8 us: the loads sit on every wave's critical path.)
     int e_ptr = -2, e_px = 0, e_py = 0, e_pz = 0;
     if (lane < G && base + lane < nvis) {
-      const HashEntry e = load_entry(p.hash, p.visible_ids[base + lane]);
+      const HashEntry e = load_entry(p.hash, (PLAIN && p.spec_ids && G == 1) ? id_spec : p.visible_ids[base + lane]);
       e_ptr = e.ptr; e_px = e.pos[0]; e_py = e.pos[1]; e_pz = e.pos[2];
       if (!PLAIN && p.expect_pos) {  // a list stored with a keyframe: the entry must still hold the block it held then
         const short4 ep = p.expect_pos[base + lane];
@@ -555,7 +582,10 @@ __global__ __launch_bounds__(256, 8) void k_integrate(IntegrateParams p) {
       if (e_ptr >= 0) {
         const int ptr = e_ptr;
         if (p.push_words) {  // queue this block on the visible-list ring (one lane per block: no race)
-          p.masks[((size_t)ptr * 2 + p.push_ring) * p.push_words + (p.push_bit >> 6)] |= 1ull << (p.push_bit & 63);
+          unsigned long long *word = &p.masks[((size_t)ptr * 2 + p.push_ring) * p.push_words + (p.push_bit >> 6)];
+          // (PLAIN: an atomic OR whose result nobody reads -- nothing to wait for in front of the block loads)
+          if constexpr (PLAIN) __hip_atomic_fetch_or(word, 1ull << (p.push_bit & 63), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          else *word |= 1ull << (p.push_bit & 63);
           p.last_seen[ptr] = p.push_frame;
         }
         if constexpr (!PLAIN) {
@@ -724,6 +754,7 @@ static void fill_params(IntegrateParams &ip, dslam_engine *e, dslam_scene *s, co
   ip.shard_first = s->shard_first; ip.shard_count = s->shard_count;
   ip.dirty = s->dirty_tracking ? s->dirty : nullptr;
   ip.expect_pos = nullptr;
+  ip.spec_ids = 0;
 }
 
 static int launch_integrate_params(dslam_engine *e, IntegrateParams &ip, bool deintegrate) {
@@ -762,6 +793,7 @@ int launch_integrate(dslam_engine *e, dslam_scene *s, const dslam_view *v, const
   IntegrateParams ip;
   fill_params(ip, e, s, v, r, M_d, intr_d, M_rgb, intr_rgb);
   ip.masks = s->masks; ip.last_seen = s->last_seen; ip.push_words = 0; ip.push_ring = 0; ip.push_bit = 0; ip.push_frame = 0;
+  ip.spec_ids = r->n_local >= kIntegrateGrid * 4 ? 1 : 0;  // (a visible list has room for every voxel-block slot)
   if (push_ring >= 0) {
     if ((rc = prepare_push_visible_list(e, s, push_ring, &ip.push_bit, &ip.push_frame))) return rc;
     ip.push_words = s->history_words; ip.push_ring = push_ring;
