@@ -12,7 +12,7 @@
 //   with one vector load each (16 B, the table stays in the Infinity Cache) and the wave then walks them with
 //   v_readlane -- no per-block dependent scalar-load chain.  Depth / RGB gathers hit L2 (1.2 MB images).
 //   Only 16-byte chunks that changed are written back.
-//   Grid = fixed 2048 workgroups of 4 waves (one full residency wave of the 256 CUs), grid-stride over the
+//   Grid = fixed 512 workgroups of 16 waves (one full residency wave of the 256 CUs), grid-stride over the
 //   visible list whose length is read from device memory (no host round trip after allocation).
 #include <hip/hip_ext.h>
 
@@ -517,7 +517,12 @@ __device__ __forceinline__ bool pair_update(uint4 &vv, const PairProj &q, const 
 }
 
 constexpr int kMaxGroup = 8;
-constexpr int kIntegrateGrid = 2048;  // workgroups of 4 waves: one full residency wave of the 256 CUs
+// 8192 waves = one full residency wave of the 256 CUs (8 per SIMD), as 512 workgroups of 16 waves: two per CU.  (2048
+// workgroups of 4 waves: 0.35 us slower per launch -- four times the workgroups to dispatch and tables to fill.  A
+// workgroup barrier between the entry gathers and the block loads, so that no wave's small dependent loads queue behind
+// its neighbours' kilobytes, was measured too, with 4 and with 16 waves: +0.6 ... 0.9 us.)
+constexpr int kWgWaves = 16;
+constexpr int kIntegrateGrid = 8192 / kWgWaves;
 
 // SAME_CAM: the RGB camera is the depth camera (identity calib, as the reference sets it up): the colour update
 // reuses the depth projection, and the kernel carries one matrix instead of two (the scalar register file does not
@@ -527,25 +532,25 @@ constexpr int kIntegrateGrid = 2048;  // workgroups of 4 waves: one full residen
 // fewer live arguments (36 scalar registers spilled to VGPR lanes instead of 72, a shorter preamble) and can afford the
 // split update (pair_project / pair_update): 22.9 -> 21.4 us for the specialisation, -> 19.9 us with the split.
 template <bool DEINT, bool SAME_CAM, bool PLAIN = false>
-__global__ __launch_bounds__(256, 8) void k_integrate(IntegrateParams p) {
+__global__ __launch_bounds__(kWgWaves * 64, 8) void k_integrate(IntegrateParams p) {
   static_assert(!PLAIN || (!DEINT && SAME_CAM && DSLAM_PACKED && DSLAM_COLOUR_QUEUE), "PLAIN is the queued one-camera fusion");
   __shared__ float inv_tab[kInvTab];
   // the one-camera fusion variant runs its colour updates densely from a per-wave LDS queue (fuse_colour_word)
   constexpr bool kQueueColour = !DEINT && SAME_CAM && DSLAM_PACKED && DSLAM_COLOUR_QUEUE;
   // The queue of one wave.  The data of a queued voxel sits at the voxel's OWN place (chunk-voxel k of lane l: k * 64 + l:
   // no address arithmetic for its owner, neither to queue it nor to fetch the result), `list` holds the places in queue
-  // order, and the result comes back at the same place.  4.25 KiB per wave: 19 KiB per workgroup with the table.
+  // order, and the result comes back at the same place.  4.25 KiB per wave: 70 KiB per 16-wave workgroup with the table (two workgroups per CU).
   struct ColQueue {
     float u[kColQueue], w[kColQueue];
     unsigned c[kColQueue], r[kColQueue];
     unsigned char list[kColQueue];
   };
-  __shared__ ColQueue col_q[kQueueColour ? 4 : 1];
-  for (int i = threadIdx.x; i < kInvTab; i += 256) inv_tab[i] = recip_table_entry(i);  // = RN(1 / i)
+  __shared__ ColQueue col_q[kQueueColour ? kWgWaves : 1];
+  for (int i = threadIdx.x; i < kInvTab; i += kWgWaves * 64) inv_tab[i] = recip_table_entry(i);  // = RN(1 / i)
   __syncthreads();
   const int lane = threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane((int)((blockIdx.x * 256 + threadIdx.x) >> 6));
-  constexpr int n_waves = kIntegrateGrid * 4;  // (the launch below uses exactly this grid)
+  const int wave = __builtin_amdgcn_readfirstlane((int)((blockIdx.x * (kWgWaves * 64) + threadIdx.x) >> 6));
+  constexpr int n_waves = kIntegrateGrid * kWgWaves;  // (the launch below uses exactly this grid)
   // With at most one block per wave (G = 1: the bench's 7.9 k blocks on 8192 waves) wave w takes list entry w, so that
   // id is requested BEFORE the list length is known and the two loads travel together.  (`zero` is opaque to the
   // compiler: with a provably uniform address it would make this a scalar load and wait for it on the spot.)
@@ -770,7 +775,7 @@ static int launch_integrate_params(dslam_engine *e, IntegrateParams &ip, bool de
     ev1 = e->ev_pool[e->ev_used + 1];
     e->ev_used += 2;
   }
-  const dim3 grid(kIntegrateGrid), block(256);
+  const dim3 grid(kIntegrateGrid), block(kWgWaves * 64);
   if (deintegrate) {
     if (ip.same_cam) hipExtLaunchKernelGGL((k_integrate<true, true>), grid, block, 0, e->stream, ev0, ev1, 0, ip);
     else hipExtLaunchKernelGGL((k_integrate<true, false>), grid, block, 0, e->stream, ev0, ev1, 0, ip);
@@ -793,7 +798,7 @@ int launch_integrate(dslam_engine *e, dslam_scene *s, const dslam_view *v, const
   IntegrateParams ip;
   fill_params(ip, e, s, v, r, M_d, intr_d, M_rgb, intr_rgb);
   ip.masks = s->masks; ip.last_seen = s->last_seen; ip.push_words = 0; ip.push_ring = 0; ip.push_bit = 0; ip.push_frame = 0;
-  ip.spec_ids = r->n_local >= kIntegrateGrid * 4 ? 1 : 0;  // (a visible list has room for every voxel-block slot)
+  ip.spec_ids = r->n_local >= kIntegrateGrid * kWgWaves ? 1 : 0;  // (a visible list has room for every voxel-block slot)
   if (push_ring >= 0) {
     if ((rc = prepare_push_visible_list(e, s, push_ring, &ip.push_bit, &ip.push_frame))) return rc;
     ip.push_words = s->history_words; ip.push_ring = push_ring;
