@@ -16,6 +16,9 @@
 //   visible list whose length is read from device memory (no host round trip after allocation).
 #include <hip/hip_ext.h>
 
+#include <cstdio>
+#include <cstdlib>
+
 #include "dslam_internal.h"
 
 #pragma clang fp contract(off)
@@ -59,6 +62,11 @@ struct IntegrateParams {
   unsigned char *dirty;  // sharded re-integration: per slot "visited since tracking began" (null: not tracked)
   const short4 *expect_pos;  // stored keyframe list: the block each listed entry held at fusion time (null: a live list)
   int spec_ids;  // the id list has a slot for every wave of the grid: a wave may read "its" id before the count is known
+  // diagnostics only (env DSLAM_DBG_INTEGRATE=<file>, DIAG instantiation): per wave 16 words -- s_memrealtime (10 ns ticks)
+  // at [0] entry, [1] table ready, [2] list length known, [3] entries gathered, then per half block [4 + 4h] chunk 0 and
+  // [5 + 4h] chunk 1 updated, [6 + 4h] colour pass done, [7 + 4h] stores issued; [12], [13] shader clock at entry and end;
+  // [14] voxel-block slot; [15] XCC id << 32 | HW_ID
+  unsigned long long *dbg_waves;
 };
 
 // a / b for a divisor whose correctly rounded reciprocal y = RN(1/b) is known: q = RN(a*y), r = a - b*q (exact, FMA),
@@ -531,10 +539,15 @@ constexpr int kIntegrateGrid = 8192 / kWgWaves;
 // weighting -- i.e. the per-frame fusion of the reference's configuration.  Compiled without them the kernel carries
 // fewer live arguments (36 scalar registers spilled to VGPR lanes instead of 72, a shorter preamble) and can afford the
 // split update (pair_project / pair_update): 22.9 -> 21.4 us for the specialisation, -> 19.9 us with the split.
-template <bool DEINT, bool SAME_CAM, bool PLAIN = false>
+template <bool DEINT, bool SAME_CAM, bool PLAIN = false, bool DIAG = false>
 __global__ __launch_bounds__(kWgWaves * 64, 8) void k_integrate(IntegrateParams p) {
   static_assert(!PLAIN || (!DEINT && SAME_CAM && DSLAM_PACKED && DSLAM_COLOUR_QUEUE), "PLAIN is the queued one-camera fusion");
+  static_assert(!DIAG || PLAIN, "the per-wave timeline exists for the plain fusion kernel");
   __shared__ float inv_tab[kInvTab];
+  [[maybe_unused]] unsigned long long diag_entry = 0, diag_cyc = 0;
+  [[maybe_unused]] bool diag_first = true;  // a wave records its first block
+  if constexpr (DIAG) { diag_entry = wall_clock64(); diag_cyc = clock64(); }
+#define DSLAM_STAMP(k) do { if constexpr (DIAG) { if (lane == 0 && diag_first) p.dbg_waves[(size_t)wave * 16 + (k)] = wall_clock64(); } } while (0)
   // the one-camera fusion variant runs its colour updates densely from a per-wave LDS queue (fuse_colour_word)
   constexpr bool kQueueColour = !DEINT && SAME_CAM && DSLAM_PACKED && DSLAM_COLOUR_QUEUE;
   // The queue of one wave.  The data of a queued voxel sits at the voxel's OWN place (chunk-voxel k of lane l: k * 64 + l:
@@ -551,6 +564,9 @@ __global__ __launch_bounds__(kWgWaves * 64, 8) void k_integrate(IntegrateParams 
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane((int)((blockIdx.x * (kWgWaves * 64) + threadIdx.x) >> 6));
   constexpr int n_waves = kIntegrateGrid * kWgWaves;  // (the launch below uses exactly this grid)
+  if constexpr (DIAG) {
+    if (lane == 0) { p.dbg_waves[(size_t)wave * 16] = diag_entry; p.dbg_waves[(size_t)wave * 16 + 12] = diag_cyc; p.dbg_waves[(size_t)wave * 16 + 1] = wall_clock64(); }
+  }
   // With at most one block per wave (G = 1: the bench's 7.9 k blocks on 8192 waves) wave w takes list entry w, so that
   // id is requested BEFORE the list length is known and the two loads travel together.  (`zero` is opaque to the
   // compiler: with a provably uniform address it would make this a scalar load and wait for it on the spot.)
@@ -563,6 +579,7 @@ __global__ __launch_bounds__(kWgWaves * 64, 8) void k_integrate(IntegrateParams 
   }
   const int nvis = p.rc->no_visible;
   if (p.timer_slot && blockIdx.x == 0 && threadIdx.x == 0) *p.timer_slot = nvis;
+  DSLAM_STAMP(2);
   int G = (nvis + n_waves - 1) / n_waves;
   G = G < 1 ? 1 : (G > kMaxGroup ? kMaxGroup : G);
 
@@ -601,6 +618,7 @@ __global__ __launch_bounds__(kWgWaves * 64, 8) void k_integrate(IntegrateParams 
         }
       }
     }
+    DSLAM_STAMP(3);
     for (int k = 0; k < G; k++) {
       const int ptr = __builtin_amdgcn_readlane(e_ptr, k);
       if (ptr < 0) continue;
@@ -670,6 +688,7 @@ __global__ __launch_bounds__(kWgWaves * 64, 8) void k_integrate(IntegrateParams 
           unsigned cm;
           chs[jj] = pair_update(v[jj], pq[jj], p, inv_tab, cm);
           queue_colour(jj, cm, pq[jj].u, pq[jj].w);
+          DSLAM_STAMP(4 + half * 4 + jj);
         }
       } else
 #pragma unroll
@@ -729,12 +748,26 @@ __global__ __launch_bounds__(kWgWaves * 64, 8) void k_integrate(IntegrateParams 
               }
         }
       }
+      DSLAM_STAMP(6 + half * 4);
 #pragma unroll
       for (int jj = 0; jj < 2; jj++)
         if (chs[jj]) blk[(half * 2 + jj) * 64 + lane] = v[jj];
+      DSLAM_STAMP(7 + half * 4);
+      }
+      if constexpr (DIAG) {
+        if (lane == 0 && diag_first) {
+          unsigned hw, xcc;
+          asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+          asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+          p.dbg_waves[(size_t)wave * 16 + 13] = clock64();
+          p.dbg_waves[(size_t)wave * 16 + 14] = (unsigned long long)ptr;
+          p.dbg_waves[(size_t)wave * 16 + 15] = ((unsigned long long)xcc << 32) | hw;
+        }
+        diag_first = false;
       }
     }
   }
+#undef DSLAM_STAMP
 }
 
 static void fill_params(IntegrateParams &ip, dslam_engine *e, dslam_scene *s, const dslam_view *v,
@@ -764,6 +797,7 @@ static void fill_params(IntegrateParams &ip, dslam_engine *e, dslam_scene *s, co
 
 static int launch_integrate_params(dslam_engine *e, IntegrateParams &ip, bool deintegrate) {
   ip.timer_slot = nullptr;
+  ip.dbg_waves = nullptr;
   // Timed launches (bench roofline) attach their two events to the dispatch packet itself (hipExtLaunchKernelGGL), so
   // the elapsed time is the kernel's own start-to-end interval -- what rocprofv3 reports -- not the interval between
   // two separately recorded stream events, which also contains ~3 us of packet processing.
@@ -782,6 +816,24 @@ static int launch_integrate_params(dslam_engine *e, IntegrateParams &ip, bool de
   } else {
     const bool plain = DSLAM_PACKED && DSLAM_COLOUR_QUEUE && ip.same_cam && !ip.expect_pos && ip.num_shards <= 1 &&
                        ip.shard_count < 0 && !ip.dirty && !ip.stop_max && !ip.depth_weighting;
+    // diagnostics: the per-wave timeline of one launch, well into the run (DSLAM_DBG_INTEGRATE=<file>)
+    static const char *dbg_file = getenv("DSLAM_DBG_INTEGRATE");
+    static int dbg_calls = 0;
+    if (dbg_file && plain && ++dbg_calls == 60) {
+      constexpr size_t kTraceBytes = (size_t)kIntegrateGrid * kWgWaves * 16 * sizeof(unsigned long long);
+      unsigned long long *trace_dev = nullptr;
+      DSLAM_HIP(hipMalloc((void **)&trace_dev, kTraceBytes));
+      DSLAM_HIP(hipMemsetAsync(trace_dev, 0, kTraceBytes, e->stream));
+      ip.dbg_waves = trace_dev;
+      hipExtLaunchKernelGGL((k_integrate<false, true, DSLAM_PACKED && DSLAM_COLOUR_QUEUE, DSLAM_PACKED && DSLAM_COLOUR_QUEUE>), grid, block, 0, e->stream, ev0, ev1, 0, ip);
+      DSLAM_HIP(hipGetLastError());
+      DSLAM_HIP(hipStreamSynchronize(e->stream));
+      std::vector<unsigned long long> h(kTraceBytes / sizeof(unsigned long long));
+      DSLAM_HIP(hipMemcpy(h.data(), trace_dev, kTraceBytes, hipMemcpyDeviceToHost));
+      if (FILE *f = fopen(dbg_file, "wb")) { fwrite(h.data(), 1, kTraceBytes, f); fclose(f); }
+      (void)hipFree(trace_dev);
+      return DSLAM_OK;
+    }
     if (plain) hipExtLaunchKernelGGL((k_integrate<false, true, DSLAM_PACKED && DSLAM_COLOUR_QUEUE>), grid, block, 0, e->stream, ev0, ev1, 0, ip);
     else if (ip.same_cam) hipExtLaunchKernelGGL((k_integrate<false, true>), grid, block, 0, e->stream, ev0, ev1, 0, ip);
     else hipExtLaunchKernelGGL((k_integrate<false, false>), grid, block, 0, e->stream, ev0, ev1, 0, ip);

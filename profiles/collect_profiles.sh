@@ -13,11 +13,11 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/final_stat
 # HBM traffic of k_integrate: two separate counter passes (MI355X_MICROARCH.md, HBM / rocprofv3)
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $R/gpurun_out/final_fetch -- python3 $R/bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-stress --no-extra-rates --reint 0 --mode device > $R/gpurun_out/final_fetch.log 2>&1; echo fetch rc=$?
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $R/gpurun_out/final_write -- python3 $R/bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-stress --no-extra-rates --reint 0 --mode device > $R/gpurun_out/final_write.log 2>&1; echo write rc=$?
-# instruction counters of k_integrate (VALU instructions per block-wave)
-rocprofv3 --pmc SQ_INSTS_VALU SQ_WAVES --kernel-trace --output-format csv -d $R/gpurun_out/final_sq -- python3 $R/bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-stress --no-extra-rates --reint 0 --mode device > $R/gpurun_out/final_sq.log 2>&1; echo sq rc=$?
+# instruction and wave-time counters (VALU instructions per block-wave; parked / issue-stalled / issuing shares)
+rocprofv3 --pmc SQ_INSTS_VALU SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_SALU --kernel-trace --output-format csv -d $R/gpurun_out/final_sq -- python3 $R/bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-stress --no-extra-rates --reint 0 --mode device > $R/gpurun_out/final_sq.log 2>&1; echo sq rc=$?
 cd $R
-# per-wave dump of the ray march and per-tile timeline of the allocation sweep (diagnostic instantiations)
-DSLAM_DBG_WAVETIME=gpurun_out/final_wavetime.bin DSLAM_DBG_SWEEP=gpurun_out/final_sweep.bin python bench.py $BENCH_FAST --mode device > /dev/null 2>&1; ls -la gpurun_out/final_wavetime.bin gpurun_out/final_sweep.bin
+# per-wave dump of the ray march, per-tile timeline of the allocation sweep, per-wave timeline of the fusion kernel (diagnostic instantiations)
+DSLAM_DBG_WAVETIME=gpurun_out/final_wavetime.bin DSLAM_DBG_SWEEP=gpurun_out/final_sweep.bin DSLAM_DBG_INTEGRATE=gpurun_out/final_integrate_waves.bin python bench.py $BENCH_FAST --mode device > /dev/null 2>&1; ls -la gpurun_out/final_wavetime.bin gpurun_out/final_sweep.bin gpurun_out/final_integrate_waves.bin
 python bench.py --mode sync --steps 100 --warmup 10 --no-cpu-baseline --no-stress --no-extra-rates --reint 0 > gpurun_out/final_bench_sync.json 2>/dev/null
 python denseslam-global-consistency-h_amd/harness/stress.py 64 > gpurun_out/final_stress.json; cat gpurun_out/final_stress.json
 python profiles/experiments/pipeline_breakdown.py 100 > gpurun_out/final_pipeline.json 2>/dev/null; cat gpurun_out/final_pipeline.json

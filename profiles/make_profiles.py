@@ -6,7 +6,9 @@ gpurun_out/final_bench.json              <- python bench.py                     
 gpurun_out/final_bench_sync.json         <- python bench.py --mode sync ...
 gpurun_out/final_stats[_device]/         <- rocprofv3 --kernel-trace --stats ... bench.py [--mode device]
 gpurun_out/final_fetch|final_write/      <- rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --kernel-trace ... bench.py --mode device
-gpurun_out/final_sq/                     <- rocprofv3 --pmc SQ_INSTS_VALU SQ_WAVES --kernel-trace ... bench.py --mode device
+gpurun_out/final_sq/                     <- rocprofv3 --pmc SQ_INSTS_VALU SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY
+                                            SQ_ACTIVE_INST_VALU SQ_INSTS_SALU --kernel-trace ... bench.py --mode device
+gpurun_out/final_integrate_waves.bin     <- DSLAM_DBG_INTEGRATE dump of k_integrate (per wave: 12 timestamps, clocks, placement)
 gpurun_out/final_wavetime.bin            <- DSLAM_DBG_WAVETIME dump of k_render (per wave: cycles, march length, ...)
 gpurun_out/final_sweep.bin               <- DSLAM_DBG_SWEEP dump of k_alloc_sweep (per tile: 8 timestamps)
 gpurun_out/final_{stress,pipeline,side_bench,quality,maintenance,shard_emulation}.json
@@ -96,7 +98,26 @@ def main():
             pmc["SQ_INSTS_VALU_mean"] = sum(valu) / len(valu)
             pmc["SQ_WAVES_mean"] = sum(waves) / len(waves)
             pmc["valu_instructions_per_visible_block"] = (sum(valu) / len(valu)) / vis
-            pmc["sq_command"] = "rocprofv3 --pmc SQ_INSTS_VALU SQ_WAVES --kernel-trace ... (same bench command, its own pass)"
+            pmc["sq_command"] = "rocprofv3 --pmc SQ_INSTS_VALU SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_SALU --kernel-trace ... (same bench command, its own pass)"
+        # where the waves' time goes (quad-cycle counters, MI355X_MICROARCH.md "rocprofv3 PMC slots"): parked on
+        # s_waitcnt / barrier, stalled at issue, issuing -- for the kernels of the frame
+        breakdown = {}
+        for kern in ("k_integrate", "k_render", "k_alloc_sweep", "k_mark"):
+            c = {n: counter_rows("final_sq", n, kern)[warm:] for n in
+                 ("SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "SQ_ACTIVE_INST_VALU", "SQ_INSTS_VALU",
+                  "SQ_INSTS_SALU", "SQ_WAVES")}
+            if not c["SQ_WAVE_CYCLES"]:
+                continue
+            m = {n: sum(v) / len(v) for n, v in c.items() if v}
+            wc = m["SQ_WAVE_CYCLES"]
+            breakdown[kern] = {"waves": m.get("SQ_WAVES"), "valu_instructions_per_wave": m["SQ_INSTS_VALU"] / m["SQ_WAVES"],
+                               "salu_instructions_per_wave": m["SQ_INSTS_SALU"] / m["SQ_WAVES"],
+                               "wave_lifetime_cycles_mean": 4.0 * wc / m["SQ_WAVES"],
+                               "frac_parked_on_waitcnt_or_barrier": m["SQ_WAIT_ANY"] / wc,
+                               "frac_stalled_at_issue": m["SQ_WAIT_INST_ANY"] / wc, "frac_issuing": m["SQ_ACTIVE_INST_ANY"] / wc,
+                               "valu_busy_quad_cycles_per_simd": m["SQ_ACTIVE_INST_VALU"] / 1024.0}
+        if breakdown:
+            pmc["wave_time_breakdown"] = breakdown
     json.dump(pmc, open(os.path.join(HERE, f"{tag}_integrate_pmc.json"), "w"), indent=1)
 
     # per-wave dump of the ray march: 6 u64 per single-wave workgroup {cycles, longest march of its lanes, iterations in
@@ -116,6 +137,32 @@ def main():
             "cycles_per_plain_iteration": float((d[:, 0] - d[:, 3] - d[:, 4] - d[:, 5]).sum() / max(1.0, (d[:, 1] - d[:, 2]).sum())),
             "cycles_per_straddling_iteration": float(d[:, 3].sum() / max(1.0, d[:, 2].sum())),
         }, open(os.path.join(HERE, f"{tag}_render_wave_dump.json"), "w"), indent=1)
+    # per-wave timeline of the fusion kernel: 16 u64 per wave (see IntegrateParams::dbg_waves), s_memrealtime = 10 ns ticks
+    iw = os.path.join(OUT, "final_integrate_waves.bin")
+    if os.path.exists(iw):
+        a = np.fromfile(iw, dtype=np.uint64).reshape(-1, 16).astype(np.int64)
+        act = a[:, 11] > 0
+        w = a[act]
+        t0 = a[a[:, 0] > 0, 0].min()
+        names = ["entry", "table_ready", "list_length_known", "entries_gathered", "h0_chunk0_updated", "h0_chunk1_updated",
+                 "h0_colour_done", "h0_stores_issued", "h1_chunk0_updated", "h1_chunk1_updated", "h1_colour_done", "h1_stores_issued"]
+        us = lambda x: (x - t0) * 0.01
+        pct = lambda t: {k: round(float(v), 2) for k, v in zip(("min", "p10", "median", "p90", "max"),
+                                                                 [t.min(), np.percentile(t, 10), np.median(t), np.percentile(t, 90), t.max()])}
+        d = np.diff(w[:, :12], axis=1) * 0.01
+        life = (w[:, 11] - w[:, 0]) * 0.01
+        xcc = (w[:, 15] >> 32) & 0xf
+        ends = us(w[:, 11])
+        json.dump({
+            "kernel": "k_integrate<false,true,PLAIN,DIAG>", "source": "DSLAM_DBG_INTEGRATE dump of the 60th fusion launch of the bench loop (s_memrealtime, 10 ns ticks; us since the first wave's entry)",
+            "waves_with_a_block": int(act.sum()), "waves_without": int(((a[:, 0] > 0) & ~act).sum()),
+            "reached_at_us": {n: pct(us(w[:, k])) for k, n in enumerate(names)},
+            "phase_median_us": {names[k + 1]: round(float(np.median(d[:, k])), 2) for k in range(11)},
+            "wave_lifetime_us": pct(life),
+            "shader_clock_GHz_median": round(float(np.median((w[:, 13] - w[:, 12]) / (life * 1e3))), 3),
+            "entry_median_us_per_xcc": {int(x): round(float(np.median(us(w[xcc == x, 0]))), 2) for x in np.unique(xcc)},
+            "waves_still_running_at_us": {str(t): int(((us(w[:, 0]) <= t) & (ends > t)).sum()) for t in range(0, int(ends.max()) + 2, 2)},
+        }, open(os.path.join(HERE, f"{tag}_integrate_wave_timeline.json"), "w"), indent=1)
     sw = os.path.join(OUT, "final_sweep.bin")
     if os.path.exists(sw):
         subprocess.run([sys.executable, os.path.join(HERE, "experiments", "sweep_timeline.py"), sw,
