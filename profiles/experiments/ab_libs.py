@@ -1,12 +1,10 @@
 #!/usr/bin/env python3
 """A/B timing of libdslam_fusion.so builds on the bench scene (device-resident loop): per library, in a fresh process,
-K frames of UpdateView -> ProcessFrame -> GetImage with the integrate kernel timed by packet-attached events, plus a CRC
-of the final map (hash table, used voxel blocks, last_seen) so that a variant that changes a single bit shows up.
-usage: ab_libs.py [--rounds R] [--steps K] lib_a.so lib_b.so ...   (alternates the libraries R times on one box;
-variants are built with build_variant.sh: one recompiled source linked with the product's other objects)"""
+K frames of UpdateView -> ProcessFrame -> GetImage with the integrate kernel timed by packet-attached events.
+usage: ab_libs.py [--rounds R] [--steps K] lib_a.so lib_b.so ...   (alternates the libraries R times)"""
 import json, os, subprocess, sys
 
-ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))  # profiles/experiments/ -> repo root
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 
 def child(lib, K, Wm):
@@ -58,8 +56,10 @@ def child(lib, K, Wm):
     for lo in range(first, nlb, 16384):
         crc = zlib.crc32(eng.download_voxel_blocks(scene, lo, min(16384, nlb - lo)).tobytes(), crc)
     crc = zlib.crc32(eng.download_last_seen(scene).tobytes(), crc)
+    img = eng.get_image(scene, rs_free, Ms[n - 1], wl.intr, pkg.IMAGE_DEPTH)
+    img_crc = zlib.crc32(np.ascontiguousarray(img).tobytes())
     print(json.dumps({"lib": os.path.basename(lib), "integrate_us": ms / launches * 1e3, "frame_us": (t1 - t0) / K * 1e6,
-                      "blocks": blocks / launches, "map_crc": "%08x" % crc}), flush=True)
+                      "blocks": blocks / launches, "map_crc": "%08x" % crc, "img_crc": "%08x" % img_crc}), flush=True)
 
 
 if __name__ == "__main__":
