@@ -194,13 +194,26 @@ __global__ __launch_bounds__(256) void k_mark(MarkParams p) {
   int wave_steps = no_steps;
   for (int o = 32; o > 0; o >>= 1) { const int v = __shfl_xor(wave_steps, o, 64); wave_steps = v > wave_steps ? v : wave_steps; }
 
+  // The bucket heads of the first kPre steps are requested together, before any of them is looked at: a pixel's walk is
+  // 2-3 steps of one dependent 16-byte read each, and the positions of all of them are known up front (the same
+  // additions in the same order as the walk below).  A lane with fewer steps reads a bucket it will not use.
+  constexpr int kPre = 3;
+  HashEntry pre[kPre];
+  {
+    Vec3 q = pt;
+#pragma unroll
+    for (int i = 0; i < kPre; i++) {
+      pre[i] = load_entry(p.hash, hash_index((short)(int)floorf(q.x), (short)(int)floorf(q.y), (short)(int)floorf(q.z), p.mask));
+      q.x += dir.x; q.y += dir.y; q.z += dir.z;
+    }
+  }
   for (int i = 0; i < wave_steps; i++) {
     bool need = false;    // this lane asks for slot h at this step
     int h = 0;
     if (i < no_steps) {
       const short bx = (short)(int)floorf(pt.x), by = (short)(int)floorf(pt.y), bz = (short)(int)floorf(pt.z);
       h = hash_index(bx, by, bz, p.mask);
-      HashEntry e = load_entry(p.hash, h);
+      HashEntry e = i == 0 ? pre[0] : (i == 1 ? pre[1] : (i == 2 ? pre[2] : load_entry(p.hash, h)));
       bool found = false;
       if (e.pos[0] == bx && e.pos[1] == by && e.pos[2] == bz && e.ptr >= -1) {
         p.vis_type[h] = (unsigned char)(p.gen | ((e.ptr == -1) ? 2u : 1u));

@@ -177,6 +177,29 @@ def test_gpu_is_deterministic(pkg, synth, gpu):
     assert np.array_equal(snaps[0]["img"], snaps[1]["img"])
 
 
+def test_plain_and_general_fusion_kernels_agree(pkg, synth, gpu, oracle):
+    """The fusion kernel has a specialised instantiation for the reference's plain configuration (weight 1, no stored
+    list / shards / dirty marks / stopIntegratingAtMaxW: integrate.hip, PLAIN) with its own code path for the depth
+    update (both chunks of a half block projected before either is updated, images read through buffer resources).
+    Arming the dirty marks selects the general instantiation without changing what is fused: both must leave the same
+    map, at a size with many visible blocks per wave as well as at the tiny one, and both must equal the oracle."""
+    for wl, n in ((synth.s_tiny(), 6), (synth.s_street(320, 240), 3)):
+        p = util.small_params(pkg, wl) if wl.W < 100 else pkg.SceneParams(num_local_blocks=0x8000, **wl.scene_kwargs)
+        snaps = {}
+        for name, api, dirty in (("plain", gpu, False), ("general", gpu, True), ("oracle", oracle, False)):
+            s = api.create_scene(p)
+            rs, v = api.create_render_state(s, wl.W, wl.H), api.create_view(wl.W, wl.H)
+            if dirty:
+                api.track_dirty(s, True)
+            for i in range(n):
+                rgba, mm, M = wl.frame(i)
+                api.view_update(v, rgba, mm, timestamp=float(i))
+                api.process_frame(s, v, rs, M, wl.intr)
+            snaps[name] = util.snapshot(api, s, rs)
+        util.assert_same_state(snaps["plain"], snaps["general"], f"{wl.name}: plain vs general kernel")
+        util.assert_same_state(snaps["plain"], snaps["oracle"], f"{wl.name}: plain kernel vs oracle")
+
+
 def test_separate_visualisation_calls_equal_get_image(pkg, synth, gpu, oracle):
     """ITMVisualisationEngine's steps called one by one (FindVisibleBlocks, CreateExpectedDepths, RenderImage,
     CountVisibleBlocks: InfiniTamDriver.cpp:229-277, DenseSlam.cpp:555-556) give what GetImage's fused launches give,
@@ -218,5 +241,6 @@ def test_separate_visualisation_calls_equal_get_image(pkg, synth, gpu, oracle):
 
 def test_packed_division_selftest(gpu):
     """The integration kernel's 2-wide IEEE division (div_ieee2: the hardware sequence without its scaling / fix-up
-    instructions) against the native float division on 2^28 random operand pairs of the kernel's ranges."""
+    instructions) against the native float division on 2^28 random operand pairs of the kernel's ranges; the same call
+    compares every entry of the kernel's reciprocal table (v_rcp_f32 + one Newton step, integers 1..65535) with 1.0f / i."""
     assert gpu.selftest_division(1 << 28) == 0
