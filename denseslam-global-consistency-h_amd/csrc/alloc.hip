@@ -332,7 +332,6 @@ __device__ __forceinline__ void sweep_block_vis(SweepVisScratch &s, unsigned can
 template <bool SWAPPING>
 __global__ __launch_bounds__(256) void k_alloc_sweep(SweepParams p) {
   __shared__ int red[2][8];
-  __shared__ int s_flag;
   __shared__ SweepVisScratch vis_scratch;
   // the pool tops are not modified before every tile has finished committing (the last tile folds the results in)
   const int base_free = p.cnt->last_free, base_free_ex = p.cnt->last_free_ex;
@@ -474,20 +473,16 @@ __global__ __launch_bounds__(256) void k_alloc_sweep(SweepParams p) {
         if (pass == 1 && p.do_commit) {
           for (int d = 32; d > 0; d >>= 1) { succ_vba += __shfl_xor(succ_vba, d, 64); succ_ex += __shfl_xor(succ_ex, d, 64); }
           const unsigned long long any_remote = __ballot(remote);
-          if (threadIdx.x == 0) s_flag = 0;
           if (any_remote) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
           __syncthreads();
           if ((threadIdx.x & 63) == 0) {
             red[1][threadIdx.x >> 6] = succ_vba;
             red[1][4 + (threadIdx.x >> 6)] = succ_ex;
-            if (any_remote) s_flag = 1;
           }
           __syncthreads();
           if (threadIdx.x == 0) {
-            if (s_flag) {
-              __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-              asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            }
+            // (a tile that stored into other tiles: each of its storing waves waited for its write-through stores in
+            // front of the barrier above; no release fence -- see pass 0)
             publish(p.agg_succ, b, p.epoch, red[1][0] + red[1][1] + red[1][2] + red[1][3], red[1][4] + red[1][5] + red[1][6] + red[1][7]);
           }
           succ_published = true;
@@ -519,8 +514,22 @@ __global__ __launch_bounds__(256) void k_alloc_sweep(SweepParams p) {
               const int ex_off = p.excess_list[base_free_ex - q2];
               const short4 bc = p.coords[t];
               p.hash[t].offset = ex_off + 1;
-              store_entry(p.hash, p.num_buckets + ex_off, bc.x, bc.y, bc.z, 0, p.alloc_list[base_free - vr]);
-              p.vis_type[p.num_buckets + ex_off] = (unsigned char)(p.gen | 1u);
+              // The two stores that land in ANOTHER tile's entries go out write-through (sc1): once this wave's vmcnt is
+              // back at 0 they are in memory, so the commit word needs no agent-scope release in front of it -- that is a
+              // write-back of the XCD's L2 (1.7-6.5 us) on the critical path of every tile behind this one (the tiles of
+              // the excess area wait for EVERY commit word): last tile done at 17.5 instead of 19.3 us.  The readers keep
+              // their agent-scope acquire (MI355X_MICROARCH.md, inter-workgroup visibility: sc1 stores + the storing
+              // waves' vmcnt(0) + barrier, then the flag; acquire + plain loads on the other side).
+              {  // (relaxed agent-scope atomic stores = plain store instructions with sc1; the entry as two 8-byte halves)
+                unsigned long long *dst = reinterpret_cast<unsigned long long *>(p.hash + (p.num_buckets + ex_off));
+                const unsigned long long lo = ((unsigned long long)((unsigned)bc.z & 0xffffu) << 32) |
+                                              (((unsigned)bc.x & 0xffffu) | ((unsigned)bc.y << 16));
+                const unsigned long long hi = (unsigned long long)(unsigned)p.alloc_list[base_free - vr] << 32;  // offset 0, ptr
+                __hip_atomic_store(dst, lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(dst + 1, hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(p.vis_type + (p.num_buckets + ex_off), (unsigned char)(p.gen | 1u), __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);
+              }
             }
             if (pass == 1) p.req_list[qq] = t;
             q2++;
