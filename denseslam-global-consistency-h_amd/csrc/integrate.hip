@@ -167,8 +167,9 @@ __device__ __forceinline__ bool in_image(float u, float w, float umax, float wma
   return u >= 1.0f && u <= umax && w >= 1.0f && w <= wmax;  // false for NaN
 }
 
+template <bool PLAIN = false>  // PLAIN: the weight is 1 by construction
 __device__ __forceinline__ int new_weight(const IntegrateParams &p, float depth_measure) {
-  if (!p.depth_weighting) return 1;
+  if (PLAIN || !p.depth_weighting) return 1;
   const float dd = depth_measure < p.max_distance ? depth_measure : p.max_distance;
   const int w = (int)roundf((float)p.max_new_w * (1.0f - dd / p.max_distance));
   // (the upper clamp never acts on a measured depth > 0; it keeps the table index of an inactive lane, which
@@ -374,6 +375,30 @@ __device__ __forceinline__ unsigned fuse_colour_word(unsigned pack, float u, flo
   return (lo >> 24) | ((hi & 0xffffffu) << 8);
 }
 
+// computeUpdatedVoxelColorInfo of the de-integration (update_voxel<true, true>'s colour part) on a queued colour word
+template <bool BUF>
+__device__ __forceinline__ unsigned defuse_colour_word(unsigned pack, float u, float w, const IntegrateParams &p,
+                                                       const float *inv_tab) {
+  const unsigned wc = pack >> 24;
+  if (wc < 1) return pack;  // nothing was ever fused into this colour
+  float m[3];
+  if constexpr (BUF) bilinear_rgb_buf(image_rsrc(p.rgba, p.Wr, p.Hr), u, w, p.Wr, m);
+  else bilinear_rgb(p.rgba, u, w, p.Wr, m);
+  const float oldW = (float)wc, remW = oldW - 1.0f;
+  if (remW == 0.0f) return 0u;  // colour 0, weight 0
+  const float inv_rem = inv_tab[wc - 1];
+  unsigned out = (unsigned)(unsigned char)remW << 24;
+#pragma unroll
+  for (int k = 0; k < 3; k++) {
+    const float oldC = div_exact((float)((pack >> (8 * k)) & 0xffu), 255.0f, p.inv_255);
+    const float c = div_exact(m[k], 255.0f, p.inv_255);
+    float v = div_exact(oldC * oldW - c * 1.0f, remW, inv_rem);
+    v = fmaxf(0.0f, fminf(1.0f, v));
+    out |= (unsigned)(unsigned char)(v * 255.0f) << (8 * k);
+  }
+  return out;
+}
+
 constexpr int kColQueue = 256;  // one slot per voxel of a half block
 
 // ComputeUpdatedVoxelInfo<hasColor>::compute for the two voxels of one chunk: (vv.x, vv.y) at x, (vv.z, vv.w) at x + 1
@@ -479,7 +504,10 @@ __device__ __forceinline__ void pair_project(PairProj &q, f2 pcx, f2 pcy, f2 pcz
   q.dm.y = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(depth_rs, pixel_offset((int)ur.y, (int)wr.y, p.Wd), 0, 0));
 }
 
-// The depth update of the two voxels (fuse_pair from `eta` on, with newW = 1); `cmask` as fuse_pair<., QUEUE> returns it
+// The depth update of the two voxels (fuse_pair from `eta` on; PLAIN: newW = 1); `cmask` as fuse_pair<., QUEUE> returns
+// it.  DEINT: update_voxel<true, .>'s depth part on both voxels at once -- W' = W - w, F' = clamp((W F - w f) / W'),
+// W' = 0 -> the empty voxel, a voxel with W < w is left alone; the narrow-band colour test does not depend on that.
+template <bool DEINT, bool PLAIN>
 __device__ __forceinline__ bool pair_update(uint4 &vv, const PairProj &q, const IntegrateParams &p, const float *inv_tab,
                                             unsigned &cmask) {
   cmask = 0;
@@ -500,22 +528,47 @@ __device__ __forceinline__ bool pair_update(uint4 &vv, const PairProj &q, const 
   newF.y = fminf(1.0f, eta_mu.y);
   f2 oW;
   oW.x = (float)oldW0; oW.y = (float)oldW1;
-  f2 nf = oW * oldF + newF;  // oldW * oldF + newW * newF with newW = 1 (that product is exact: it is newF)
-  int nW0 = oldW0 + 1, nW1 = oldW1 + 1;
-  f2 nWf, inv;
-  nWf.x = (float)nW0; nWf.y = (float)nW1;
-  inv.x = inv_tab[nW0]; inv.y = inv_tab[nW1];
-  {  // div_exact with per-component divisors
-    const f2 qq = nf * inv;
-    const f2 r = __builtin_elementwise_fma(-nWf, qq, nf);
-    nf = __builtin_elementwise_fma(r, inv, qq);
-  }
-  nW0 = nW0 < p.max_w ? nW0 : p.max_w;
-  nW1 = nW1 < p.max_w ? nW1 : p.max_w;
+  const int addW0 = new_weight<PLAIN>(p, q.dm.x), addW1 = new_weight<PLAIN>(p, q.dm.y);
+  f2 aW;
+  aW.x = (float)addW0; aW.y = (float)addW1;
   const f2 scale = {32767.0f, 32767.0f};
-  const f2 sf = nf * scale;
-  if (act0) vv.x = (vv.x & 0xff000000u) | ((unsigned)nW0 << 16) | (unsigned)(unsigned short)(short)sf.x;
-  if (act1) vv.z = (vv.z & 0xff000000u) | ((unsigned)nW1 << 16) | (unsigned)(unsigned short)(short)sf.y;
+  if constexpr (!DEINT) {
+    // oldW * oldF + newW * newF (PLAIN: newW = 1 and that product is exact: it is newF)
+    f2 nf = PLAIN ? oW * oldF + newF : oW * oldF + aW * newF;
+    int nW0 = oldW0 + addW0, nW1 = oldW1 + addW1;
+    f2 nWf, inv;
+    nWf.x = (float)nW0; nWf.y = (float)nW1;
+    inv.x = inv_tab[nW0]; inv.y = inv_tab[nW1];
+    {  // div_exact with per-component divisors
+      const f2 qq = nf * inv;
+      const f2 r = __builtin_elementwise_fma(-nWf, qq, nf);
+      nf = __builtin_elementwise_fma(r, inv, qq);
+    }
+    nW0 = nW0 < p.max_w ? nW0 : p.max_w;
+    nW1 = nW1 < p.max_w ? nW1 : p.max_w;
+    const f2 sf = nf * scale;
+    if (act0) vv.x = (vv.x & 0xff000000u) | ((unsigned)nW0 << 16) | (unsigned)(unsigned short)(short)sf.x;
+    if (act1) vv.z = (vv.z & 0xff000000u) | ((unsigned)nW1 << 16) | (unsigned)(unsigned short)(short)sf.y;
+  } else {
+    const int rW0 = oldW0 - addW0, rW1 = oldW1 - addW1;  // (< 0: the voxel holds less than this frame's weight -- left alone)
+    f2 nf = oW * oldF - aW * newF;  // oldW * oldF - newW * newF: two products, one difference
+    f2 rWf, inv;
+    rWf.x = (float)rW0; rWf.y = (float)rW1;
+    inv.x = inv_tab[rW0 > 0 ? rW0 : 0]; inv.y = inv_tab[rW1 > 0 ? rW1 : 0];
+    {
+      const f2 qq = nf * inv;
+      const f2 r = __builtin_elementwise_fma(-rWf, qq, nf);
+      nf = __builtin_elementwise_fma(r, inv, qq);
+    }
+    nf.x = fmaxf(-1.0f, fminf(1.0f, nf.x));
+    nf.y = fmaxf(-1.0f, fminf(1.0f, nf.y));
+    const f2 sf = nf * scale;
+    // W' = 0: sdf 32767, weight 0 (the quotient above is then 0 / 0 and not used)
+    const unsigned s0 = rW0 == 0 ? 0x7fffu : (unsigned)(unsigned short)(short)sf.x;
+    const unsigned s1 = rW1 == 0 ? 0x7fffu : (unsigned)(unsigned short)(short)sf.y;
+    if (act0 && rW0 >= 0) vv.x = (vv.x & 0xff000000u) | ((unsigned)rW0 << 16) | s0;
+    if (act1 && rW1 >= 0) vv.z = (vv.z & 0xff000000u) | ((unsigned)rW1 << 16) | s1;
+  }
   // upstream skips the colour when `eta > mu || fabs(eta / mu) > 0.25`.  With mu > 0, eta > mu makes the exact quotient
   // exceed 1, so its rounding is >= 1 > 0.25: the first test never decides anything the second does not already
   const bool col0 = act0 && !(fabsf(eta_mu.x) > 0.25f);
@@ -549,7 +602,10 @@ __global__ __launch_bounds__(kWgWaves * 64, 8) void k_integrate(IntegrateParams 
   if constexpr (DIAG) { diag_entry = wall_clock64(); diag_cyc = clock64(); }
 #define DSLAM_STAMP(k) do { if constexpr (DIAG) { if (lane == 0 && diag_first) p.dbg_waves[(size_t)wave * 16 + (k)] = wall_clock64(); } } while (0)
   // the one-camera fusion variant runs its colour updates densely from a per-wave LDS queue (fuse_colour_word)
-  constexpr bool kQueueColour = !DEINT && SAME_CAM && DSLAM_PACKED && DSLAM_COLOUR_QUEUE;
+  constexpr bool kQueueColour = SAME_CAM && DSLAM_PACKED && DSLAM_COLOUR_QUEUE;
+  // the split update (pair_project / pair_update): plain fusion, and the one-camera de-integration (41.6 -> ... us per
+  // launch against the voxel-by-voxel form it replaces; the general fusion variant has no registers for it)
+  constexpr bool kPairPath = PLAIN || (DEINT && kQueueColour);
   // The queue of one wave.  The data of a queued voxel sits at the voxel's OWN place (chunk-voxel k of lane l: k * 64 + l:
   // no address arithmetic for its owner, neither to queue it nor to fetch the result), `list` holds the places in queue
   // order, and the result comes back at the same place.  4.25 KiB per wave: 70 KiB per 16-wave workgroup with the table (two workgroups per CU).
@@ -670,24 +726,31 @@ __global__ __launch_bounds__(kWgWaves * 64, 8) void k_integrate(IntegrateParams 
           q_n += __popcll(bm);
         }
       };
-      if constexpr (PLAIN) {
-        // both chunks projected and their depth pixels requested, then both updated (see pair_project)
-        PairProj pq[2];
+      if constexpr (kPairPath) {
+        // PLAIN: both chunks projected and their depth pixels requested, then both updated (see pair_project).  The
+        // de-integration variant carries the optional features and has no registers to hold two projections: its chunks
+        // go one after the other -- packed arithmetic and the colour queue, but one depth wait per chunk.
+        PairProj pq[PLAIN ? 2 : 1];
         const __amdgpu_buffer_rsrc_t depth_rs = image_rsrc(p.depth, p.Wd, p.Hd);
-#pragma unroll
-        for (int jj = 0; jj < 2; jj++) {
+        auto project = [&](int jj, PairProj &q) {
           const float fz = (float)(gz + (half * 2 + jj) * 2 + vz0) * p.voxel_size;
           const float az0 = p.M_d.m[8] * fz, az1 = p.M_d.m[9] * fz, az2 = p.M_d.m[10] * fz;
           const f2 a0 = {az0, az0}, a1 = {az1, az1}, a2 = {az2, az2};
           const f2 t0 = {p.M_d.m[12], p.M_d.m[12]}, t1 = {p.M_d.m[13], p.M_d.m[13]}, t2 = {p.M_d.m[14], p.M_d.m[14]};
           const f2 px = {pxy[0][0], pxy[1][0]}, py = {pxy[0][1], pxy[1][1]}, pz = {pxy[0][2], pxy[1][2]};
-          pair_project(pq[jj], (px + a0) + t0, (py + a1) + t1, (pz + a2) + t2, p, depth_rs);
+          pair_project(q, (px + a0) + t0, (py + a1) + t1, (pz + a2) + t2, p, depth_rs);
+        };
+        if constexpr (PLAIN) {
+#pragma unroll
+          for (int jj = 0; jj < 2; jj++) project(jj, pq[jj]);
         }
 #pragma unroll
         for (int jj = 0; jj < 2; jj++) {
+          if constexpr (!PLAIN) project(jj, pq[0]);
+          PairProj &q = pq[PLAIN ? jj : 0];
           unsigned cm;
-          chs[jj] = pair_update(v[jj], pq[jj], p, inv_tab, cm);
-          queue_colour(jj, cm, pq[jj].u, pq[jj].w);
+          chs[jj] = pair_update<DEINT, PLAIN>(v[jj], q, p, inv_tab, cm);
+          queue_colour(jj, cm, q.u, q.w);
           DSLAM_STAMP(4 + half * 4 + jj);
         }
       } else
@@ -733,7 +796,9 @@ __global__ __launch_bounds__(kWgWaves * 64, 8) void k_integrate(IntegrateParams 
           ColQueue &Q = col_q[threadIdx.x >> 6];
           for (int i = lane; i < q_n; i += 64) {
             const int o = Q.list[i];
-            Q.r[o] = fuse_colour_word<PLAIN>(Q.c[o], Q.u[o], Q.w[o], p, inv_tab);  // (the general variant has no scalar registers to spare for a second buffer resource)
+            // (texels through a buffer resource where the variant has scalar registers to spare for a second one)
+            if constexpr (DEINT) Q.r[o] = defuse_colour_word<false>(Q.c[o], Q.u[o], Q.w[o], p, inv_tab);
+            else Q.r[o] = fuse_colour_word<PLAIN>(Q.c[o], Q.u[o], Q.w[o], p, inv_tab);
           }
 #pragma unroll
           for (int jj = 0; jj < 2; jj++)
