@@ -287,10 +287,15 @@ __global__ __launch_bounds__(256) void k_push_freed_finalize(unsigned char *free
 }
 
 // rebuild of a render state's visible list from its types, only when the pass took an entry out of it: single-pass
-// ordered compaction over the type bytes (4096-entry tiles)
-__global__ __launch_bounds__(256) void k_rebuild_visible(const unsigned char *__restrict__ vis_type, int n_entries, int *ids,
+// ordered compaction over the type bytes (4096-entry tiles).
+// `gen` = the generation bit of the render state's last allocation pass.  An entry that did not fit into the list of that
+// pass (a visible list is capped at the pool size) kept its 1 / 2 with the NEXT pass' bit -- upstream leaves such a type in
+// place without re-arming it, so it counts as marked again.  Once the rebuilt, shorter list has room for it, it is an
+// ordinary listed entry, which upstream's next pass re-arms as 3: its byte gets the last pass' bit here (found by the
+// fuzz test, seed 10744: list full after an allocation-only pass, then a window pop, then a fusion).
+__global__ __launch_bounds__(256) void k_rebuild_visible(unsigned char *__restrict__ vis_type, int n_entries, int *ids,
                                                          int capacity, RenderCounters *rc, int *maint_flags,
-                                                         unsigned long long *agg, unsigned epoch, int n_tiles) {
+                                                         unsigned long long *agg, unsigned epoch, int n_tiles, unsigned gen) {
   __shared__ int red[8];
   if (maint_flags[0] == 0) return;
   for (int b = blockIdx.x; b < n_tiles; b += gridDim.x) {
@@ -319,7 +324,12 @@ __global__ __launch_bounds__(256) void k_rebuild_visible(const unsigned char *__
       }
       r += offset;
       for (; m; m &= m - 1) {
-        if (r < capacity) ids[r] = t0 + __ffs((int)m) - 1;
+        if (r < capacity) {
+          const int t = t0 + __ffs((int)m) - 1;
+          ids[r] = t;
+          const unsigned char ty = vis_type[t];  // (this thread owns the bytes of its entries)
+          if ((ty & 0x80u) != gen) vis_type[t] = (unsigned char)(gen | (ty & 0x7fu));
+        }
         r++;
       }
     }
@@ -358,6 +368,9 @@ static int lookback_grid(dslam_engine *e, int n_tiles) {
 
 static int rebuild_visible_list(dslam_engine *e, dslam_render_state *r) {
   // (the swapping paths call this directly after they have changed types themselves)
+  // the list no longer is "what the last pass left visible": the next allocation pass re-derives the marks from it
+  // (an entry that had not fitted into that pass' list may be listed now, see k_rebuild_visible)
+  r->types_follow_list = false;
   const int N = r->n_entries, n_tiles = num_tiles(N);
   hipLaunchKernelGGL(k_flag_count, dim3(n_tiles), dim3(256), 0, e->stream, r->visible_type, N, e->tile_counts);
   hipLaunchKernelGGL(k_compact_apply_fused, dim3(n_tiles), dim3(256), 0, e->stream, r->visible_type, N, e->tile_counts,
@@ -380,7 +393,8 @@ static int release_listed(dslam_engine *e, dslam_scene *s, dslam_render_state *r
   if (r) {
     const int v_tiles = (r->n_entries + kSweepTile - 1) / kSweepTile;
     hipLaunchKernelGGL(k_rebuild_visible, dim3(lookback_grid(e, v_tiles)), dim3(256), 0, e->stream, r->visible_type,
-                       r->n_entries, r->visible_ids, r->n_local, r->counters, e->maint_flags, e->agg, next_epoch(e), v_tiles);
+                       r->n_entries, r->visible_ids, r->n_local, r->counters, e->maint_flags, e->agg, next_epoch(e), v_tiles,
+                       (unsigned)r->gen);
   }
   DSLAM_HIP(hipGetLastError());
   return DSLAM_OK;
