@@ -13,8 +13,9 @@ import util
 pytestmark = pytest.mark.gpu
 
 
-def _trial(pkg, synth, gpu, oracle, seed):
+def _trial(pkg, synth, gpu, oracle, seed, use_store=None):
     rng = np.random.default_rng(seed)
+    rng_store = np.random.default_rng(seed + 7777777)  # (its own stream: trials without a store stay what they were)
     big = os.environ.get("DSLAM_FUZZ_BIG") == "1"  # one-off hunts: larger images, pools and longer sequences
     W, H = (int(rng.choice([160, 200])), int(rng.choice([120, 96]))) if big else (int(rng.choice([48, 52, 64, 70, 80])), int(rng.choice([36, 45, 48])))
     wl = synth.s_room(W, H, scale=float(rng.choice([3.0, 4.0, 6.0])))
@@ -33,6 +34,25 @@ def _trial(pkg, synth, gpu, oracle, seed):
     for name, api in (("gpu", gpu), ("oracle", oracle)):
         s = api.create_scene(p)
         objs[name] = (api, s, api.create_render_state(s, W, H), api.create_view(W, H), api.create_render_state(s, W, H))
+    # every second trial also keeps its fused keyframes in a keyframe store with their fusion-time visible lists and
+    # re-fuses from there (dslam_deprocess_frame_stored: no allocation pass at the old pose, entries that no longer hold
+    # their block are skipped) -- interleaved with everything else, decay / window / swapping included
+    if use_store is None:
+        use_store = bool(rng_store.random() < 0.5)
+    stores = {}
+    if use_store:
+        for name, (api, s, *_r) in objs.items():
+            stores[name] = api.create_frame_store(W, H, 12)
+            api.frame_store_enable_lists(stores[name], s)
+    stored = {}  # slot -> pose of the keyframe's last fusion
+    # one trial in four has an RGB camera that is not the depth camera (the two-camera kernels; the reference's calib is
+    # the identity, upstream's interface is general)
+    two_cam = bool(rng_store.random() < 0.25)
+    T_rgb = synth.pose_matrix(synth.look_rotation(0.01, -0.006), [0.012, -0.004, 0.003]).astype(np.float32)
+    intr_rgb = (np.asarray(wl.intr, np.float32) * np.float32(1.015)) if two_cam else None
+
+    def cam(Md):  # keyword arguments of the colour camera for a fusion / de-integration at depth pose Md
+        return dict(M_rgb=(T_rgb @ np.asarray(Md, np.float32)).astype(np.float32), intr_rgb=intr_rgb) if two_cam else {}
     if rng.random() < 0.3:
         max_new_w = int(rng.integers(2, 6))
         for api, *_ in objs.values():
@@ -41,7 +61,8 @@ def _trial(pkg, synth, gpu, oracle, seed):
     try:
         fused = []
         for step in range(int(rng.integers(25, 45)) if big else int(rng.integers(10, 26))):
-            op = rng.choice(["fuse", "fuse", "fuse", "refuse", "decay", "slide", "alloc_only", "raycast", "defusion_ring", "flush"])
+            op = rng.choice(["fuse", "fuse", "fuse", "refuse", "decay", "slide", "alloc_only", "raycast", "defusion_ring", "flush"] +
+                            (["refuse_stored", "refuse_stored"] if use_store else []))
             i = int(rng.integers(0, 12))
             rgba, mm, M = wl.frame(i)
             jitter = synth.pose_matrix(synth.look_rotation(rng.normal(0, 0.01), rng.normal(0, 0.01)), rng.normal(0, 0.01, 3))
@@ -64,6 +85,9 @@ def _trial(pkg, synth, gpu, oracle, seed):
                 args = (bool(rng.integers(0, 2)),)
             elif op == "fuse":
                 args = (bool(rng.random() < 0.2), bool(rng.random() < 0.2))  # bilateral filter, BGR input
+            slot = -1
+            if op == "refuse_stored" and stored:
+                slot = int(rng_store.choice(sorted(stored)))
             log.append((op, i, args))
             imgs = {}
             for name, (api, s, rs, v, free) in objs.items():
@@ -72,12 +96,21 @@ def _trial(pkg, synth, gpu, oracle, seed):
                         api.view_update_bgr(v, np.ascontiguousarray(rgba[..., 2::-1]), mm, timestamp=float(step), bilateral=args[0])
                     else:
                         api.view_update(v, rgba, mm, timestamp=float(step), bilateral=args[0])
-                    api.process_frame(s, v, rs, M, wl.intr)
+                    if use_store and not args[0]:  # (the store keeps the unfiltered images)
+                        api.frame_store_put_view(stores[name], i, v)
+                    api.process_frame(s, v, rs, M, wl.intr, **cam(M))
+                    if use_store and not args[0]:
+                        api.frame_store_put_visible_list(stores[name], i, s, rs)
+                elif op == "refuse_stored" and slot >= 0:
+                    api.view_update_from_store(v, stores[name], slot, timestamp=float(step))
+                    api.deprocess_frame_stored(s, v, stores[name], slot, stored[slot], wl.intr, **cam(stored[slot]))
+                    api.process_frame(s, v, rs, M, wl.intr, is_defusion=True, **cam(M))
+                    api.frame_store_put_visible_list(stores[name], slot, s, rs)
                 elif op == "refuse" and fused:
                     rgba_o, mm_o, M_o = fused[-1]
                     api.view_update(v, rgba_o, mm_o, timestamp=float(step))
-                    api.deprocess_frame(s, v, rs, M_o, wl.intr)
-                    api.process_frame(s, v, rs, M, wl.intr, is_defusion=True)
+                    api.deprocess_frame(s, v, rs, M_o, wl.intr, **cam(M_o))
+                    api.process_frame(s, v, rs, M, wl.intr, is_defusion=True, **cam(M))
                 elif op == "decay":
                     api.decay(s, rs, *args)
                 elif op == "slide":
@@ -93,6 +126,10 @@ def _trial(pkg, synth, gpu, oracle, seed):
                     imgs[name] = [api.get_image(s, free, M, wl.intr, args[0]), api.get_image(s, free, M, wl.intr, args[1])]
                 elif op == "flush" and p.use_swapping:
                     api.save_to_global_memory(s)
+            if op == "fuse" and not args[0] and use_store:
+                stored[i] = M
+            if op == "refuse_stored" and slot >= 0:
+                stored[slot] = M
             if op == "fuse" and not args[0]:
                 rgba_n = rgba.copy()
                 rgba_n[..., 3] = 255 if args[1] else rgba[..., 3]
@@ -125,7 +162,7 @@ def _trial(pkg, synth, gpu, oracle, seed):
 #          not fitted kept the "marked again next pass" encoding although the rebuilt list now held it (type 1, oracle 3)
 @pytest.mark.parametrize("seed", [10744])
 def test_regression_seeds(pkg, synth, gpu, oracle, seed):
-    _trial(pkg, synth, gpu, oracle, seed)
+    _trial(pkg, synth, gpu, oracle, seed, use_store=False)
 
 
 # DSLAM_FUZZ_SEEDS="first:count" widens the hunt (e.g. 5000:500); the default 60 trials take a few seconds
