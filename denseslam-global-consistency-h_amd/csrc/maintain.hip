@@ -200,12 +200,17 @@ __global__ __launch_bounds__(256) void k_release_and_leaders(const int *__restri
 // leaders rewrite their bucket chain once (DESIGN.md "batch release"); consumes (clears) the removal flags
 __global__ __launch_bounds__(256) void k_unlink(const int *__restrict__ leader_bucket, const SceneCounters *cnt,
                                                 HashEntry *hash, int num_buckets, unsigned char *remove_flags,
-                                                unsigned char *freed_flags, unsigned char *vis_type, int *maint_flags) {
+                                                unsigned char *freed_flags, unsigned char *vis_type, int *maint_flags,
+                                                int list_is_foreign) {
+  // list_is_foreign: the render state's visible list is not "the entries with a type" at the moment (FindVisibleBlocks
+  // wrote it, or it was uploaded): any release then rebuilds it from the types, as the batch release is defined --
+  // a released or moved entry may sit in that list without having a type (found by the fuzz test, seed 60045)
   const int n = cnt->remove_count;
   bool touched_visible = false;
   for (int r = blockIdx.x * blockDim.x + threadIdx.x; r < n; r += gridDim.x * blockDim.x) {
     const int head = leader_bucket[r];
     if (head < 0) continue;
+    if (list_is_foreign) touched_visible = true;
     int c = head, prev = -1;
     while (c >= 0) {
       const HashEntry e = load_entry(hash, c);
@@ -386,7 +391,8 @@ static int release_listed(dslam_engine *e, dslam_scene *s, dslam_render_state *r
                      s->hash, reinterpret_cast<uint4 *>(s->voxels), s->alloc_list, s->masks, s->last_seen, s->history_words,
                      s->p.num_buckets, (unsigned)(s->p.num_buckets - 1), m.rem_flags, m.leaders);
   hipLaunchKernelGGL(k_unlink, dim3(256), dim3(256), 0, e->stream, m.leaders, s->counters, s->hash, s->p.num_buckets,
-                     m.rem_flags, m.freed_flags, r ? r->visible_type : (unsigned char *)nullptr, e->maint_flags);
+                     m.rem_flags, m.freed_flags, r ? r->visible_type : (unsigned char *)nullptr, e->maint_flags,
+                     (r && !r->types_follow_list) ? 1 : 0);
   const int x_tiles = (s->p.num_excess + kSweepTile - 1) / kSweepTile;
   hipLaunchKernelGGL(k_push_freed_finalize, dim3(lookback_grid(e, x_tiles)), dim3(256), 0, e->stream, m.freed_flags,
                      s->p.num_excess, s->excess_list, s->counters, count_as_slid, e->agg, next_epoch(e), x_tiles);

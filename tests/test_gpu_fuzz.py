@@ -13,7 +13,7 @@ import util
 pytestmark = pytest.mark.gpu
 
 
-def _trial(pkg, synth, gpu, oracle, seed, use_store=None):
+def _trial(pkg, synth, gpu, oracle, seed, use_store=None, extras=True):
     rng = np.random.default_rng(seed)
     rng_store = np.random.default_rng(seed + 7777777)  # (its own stream: trials without a store stay what they were)
     big = os.environ.get("DSLAM_FUZZ_BIG") == "1"  # one-off hunts: larger images, pools and longer sequences
@@ -85,6 +85,9 @@ def _trial(pkg, synth, gpu, oracle, seed, use_store=None):
                 args = (bool(rng.integers(0, 2)),)
             elif op == "fuse":
                 args = (bool(rng.random() < 0.2), bool(rng.random() < 0.2))  # bilateral filter, BGR input
+            # one raycast in five goes through the FUSION render state: its visible list is replaced behind the types' back
+            # (upstream's FindVisibleBlocks writes renderState->visibleEntryIDs), which the next allocation pass must digest
+            same_rs = bool(extras and op == "raycast" and rng_store.random() < 0.2)
             slot = -1
             if op == "refuse_stored" and stored:
                 slot = int(rng_store.choice(sorted(stored)))
@@ -123,7 +126,8 @@ def _trial(pkg, synth, gpu, oracle, seed, use_store=None):
                     api.view_update(v, rgba, mm, timestamp=float(step))
                     api.allocate_scene_from_depth(s, v, rs, M, wl.intr, only_update_visible_list=args[0])
                 elif op == "raycast":
-                    imgs[name] = [api.get_image(s, free, M, wl.intr, args[0]), api.get_image(s, free, M, wl.intr, args[1])]
+                    target = rs if same_rs else free
+                    imgs[name] = [api.get_image(s, target, M, wl.intr, args[0]), api.get_image(s, target, M, wl.intr, args[1])]
                 elif op == "flush" and p.use_swapping:
                     api.save_to_global_memory(s)
             if op == "fuse" and not args[0] and use_store:
@@ -162,7 +166,14 @@ def _trial(pkg, synth, gpu, oracle, seed, use_store=None):
 #          not fitted kept the "marked again next pass" encoding although the rebuilt list now held it (type 1, oracle 3)
 @pytest.mark.parametrize("seed", [10744])
 def test_regression_seeds(pkg, synth, gpu, oracle, seed):
-    _trial(pkg, synth, gpu, oracle, seed, use_store=False)
+    _trial(pkg, synth, gpu, oracle, seed, use_store=False, extras=False)
+
+
+#   60045  a raycast through the fusion render state (FindVisibleBlocks replaces its list), then a Decay that released
+#          entries which sat in that list without having a type: the engine rebuilt the list only when a typed entry left
+@pytest.mark.parametrize("seed", [60045])
+def test_regression_seeds_with_extras(pkg, synth, gpu, oracle, seed):
+    _trial(pkg, synth, gpu, oracle, seed)
 
 
 # DSLAM_FUZZ_SEEDS="first:count" widens the hunt (e.g. 5000:500); the default 60 trials take a few seconds
