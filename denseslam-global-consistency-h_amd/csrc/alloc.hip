@@ -574,14 +574,17 @@ __global__ __launch_bounds__(256) void k_alloc_sweep(SweepParams p) {
         load_vis(t0, in);
         settle(b, t0, in);
       } else if (p.do_commit && has_excess && in) {
-        // other tiles' commits may have created entries here: they carry this pass' mark; everything else was settled in A
+        // other tiles' commits may have created entries here: they carry this pass' mark; everything else was settled in A.
+        // A byte that differs from what this tile last saw or wrote IS such a mark -- also where the slot still carried
+        // a stale type of an entry that no longer exists (a render state that outlived a ResetScene: the stale byte
+        // used to hide the new entry's mark; fuzz seed 70473)
 #pragma unroll
         for (int q = 0; q < kSweepPer / 4; q++) {
           const uchar4 v4 = *reinterpret_cast<const uchar4 *>(p.vis_type + t0 + q * 4);
           const unsigned char nb4[4] = {v4.x, v4.y, v4.z, v4.w};
 #pragma unroll
           for (int kk = 0; kk < 4; kk++)
-            if (v[q * 4 + kk] == 0 && nb4[kk] != 0) { v[q * 4 + kk] = nb4[kk]; ty[q * 4 + kk] = nb4[kk] & 0x7f; }
+            if (nb4[kk] != v[q * 4 + kk]) { v[q * 4 + kk] = nb4[kk]; ty[q * 4 + kk] = nb4[kk] & 0x7f; }
         }
       }
       count_and_publish(b, t0);

@@ -13,7 +13,7 @@ import util
 pytestmark = pytest.mark.gpu
 
 
-def _trial(pkg, synth, gpu, oracle, seed, use_store=None, extras=True):
+def _trial(pkg, synth, gpu, oracle, seed, use_store=None, extras=True, more_ops=None):
     rng = np.random.default_rng(seed)
     rng_store = np.random.default_rng(seed + 7777777)  # (its own stream: trials without a store stay what they were)
     big = os.environ.get("DSLAM_FUZZ_BIG") == "1"  # one-off hunts: larger images, pools and longer sequences
@@ -45,6 +45,10 @@ def _trial(pkg, synth, gpu, oracle, seed, use_store=None, extras=True):
             stores[name] = api.create_frame_store(W, H, 12)
             api.frame_store_enable_lists(stores[name], s)
     stored = {}  # slot -> pose of the keyframe's last fusion
+    # half of the trials also call the swapping engine directly (ITMSwappingEngine::IntegrateGlobalIntoLocal /
+    # SaveToGlobalMemory outside ProcessFrame) and reset the map in mid-sequence (InfiniTamDriver::ResetLocalMap)
+    if more_ops is None:
+        more_ops = bool(extras and rng_store.random() < 0.5)
     # one trial in four has an RGB camera that is not the depth camera (the two-camera kernels; the reference's calib is
     # the identity, upstream's interface is general)
     two_cam = bool(rng_store.random() < 0.25)
@@ -62,7 +66,10 @@ def _trial(pkg, synth, gpu, oracle, seed, use_store=None, extras=True):
         fused = []
         for step in range(int(rng.integers(25, 45)) if big else int(rng.integers(10, 26))):
             op = rng.choice(["fuse", "fuse", "fuse", "refuse", "decay", "slide", "alloc_only", "raycast", "defusion_ring", "flush"] +
-                            (["refuse_stored", "refuse_stored"] if use_store else []))
+                            (["refuse_stored", "refuse_stored"] if use_store else []) +
+                            (["swap_in", "swap_out", "reset"] if more_ops else []))
+            if op == "reset" and rng_store.random() < 0.6:
+                op = "fuse"  # (a reset is a rare event)
             i = int(rng.integers(0, 12))
             rgba, mm, M = wl.frame(i)
             jitter = synth.pose_matrix(synth.look_rotation(rng.normal(0, 0.01), rng.normal(0, 0.01)), rng.normal(0, 0.01, 3))
@@ -130,6 +137,12 @@ def _trial(pkg, synth, gpu, oracle, seed, use_store=None, extras=True):
                     imgs[name] = [api.get_image(s, target, M, wl.intr, args[0]), api.get_image(s, target, M, wl.intr, args[1])]
                 elif op == "flush" and p.use_swapping:
                     api.save_to_global_memory(s)
+                elif op == "swap_in" and p.use_swapping:
+                    api.swap_in(s, rs)
+                elif op == "swap_out" and p.use_swapping:
+                    api.swap_out(s, rs)
+                elif op == "reset":
+                    api.reset_scene(s)
             if op == "fuse" and not args[0] and use_store:
                 stored[i] = M
             if op == "refuse_stored" and slot >= 0:
@@ -173,6 +186,13 @@ def test_regression_seeds(pkg, synth, gpu, oracle, seed):
 #          entries which sat in that list without having a type: the engine rebuilt the list only when a typed entry left
 @pytest.mark.parametrize("seed", [60045])
 def test_regression_seeds_with_extras(pkg, synth, gpu, oracle, seed):
+    _trial(pkg, synth, gpu, oracle, seed, more_ops=False)
+
+
+#   70473  ResetScene with a render state that outlives it: a new excess entry landed on a slot whose stale type byte the
+#          sweep took for its own and so missed the new entry's visible mark (entry allocated, never listed)
+@pytest.mark.parametrize("seed", [70473])
+def test_regression_seeds_with_more_ops(pkg, synth, gpu, oracle, seed):
     _trial(pkg, synth, gpu, oracle, seed)
 
 
