@@ -13,7 +13,7 @@ import util
 pytestmark = pytest.mark.gpu
 
 
-def _trial(pkg, synth, gpu, oracle, seed, use_store=None, extras=True, more_ops=None):
+def _trial(pkg, synth, gpu, oracle, seed, use_store=None, extras=True, more_ops=None, second_map=True):
     rng = np.random.default_rng(seed)
     rng_store = np.random.default_rng(seed + 7777777)  # (its own stream: trials without a store stay what they were)
     big = os.environ.get("DSLAM_FUZZ_BIG") == "1"  # one-off hunts: larger images, pools and longer sequences
@@ -49,6 +49,19 @@ def _trial(pkg, synth, gpu, oracle, seed, use_store=None, extras=True, more_ops=
     # SaveToGlobalMemory outside ProcessFrame) and reset the map in mid-sequence (InfiniTamDriver::ResetLocalMap)
     if more_ops is None:
         more_ops = bool(extras and rng_store.random() < 0.5)
+    # ... and fuse into a SECOND map of another size on the same engine now and then (the reference keeps several local
+    # maps; the engine's allocation scratch -- order keys, allocType bytes, request list -- is shared by all scenes)
+    other = {}
+    if more_ops and second_map:
+        kw2 = dict(kw)
+        kw2["num_local_blocks"] = int(rng_store.choice([0x200, 0x1000]))
+        kw2["num_buckets"] = int(rng_store.choice([0x100, 0x800, 0x2000]))
+        kw2["num_excess"] = int(rng_store.choice([0x80, 0x400]))
+        kw2["use_swapping"] = 0
+        p2 = pkg.SceneParams(**kw2)
+        for name, (api, *_r) in objs.items():
+            s2 = api.create_scene(p2)
+            other[name] = (s2, api.create_render_state(s2, W, H), api.create_view(W, H))
     # one trial in four has an RGB camera that is not the depth camera (the two-camera kernels; the reference's calib is
     # the identity, upstream's interface is general)
     two_cam = bool(rng_store.random() < 0.25)
@@ -67,7 +80,7 @@ def _trial(pkg, synth, gpu, oracle, seed, use_store=None, extras=True, more_ops=
         for step in range(int(rng.integers(25, 45)) if big else int(rng.integers(10, 26))):
             op = rng.choice(["fuse", "fuse", "fuse", "refuse", "decay", "slide", "alloc_only", "raycast", "defusion_ring", "flush"] +
                             (["refuse_stored", "refuse_stored"] if use_store else []) +
-                            (["swap_in", "swap_out", "reset"] if more_ops else []))
+                            (["swap_in", "swap_out", "reset"] if more_ops else []) + (["other_scene", "other_scene"] if more_ops and second_map else []))
             if op == "reset" and rng_store.random() < 0.6:
                 op = "fuse"  # (a reset is a rare event)
             i = int(rng.integers(0, 12))
@@ -143,6 +156,10 @@ def _trial(pkg, synth, gpu, oracle, seed, use_store=None, extras=True, more_ops=
                     api.swap_out(s, rs)
                 elif op == "reset":
                     api.reset_scene(s)
+                elif op == "other_scene":
+                    s2, rs2, v2 = other[name]
+                    api.view_update(v2, rgba, mm, timestamp=float(step))
+                    api.process_frame(s2, v2, rs2, M, wl.intr)
             if op == "fuse" and not args[0] and use_store:
                 stored[i] = M
             if op == "refuse_stored" and slot >= 0:
@@ -159,6 +176,9 @@ def _trial(pkg, synth, gpu, oracle, seed, use_store=None, extras=True, more_ops=
                         assert np.abs(a.astype(int) - b.astype(int)).max() <= 1, f"seed {seed} step {step}: image"
             snaps = {name: util.snapshot(api, s, rs) for name, (api, s, rs, v, free) in objs.items()}
             util.assert_same_state(snaps["gpu"], snaps["oracle"], f"seed {seed} step {step} after {log[-1]}")
+            if op == "other_scene":
+                snaps2 = {name: util.snapshot(objs[name][0], other[name][0], other[name][1]) for name in objs}
+                util.assert_same_state(snaps2["gpu"], snaps2["oracle"], f"seed {seed} step {step}: the second map")
             if p.use_swapping:
                 sw = [api.download_swap_states(s) for api, s, *_ in objs.values()]
                 assert np.array_equal(sw[0], sw[1]), f"seed {seed} step {step} after {log[-1]}: swap states"
@@ -193,7 +213,7 @@ def test_regression_seeds_with_extras(pkg, synth, gpu, oracle, seed):
 #          sweep took for its own and so missed the new entry's visible mark (entry allocated, never listed)
 @pytest.mark.parametrize("seed", [70473])
 def test_regression_seeds_with_more_ops(pkg, synth, gpu, oracle, seed):
-    _trial(pkg, synth, gpu, oracle, seed)
+    _trial(pkg, synth, gpu, oracle, seed, second_map=False)
 
 
 # DSLAM_FUZZ_SEEDS="first:count" widens the hunt (e.g. 5000:500); the default 60 trials take a few seconds
