@@ -13,7 +13,7 @@ import util
 pytestmark = pytest.mark.gpu
 
 
-def _trial(pkg, synth, gpu, oracle, seed, use_store=None, extras=True, more_ops=None, second_map=True):
+def _trial(pkg, synth, gpu, oracle, seed, use_store=None, extras=True, more_ops=None, second_map=True, ops_v=2):
     rng = np.random.default_rng(seed)
     rng_store = np.random.default_rng(seed + 7777777)  # (its own stream: trials without a store stay what they were)
     big = os.environ.get("DSLAM_FUZZ_BIG") == "1"  # one-off hunts: larger images, pools and longer sequences
@@ -80,7 +80,7 @@ def _trial(pkg, synth, gpu, oracle, seed, use_store=None, extras=True, more_ops=
         for step in range(int(rng.integers(25, 45)) if big else int(rng.integers(10, 26))):
             op = rng.choice(["fuse", "fuse", "fuse", "refuse", "decay", "slide", "alloc_only", "raycast", "defusion_ring", "flush"] +
                             (["refuse_stored", "refuse_stored"] if use_store else []) +
-                            (["swap_in", "swap_out", "reset"] if more_ops else []) + (["other_scene", "other_scene"] if more_ops and second_map else []))
+                            ((["swap_in", "swap_out", "reset"] + (["icp_maps", "stepwise"] if ops_v >= 2 else [])) if more_ops else []) + (["other_scene", "other_scene"] if more_ops and second_map else []))
             if op == "reset" and rng_store.random() < 0.6:
                 op = "fuse"  # (a reset is a rare event)
             i = int(rng.integers(0, 12))
@@ -156,6 +156,13 @@ def _trial(pkg, synth, gpu, oracle, seed, use_store=None, extras=True, more_ops=
                     api.swap_out(s, rs)
                 elif op == "reset":
                     api.reset_scene(s)
+                elif op == "icp_maps":  # trackingController->Prepare: a raycast through the map's OWN render state
+                    imgs[name] = list(api.create_icp_maps(s, rs, M, wl.intr)) + [api.download_raycast_image(rs)]
+                elif op == "stepwise":  # ITMVisualisationEngine's steps one by one, into the free-view render state
+                    api.find_visible_blocks(s, free, M, wl.intr)
+                    api.create_expected_depths(s, free, M, wl.intr)
+                    imgs[name] = [api.render_image(s, free, M, wl.intr, pkg.IMAGE_DEPTH),
+                                  np.asarray(api.count_visible_blocks(s, free, 0, p.num_local_blocks), np.float32).reshape(1)]
                 elif op == "other_scene":
                     s2, rs2, v2 = other[name]
                     api.view_update(v2, rgba, mm, timestamp=float(step))
@@ -168,6 +175,14 @@ def _trial(pkg, synth, gpu, oracle, seed, use_store=None, extras=True, more_ops=
                 rgba_n = rgba.copy()
                 rgba_n[..., 3] = 255 if args[1] else rgba[..., 3]
                 fused.append((rgba_n, mm, M))
+            if op == "icp_maps" and imgs:
+                (p0, n0, g0), (p1, n1, g1) = imgs["gpu"], imgs["oracle"]
+                assert np.array_equal(p0[..., 3], p1[..., 3]), f"seed {seed} step {step}: ICP map validity"
+                assert np.abs(p0 - p1).max() <= 1e-4 and np.abs(n0 - n1).max() <= 1e-3, f"seed {seed} step {step}: ICP maps"
+                assert np.abs(g0.astype(int) - g1.astype(int)).max() <= 1, f"seed {seed} step {step}: tracking raycast image"
+            if op == "stepwise" and imgs:
+                assert np.abs(imgs["gpu"][0] - imgs["oracle"][0]).max() <= 1e-4, f"seed {seed} step {step}: stepwise depth image"
+                assert imgs["gpu"][1][0] == imgs["oracle"][1][0], f"seed {seed} step {step}: visible block count"
             if op == "raycast":
                 for kind, a, b in zip(args, imgs["gpu"], imgs["oracle"]):
                     if kind == pkg.IMAGE_DEPTH:
@@ -213,7 +228,7 @@ def test_regression_seeds_with_extras(pkg, synth, gpu, oracle, seed):
 #          sweep took for its own and so missed the new entry's visible mark (entry allocated, never listed)
 @pytest.mark.parametrize("seed", [70473])
 def test_regression_seeds_with_more_ops(pkg, synth, gpu, oracle, seed):
-    _trial(pkg, synth, gpu, oracle, seed, second_map=False)
+    _trial(pkg, synth, gpu, oracle, seed, second_map=False, ops_v=1)
 
 
 # DSLAM_FUZZ_SEEDS="first:count" widens the hunt (e.g. 5000:500); the default 60 trials take a few seconds
