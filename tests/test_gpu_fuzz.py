@@ -74,6 +74,11 @@ def _trial(pkg, synth, gpu, oracle, seed, use_store=None, extras=True, more_ops=
         max_new_w = int(rng.integers(2, 6))
         for api, *_ in objs.values():
             api.set_fusion_weight_params(depth_weighting=True, max_new_w=max_new_w, max_distance=3.0)
+    # a third of the trials run the HIP engine in async mode (calls return once their work is queued, as the pipelined
+    # bench loop drives it): everything has to be ordered by the stream alone; the snapshots below wait for it
+    async_mode = bool(extras and ops_v >= 2 and rng_store.random() < 0.33)
+    if async_mode:
+        gpu.set_async(True)
     log = []
     try:
         fused = []
@@ -204,6 +209,8 @@ def _trial(pkg, synth, gpu, oracle, seed, use_store=None, extras=True, more_ops=
         assert np.array_equal(meshes["gpu"][0], meshes["oracle"][0]), f"seed {seed}: mesh positions"
         assert np.array_equal(meshes["gpu"][1], meshes["oracle"][1]), f"seed {seed}: mesh colours"
     finally:
+        if async_mode:
+            gpu.set_async(False)
         for api, *_ in objs.values():
             api.set_fusion_weight_params()
     return log
