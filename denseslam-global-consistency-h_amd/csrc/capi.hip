@@ -379,12 +379,16 @@ int dslam_scene_get_params(const dslam_scene *s, dslam_scene_params *out) {
 
 int dslam_scene_set_shard(dslam_scene *s, int shard, int num_shards, int chunk_blocks) {
   DSLAM_REQUIRE(s && num_shards >= 1 && shard >= 0 && shard < num_shards && chunk_blocks >= 1, "bad shard spec");
+  // A rank that does not own a block still swaps its (stale) copy of it out to ITS host store during the batch, and
+  // the exchange moves device blocks only: the ranks' global caches would drift apart.  Refused, not silently wrong.
+  DSLAM_REQUIRE(!(s->p.use_swapping && num_shards > 1), "a scene with host swapping cannot be sharded (the host store is per rank)");
   s->shard = shard; s->num_shards = num_shards; s->chunk_blocks = chunk_blocks;
   return DSLAM_OK;
 }
 
 int dslam_scene_set_shard_range(dslam_scene *s, int first_block, int num_blocks) {
   DSLAM_REQUIRE(s && first_block >= 0, "bad shard range");
+  DSLAM_REQUIRE(!(s->p.use_swapping && num_blocks >= 0), "a scene with host swapping cannot be sharded (the host store is per rank)");
   s->shard_first = first_block; s->shard_count = num_blocks;
   return DSLAM_OK;
 }

@@ -462,7 +462,9 @@ void *dslam_render_state_image_dev(dslam_render_state *r, int want_float);
 /* ---- sharded re-integration (multi-GPU) ------------------------------------------------ */
 /* Restrict the voxel-writing kernels (integrate / de-integrate) of this scene to the voxel-block slots
  * whose chunk (slot / chunk_blocks) satisfies chunk % num_shards == shard; allocation stays global
- * (and bit-identical on every rank).  num_shards = 1 disables sharding. */
+ * (and bit-identical on every rank).  num_shards = 1 disables sharding.  A scene with host swapping cannot be sharded
+ * (DSLAM_ERR_INVALID): every rank would swap its own, partly stale copies out to its own host store, which the block
+ * exchange does not cover.  (The reference never turns swapping on: its ITMLibSettings is default-constructed.) */
 int dslam_scene_set_shard(dslam_scene *s, int shard, int num_shards, int chunk_blocks);
 /* Same, with a contiguous slot range [first_block, first_block + num_blocks): the layout an in-place RCCL
  * all-gather over the voxel-block array needs.  num_blocks < 0 disables. */

@@ -552,10 +552,12 @@ extern "C" int oracle_scene_create(oracle_engine *e, const dslam_scene_params *p
 }
 extern "C" int oracle_scene_destroy(oracle_scene *s) { if (s) { free(s->stored); delete s; } return 0; }
 extern "C" int oracle_scene_set_shard(oracle_scene *s, int shard, int num_shards, int chunk_blocks) {
+  if (s->p.use_swapping && num_shards > 1) return DSLAM_ERR_INVALID;  // (as the engine: the host store is per rank)
   s->shard = shard; s->num_shards = num_shards; s->chunk_blocks = chunk_blocks; return 0;
 }
 
 extern "C" int oracle_scene_set_shard_range(oracle_scene *s, int first, int count) {
+  if (s->p.use_swapping && count >= 0) return DSLAM_ERR_INVALID;
   s->shard_first = first; s->shard_count = count; return 0;
 }
 

@@ -224,6 +224,23 @@ def test_full_size_parity_with_oracle(pkg, synth, gpu, oracle, swapping):
     assert np.abs(imgs["gpu"][1].astype(int) - imgs["oracle"][1].astype(int)).max() <= 1
 
 
+def test_sharding_a_swapping_scene_is_refused(pkg, synth, gpu, oracle):
+    """The sharded batch exchanges device blocks only; with host swapping every rank would also swap its own, partly
+    stale copies out to its own host store (found by the fuzz test: a sharded re-fusion on a swapping scene left the
+    replicas' maps different from the unsharded one).  Both engines refuse the combination instead."""
+    wl = synth.s_tiny()
+    for api in (gpu, oracle):
+        s = api.create_scene(util.small_params(pkg, wl, use_swapping=1))
+        with pytest.raises(pkg.DslamError):
+            api.set_shard(s, 0, 2, 16)
+        with pytest.raises(pkg.DslamError):
+            api.set_shard_range(s, 0, 64)
+        api.set_shard(s, 0, 1, 16)      # "not sharded" stays legal
+        api.set_shard_range(s, 0, -1)
+        s2 = api.create_scene(util.small_params(pkg, wl))
+        api.set_shard(s2, 1, 2, 16)     # and a scene without swapping shards as before
+
+
 @pytest.mark.parametrize("maintenance", [False, True])
 def test_sharded_reintegration_exchanges_dirty_blocks(pkg, synth, gpu, oracle, maintenance):
     """The multi-GPU re-integration scheme rehearsed on one GPU: `world` map replicas play the ranks, each

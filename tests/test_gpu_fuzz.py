@@ -31,7 +31,11 @@ def _trial(pkg, synth, gpu, oracle, seed, use_store=None, extras=True, more_ops=
     kw["use_swapping"] = int(rng.random() < 0.25)
     p = pkg.SceneParams(**kw)
     objs = {}
-    for name, api in (("gpu", gpu), ("oracle", oracle)):
+    # one trial in four keeps a SECOND replica of the map on the HIP engine, fed the same calls, and runs every re-fusion
+    # as a two-rank sharded batch: each replica de-/re-integrates only its own slot chunks, the blocks the
+    # batch touched are exchanged (dslam_shard_dirty_plan / _pack / _unpack), both replicas must equal the unsharded oracle
+    shard_mode = bool(extras and ops_v >= 2 and not p.use_swapping and np.random.default_rng(seed + 4242424).random() < 0.25)
+    for name, api in (("gpu", gpu), ("oracle", oracle)) + ((("gpu2", gpu),) if shard_mode else ()):
         s = api.create_scene(p)
         objs[name] = (api, s, api.create_render_state(s, W, H), api.create_view(W, H), api.create_render_state(s, W, H))
     # every second trial also keeps its fused keyframes in a keyframe store with their fusion-time visible lists and
@@ -117,6 +121,12 @@ def _trial(pkg, synth, gpu, oracle, seed, use_store=None, extras=True, more_ops=
             if op == "refuse_stored" and stored:
                 slot = int(rng_store.choice(sorted(stored)))
             log.append((op, i, args))
+            sharded = shard_mode and ((op == "refuse" and bool(fused)) or (op == "refuse_stored" and slot >= 0))
+            chunk = 8
+            if sharded:
+                for k, name in enumerate(("gpu", "gpu2")):
+                    gpu.track_dirty(objs[name][1], True)
+                    gpu.set_shard(objs[name][1], k, 2, chunk)
             imgs = {}
             for name, (api, s, rs, v, free) in objs.items():
                 if op == "fuse":
@@ -172,6 +182,21 @@ def _trial(pkg, synth, gpu, oracle, seed, use_store=None, extras=True, more_ops=
                     s2, rs2, v2 = other[name]
                     api.view_update(v2, rgba, mm, timestamp=float(step))
                     api.process_frame(s2, v2, rs2, M, wl.intr)
+            if sharded:  # the exchange: both ranks derive the same lists, each packs its shard, both unpack the other's
+                import torch
+                counts = [gpu.shard_dirty_plan(objs[name][1], 2, chunk) for name in ("gpu", "gpu2")]
+                assert counts[0] == counts[1], f"seed {seed} step {step}: ranks disagree about the dirty lists"
+                cap = max(1, max(counts[0]))
+                recv = torch.zeros((2, cap, 4096), dtype=torch.uint8, device="cuda")
+                torch.cuda.synchronize()  # (torch fills on its own stream; the engine packs on its own)
+                for k, name in enumerate(("gpu", "gpu2")):
+                    gpu.shard_dirty_pack(objs[name][1], k, recv[k].data_ptr(), cap)
+                gpu.synchronize()
+                for k, name in enumerate(("gpu", "gpu2")):
+                    gpu.shard_dirty_unpack(objs[name][1], k, recv.data_ptr(), cap)
+                    gpu.set_shard(objs[name][1], 0, 1, chunk)
+                    gpu.track_dirty(objs[name][1], False)
+                gpu.synchronize()
             if op == "fuse" and not args[0] and use_store:
                 stored[i] = M
             if op == "refuse_stored" and slot >= 0:
@@ -196,6 +221,8 @@ def _trial(pkg, synth, gpu, oracle, seed, use_store=None, extras=True, more_ops=
                         assert np.abs(a.astype(int) - b.astype(int)).max() <= 1, f"seed {seed} step {step}: image"
             snaps = {name: util.snapshot(api, s, rs) for name, (api, s, rs, v, free) in objs.items()}
             util.assert_same_state(snaps["gpu"], snaps["oracle"], f"seed {seed} step {step} after {log[-1]}")
+            if shard_mode:
+                util.assert_same_state(snaps["gpu2"], snaps["oracle"], f"seed {seed} step {step} after {log[-1]}: second replica")
             if op == "other_scene":
                 snaps2 = {name: util.snapshot(objs[name][0], other[name][0], other[name][1]) for name in objs}
                 util.assert_same_state(snaps2["gpu"], snaps2["oracle"], f"seed {seed} step {step}: the second map")
