@@ -117,6 +117,9 @@ def _trial(pkg, synth, gpu, oracle, seed, use_store=None, extras=True, more_ops=
             # one raycast in five goes through the FUSION render state: its visible list is replaced behind the types' back
             # (upstream's FindVisibleBlocks writes renderState->visibleEntryIDs), which the next allocation pass must digest
             same_rs = bool(extras and op == "raycast" and rng_store.random() < 0.2)
+            # one fusion in eight goes through the OTHER render state (a scene fused through two render states: each has its
+            # own visible list, types and generation bit; upstream's local maps each own one)
+            fuse_free = bool(more_ops and ops_v >= 2 and op == "fuse" and rng_store.random() < 0.125)
             slot = -1
             if op == "refuse_stored" and stored:
                 slot = int(rng_store.choice(sorted(stored)))
@@ -136,9 +139,9 @@ def _trial(pkg, synth, gpu, oracle, seed, use_store=None, extras=True, more_ops=
                         api.view_update(v, rgba, mm, timestamp=float(step), bilateral=args[0])
                     if use_store and not args[0]:  # (the store keeps the unfiltered images)
                         api.frame_store_put_view(stores[name], i, v)
-                    api.process_frame(s, v, rs, M, wl.intr, **cam(M))
+                    api.process_frame(s, v, free if fuse_free else rs, M, wl.intr, **cam(M))
                     if use_store and not args[0]:
-                        api.frame_store_put_visible_list(stores[name], i, s, rs)
+                        api.frame_store_put_visible_list(stores[name], i, s, free if fuse_free else rs)
                 elif op == "refuse_stored" and slot >= 0:
                     api.view_update_from_store(v, stores[name], slot, timestamp=float(step))
                     api.deprocess_frame_stored(s, v, stores[name], slot, stored[slot], wl.intr, **cam(stored[slot]))
@@ -223,6 +226,9 @@ def _trial(pkg, synth, gpu, oracle, seed, use_store=None, extras=True, more_ops=
             util.assert_same_state(snaps["gpu"], snaps["oracle"], f"seed {seed} step {step} after {log[-1]}")
             if shard_mode:
                 util.assert_same_state(snaps["gpu2"], snaps["oracle"], f"seed {seed} step {step} after {log[-1]}: second replica")
+            if fuse_free:
+                snaps_f = {name: util.snapshot(api, s, free) for name, (api, s, rs, v, free) in objs.items()}
+                util.assert_same_state(snaps_f["gpu"], snaps_f["oracle"], f"seed {seed} step {step}: fused through the other render state")
             if op == "other_scene":
                 snaps2 = {name: util.snapshot(objs[name][0], other[name][0], other[name][1]) for name in objs}
                 util.assert_same_state(snaps2["gpu"], snaps2["oracle"], f"seed {seed} step {step}: the second map")
