@@ -636,7 +636,10 @@ __global__ __launch_bounds__(kWgWaves * 64, 8) void k_integrate(IntegrateParams 
   const int nvis = p.rc->no_visible;
   if (p.timer_slot && blockIdx.x == 0 && threadIdx.x == 0) *p.timer_slot = nvis;
   DSLAM_STAMP(2);
-  int G = (nvis + n_waves - 1) / n_waves;
+  // entries per wave and round: the largest group that still gives EVERY wave of the grid a group (floor, not ceil: with
+  // 11 k visible blocks on 8192 waves, one full round of single blocks plus a partial second one beats 5.5 k waves of two
+  // blocks each -- 1.5-2.7 % on the re-integration batch, whose launches see that many)
+  int G = nvis / n_waves;
   G = G < 1 ? 1 : (G > kMaxGroup ? kMaxGroup : G);
 
   // lane-constant voxel coordinates inside a block
@@ -651,7 +654,7 @@ __global__ __launch_bounds__(kWgWaves * 64, 8) void k_integrate(IntegrateParams 
     // all, leaves 28 spills instead of 72 and is SLOWER, 22.8 us: the loads sit on every wave's critical path.)
     int e_ptr = -2, e_px = 0, e_py = 0, e_pz = 0;
     if (lane < G && base + lane < nvis) {
-      const HashEntry e = load_entry(p.hash, (PLAIN && p.spec_ids && G == 1) ? id_spec : p.visible_ids[base + lane]);
+      const HashEntry e = load_entry(p.hash, (PLAIN && p.spec_ids && G == 1 && base == wave) ? id_spec : p.visible_ids[base + lane]);
       e_ptr = e.ptr; e_px = e.pos[0]; e_py = e.pos[1]; e_pz = e.pos[2];
       if (!PLAIN && p.expect_pos) {  // a list stored with a keyframe: the entry must still hold the block it held then
         const short4 ep = p.expect_pos[base + lane];
