@@ -300,9 +300,10 @@ __global__ __launch_bounds__(256) void k_push_freed_finalize(unsigned char *free
 // fuzz test, seed 10744: list full after an allocation-only pass, then a window pop, then a fusion).
 __global__ __launch_bounds__(256) void k_rebuild_visible(unsigned char *__restrict__ vis_type, int n_entries, int *ids,
                                                          int capacity, RenderCounters *rc, int *maint_flags,
-                                                         unsigned long long *agg, unsigned epoch, int n_tiles, unsigned gen) {
+                                                         unsigned long long *agg, unsigned epoch, int n_tiles, unsigned gen,
+                                                         int force) {
   __shared__ int red[8];
-  if (maint_flags[0] == 0) return;
+  if (maint_flags[0] == 0 && !force) return;  // (force: the host knows the list has to be rebuilt -- the swapping paths)
   for (int b = blockIdx.x; b < n_tiles; b += gridDim.x) {
     const int t0 = b * kSweepTile + threadIdx.x * kSweepPer;
     unsigned m = 0;
@@ -372,14 +373,13 @@ static int lookback_grid(dslam_engine *e, int n_tiles) {
 }
 
 static int rebuild_visible_list(dslam_engine *e, dslam_render_state *r) {
-  // (the swapping paths call this directly after they have changed types themselves)
-  // the list no longer is "what the last pass left visible": the next allocation pass re-derives the marks from it
-  // (an entry that had not fitted into that pass' list may be listed now, see k_rebuild_visible)
-  r->types_follow_list = false;
-  const int N = r->n_entries, n_tiles = num_tiles(N);
-  hipLaunchKernelGGL(k_flag_count, dim3(n_tiles), dim3(256), 0, e->stream, r->visible_type, N, e->tile_counts);
-  hipLaunchKernelGGL(k_compact_apply_fused, dim3(n_tiles), dim3(256), 0, e->stream, r->visible_type, N, e->tile_counts,
-                     r->visible_ids, r->n_local, &r->counters->no_visible);
+  // (the swapping paths call this directly after they have changed types themselves: the same single-pass rebuild as
+  // the release pipeline's, forced -- it also takes the "marked again" bit off entries that had not fitted into the last
+  // pass' list and are listed now, see k_rebuild_visible)
+  const int v_tiles = (r->n_entries + kSweepTile - 1) / kSweepTile;
+  hipLaunchKernelGGL(k_rebuild_visible, dim3(lookback_grid(e, v_tiles)), dim3(256), 0, e->stream, r->visible_type,
+                     r->n_entries, r->visible_ids, r->n_local, r->counters, e->maint_flags, e->agg, next_epoch(e), v_tiles,
+                     (unsigned)r->gen, 1);
   DSLAM_HIP(hipGetLastError());
   return DSLAM_OK;
 }
@@ -400,7 +400,7 @@ static int release_listed(dslam_engine *e, dslam_scene *s, dslam_render_state *r
     const int v_tiles = (r->n_entries + kSweepTile - 1) / kSweepTile;
     hipLaunchKernelGGL(k_rebuild_visible, dim3(lookback_grid(e, v_tiles)), dim3(256), 0, e->stream, r->visible_type,
                        r->n_entries, r->visible_ids, r->n_local, r->counters, e->maint_flags, e->agg, next_epoch(e), v_tiles,
-                       (unsigned)r->gen);
+                       (unsigned)r->gen, 0);
   }
   DSLAM_HIP(hipGetLastError());
   return DSLAM_OK;
