@@ -34,7 +34,10 @@ def _trial(pkg, synth, gpu, oracle, seed, use_store=None, extras=True, more_ops=
     # one trial in four keeps a SECOND replica of the map on the HIP engine, fed the same calls, and runs every re-fusion
     # as a two-rank sharded batch: each replica de-/re-integrates only its own slot chunks, the blocks the
     # batch touched are exchanged (dslam_shard_dirty_plan / _pack / _unpack), both replicas must equal the unsharded oracle
-    shard_mode = bool(extras and ops_v >= 2 and not p.use_swapping and np.random.default_rng(seed + 4242424).random() < 0.25)
+    # (tests/test_oracle_fuzz.py runs these trials with two CPU oracles: the dimensions that need the HIP engine -- device
+    # buffers for the exchange, async mode -- are left out there)
+    is_hip = gpu.has("engine_set_async")
+    shard_mode = bool(is_hip and extras and ops_v >= 2 and not p.use_swapping and np.random.default_rng(seed + 4242424).random() < 0.25)
     for name, api in (("gpu", gpu), ("oracle", oracle)) + ((("gpu2", gpu),) if shard_mode else ()):
         s = api.create_scene(p)
         objs[name] = (api, s, api.create_render_state(s, W, H), api.create_view(W, H), api.create_render_state(s, W, H))
@@ -80,7 +83,7 @@ def _trial(pkg, synth, gpu, oracle, seed, use_store=None, extras=True, more_ops=
             api.set_fusion_weight_params(depth_weighting=True, max_new_w=max_new_w, max_distance=3.0)
     # a third of the trials run the HIP engine in async mode (calls return once their work is queued, as the pipelined
     # bench loop drives it): everything has to be ordered by the stream alone; the snapshots below wait for it
-    async_mode = bool(extras and ops_v >= 2 and rng_store.random() < 0.33)
+    async_mode = bool(extras and ops_v >= 2 and rng_store.random() < 0.33) and is_hip
     if async_mode:
         gpu.set_async(True)
     log = []
