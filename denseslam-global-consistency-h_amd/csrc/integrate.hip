@@ -603,7 +603,7 @@ __global__ __launch_bounds__(kWgWaves * 64, 8) void k_integrate(IntegrateParams 
 #define DSLAM_STAMP(k) do { if constexpr (DIAG) { if (lane == 0 && diag_first) p.dbg_waves[(size_t)wave * 16 + (k)] = wall_clock64(); } } while (0)
   // the one-camera fusion variant runs its colour updates densely from a per-wave LDS queue (fuse_colour_word)
   constexpr bool kQueueColour = SAME_CAM && DSLAM_PACKED && DSLAM_COLOUR_QUEUE;
-  // the split update (pair_project / pair_update): plain fusion, and the one-camera de-integration (41.6 -> ... us per
+  // the split update (pair_project / pair_update): plain fusion, and the one-camera de-integration (41.6 -> 34.2 us per
   // launch against the voxel-by-voxel form it replaces; the general fusion variant has no registers for it)
   constexpr bool kPairPath = PLAIN || (DEINT && kQueueColour);
   // The queue of one wave.  The data of a queued voxel sits at the voxel's OWN place (chunk-voxel k of lane l: k * 64 + l:
