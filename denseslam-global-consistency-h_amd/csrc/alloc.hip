@@ -7,11 +7,13 @@
 // Allocation is bit-exact with the sequential CPU engine ("last writer in row-major pixel order wins", pool
 // slots handed out in ascending hash-index order) although it runs wave-parallel, in two launches:
 //   k_mark         per pixel, walk the +-mu segment in block units; misses do atomicMax(order_key[slot], pixel*cap+step+1)
-//   k_alloc_sweep  one pass over the table: the final key of a slot names its winner, whose walk is replayed to the
-//                  block it asked for; the r-th requesting entry in hash-index order gets voxelAllocationList[lastFree - r]
-//                  (pool exhaustion follows the closed form derived in DESIGN.md); entries visible in the previous pass
-//                  are re-tested against the frustum; visibleEntryIDs is written ascending in hash index.  The ordered
-//                  ranks come from per-tile counts exchanged INSIDE the launch (see below).
+//                  and set the slot's bit in a request bitmap; found entries get their type and a bit in `mark`
+//   k_alloc_sweep  one pass over the BITMAPS (not the table): the final key of a requested slot names its winner, whose
+//                  walk is replayed to the block it asked for; the r-th requesting entry in hash-index order gets
+//                  voxelAllocationList[lastFree - r] (pool exhaustion follows the closed form derived in DESIGN.md);
+//                  entries visible in the previous pass are re-tested against the frustum (by a job inside k_mark's
+//                  launch); visibleEntryIDs is written ascending in hash index.  The ordered ranks are popcounts plus
+//                  per-tile counts exchanged INSIDE the launch (see below).
 // No host round trip between the phases: every count lives in device memory (SceneCounters/RenderCounters).
 #include <cstdio>
 #include <cstdlib>
@@ -62,7 +64,30 @@ int launch_scene_reset(dslam_engine *e, dslam_scene *s) {
                      s->last_seen, s->p.num_local_blocks, s->excess_list, s->p.num_excess, s->counters);
   DSLAM_HIP(hipMemsetAsync(s->masks, 0, (size_t)s->p.num_local_blocks * 2 * s->history_words * sizeof(unsigned long long),
                            e->stream));
-  if (s->swap_state) DSLAM_HIP(hipMemsetAsync(s->swap_state, 0, s->n_entries, e->stream));
+  if (s->swap_state) {
+    DSLAM_HIP(hipMemsetAsync(s->swap_state, 0, s->n_entries, e->stream));
+    DSLAM_HIP(hipMemsetAsync(s->swap1_bits, 0, (size_t)bit_tiles(s->n_entries) * kBitTileWords * sizeof(unsigned), e->stream));
+  }
+  DSLAM_HIP(hipMemsetAsync(s->alloc_bits, 0, (size_t)bit_tiles(s->n_entries) * kBitTileWords * sizeof(unsigned), e->stream));
+  DSLAM_HIP(hipGetLastError());
+  return DSLAM_OK;
+}
+
+// alloc_bits from the table itself (after a table was uploaded: map restore, synthetic stress maps): the one pass that
+// still reads every entry, off every hot path
+__global__ __launch_bounds__(256) void k_build_alloc_bits(const HashEntry *__restrict__ hash, int n_entries, unsigned *alloc_bits) {
+  const int w = blockIdx.x * 256 + threadIdx.x;   // (the grid covers whole bitmap tiles)
+  unsigned out = 0;
+  for (int k = 0; k < 32; k++) {
+    const int t = w * 32 + k;
+    if (t < n_entries && hash[t].ptr >= 0) out |= 1u << k;
+  }
+  alloc_bits[w] = out;
+}
+
+int launch_build_alloc_bits(dslam_engine *e, dslam_scene *s) {
+  const int n_words = bit_tiles(s->n_entries) * kBitTileWords;
+  hipLaunchKernelGGL(k_build_alloc_bits, dim3(n_words / 256), dim3(256), 0, e->stream, s->hash, s->n_entries, s->alloc_bits);
   DSLAM_HIP(hipGetLastError());
   return DSLAM_OK;
 }
@@ -101,23 +126,26 @@ int ensure_view_depth(dslam_engine *e, const dslam_view *v) {
 // ---------------------------------------------------------------------------------------------------------
 // AllocateSceneFromDepth
 // ---------------------------------------------------------------------------------------------------------
-// TWO launches (round 1 needed six, each ~4.5 us even when nearly empty on this 8-XCD part):
-//   k_mark         per pixel: derive the float depth, walk the +-mu segment, mark found entries visible, race for the
-//                  order key of every missing block (atomicMax: the last pixel/step in row-major order wins)
-//   k_alloc_sweep  ONE pass over the table that does what used to be winners -> commit -> visible count -> compaction:
-//                  an ordered compaction normally needs a grid-wide dependency between counting and placing; here every
-//                  tile publishes its counts in an 8-byte {epoch, counts} word the moment it has them and the tiles
-//                  behind it add up the words in front of them inside the same launch (decoupled look-back on
-//                  agent-scope relaxed atomics; all workgroups are co-resident, tiles are taken in ascending order, so
-//                  a tile only ever waits for tiles that are running or done).
-// What made the other launches disappear:
-//   * no clearing pass: the sweep zeroes exactly the keys that were set, and the mark kernel clears the allocType bytes
-//     of the previous pass through the list of requests the sweep left behind;
-//   * no second walk: the winner of a slot is its final key, and (pixel, step) is all it takes to replay that pixel's
-//     walk to the block it asked for (same float operations, same order -> same coordinates); whether it is an
-//     ordered (1) or excess (2) request follows from the entry the key sits on;
-//   * no re-arming pass: the visible types carry a generation bit, so "visible in the previous pass" (upstream sets
-//     those to 3 from the previous list) is simply a non-zero byte with the other bit.
+// TWO launches, and since round 3 neither reads the hash table as a whole: the 1.18 M-entry table is 19 MB, its keys and
+// types another 6 MB, and a frame touches ~8 k entries of it.  What a pass needs to know about "all entries" lives in
+// bitmaps of one bit per entry (147 KB each, dslam_device.h):
+//   k_mark        per pixel: derive the float depth, walk the +-mu segment, mark found entries visible (type byte + a bit
+//                 in `mark`), race for the order key of every missing block (atomicMax: the last pixel / step in
+//                 row-major order wins) and set the slot's bit in q1 (empty bucket head: ordered request) or q2 (end of
+//                 an occupied bucket's chain: excess request).  Its first workgroups run an independent job: the frustum
+//                 re-test of every entry the render state held visible before the pass (`vis_bits`), one bitmap word per
+//                 lane, outcome in `retest`.
+//   k_alloc_sweep one pass over the bitmaps (36 tiles of 32768 entries instead of 288 tiles of 4096 table entries): the
+//                 r-th requesting entry in hash-index order gets voxelAllocationList[lastFree - r] -- ranks are
+//                 popcounts; the winner of a slot is its final key, whose walk is replayed to the block it asked for;
+//                 visible entries = retest | mark | committed requests, written ascending.  Per-tile counts travel in
+//                 ONE in-launch look-back (both channels published before any work, tiles taken by ticket: a tile only
+//                 waits for workgroups that are running).  Nothing else is exchanged between tiles: what a tile of the
+//                 excess area needs to know about entries other tiles create there follows from the counts and the
+//                 excess free list.
+// What made the other launches disappear (round 2): no clearing pass (the sweep zeroes the keys it reads; allocType bytes
+// of the previous pass are cleared through that pass' request bits), no second walk (replay), no re-arming pass (the
+// visible types carry a generation bit, so "visible in the previous pass" is a non-zero byte with the other bit).
 struct MarkParams {
   const short *raw;    // non-null: the float depth image is derived here (UpdateView's conversion)
   float *depth;
@@ -134,9 +162,16 @@ struct MarkParams {
   unsigned gen;        // this pass' generation bit (0 or 0x80)
   int step_cap;
   SceneCounters *cnt;
-  unsigned char *alloc_type;   // allocType bytes of the previous pass are cleared through its request list
-  const int *req_list;
-  const int *req_count;
+  unsigned char *alloc_type;   // allocType bytes of the previous pass are cleared through its request bits
+  unsigned *q1, *q2, *mark;    // this pass' bitmaps (all zero when the pass starts)
+  const unsigned *old_q1, *old_q2;  // the previous pass' request bits
+  // the re-test job
+  const unsigned *vis_bits;
+  unsigned *retest;
+  int retest_wgs, n_words;
+  Mat4 M;
+  float fx, fy, voxel_size;
+  int swapping;
 };
 
 // the +-mu segment of a pixel in block units: start point, step vector, number of steps (buildHashAllocAndVisibleTypePP)
@@ -162,13 +197,39 @@ __device__ __forceinline__ int ray_segment(float d, int x, int y, const Mat4 &in
   return no_steps;
 }
 
-__global__ __launch_bounds__(256) void k_mark(MarkParams p) {
-  const int idx = blockIdx.x * 256 + threadIdx.x;
-  const int lane = threadIdx.x & 63;
-  {  // (independent job) forget the allocType bytes of the previous pass
-    const int n = *p.req_count;
-    for (int i = idx; i < n; i += gridDim.x * 256) p.alloc_type[p.req_list[i]] = 0;
+// The re-test job of k_mark: lane = one word of the render state's visible bits.  An entry whose type byte carries the
+// OTHER generation bit was visible in the previous pass (upstream re-arms it as 3 and tests it against the frustum); a
+// byte with THIS pass' bit is visible whatever the test says (marked by a pixel of this launch, or a 1 / 2 that did not
+// fit into the previous list and counts as marked again, see k_alloc_sweep).  The job only reads types: the bytes
+// belong to the pixel lanes of this launch; the sweep writes the 3s.
+__device__ __forceinline__ void retest_job(const MarkParams &p) {
+  const int w = blockIdx.x * 256 + threadIdx.x;
+  if (w == 0) {  // the pool tops as they are before this pass' commits (the sweep's last tile moves them)
+    p.cnt->base_free = p.cnt->last_free;
+    p.cnt->base_free_ex = p.cnt->last_free_ex;
   }
+  if (w >= p.n_words) return;
+  for (unsigned m = p.old_q1[w] | p.old_q2[w]; m; m &= m - 1) p.alloc_type[w * 32 + __ffs((int)m) - 1] = 0;
+  unsigned out = 0;
+  for (unsigned m = p.vis_bits[w]; m; m &= m - 1) {
+    const int bit = __ffs((int)m) - 1;
+    const int t = w * 32 + bit;
+    const unsigned char ty = p.vis_type[t];
+    if (ty == 0) continue;
+    if ((ty & 0x80u) == p.gen) { out |= 1u << bit; continue; }
+    const HashEntry e = load_entry(p.hash, t);
+    bool vis, vis_enl;
+    if (p.swapping) check_block_vis<true>(vis, vis_enl, e.pos[0], e.pos[1], e.pos[2], p.M, p.fx, p.fy, p.cx, p.cy, p.voxel_size, p.W, p.H);
+    else check_block_vis<false>(vis, vis_enl, e.pos[0], e.pos[1], e.pos[2], p.M, p.fx, p.fy, p.cx, p.cy, p.voxel_size, p.W, p.H);
+    if (p.swapping ? vis_enl : vis) out |= 1u << bit;
+  }
+  p.retest[w] = out;
+}
+
+__global__ __launch_bounds__(256) void k_mark(MarkParams p) {
+  if ((int)blockIdx.x < p.retest_wgs) { retest_job(p); return; }
+  const int idx = ((int)blockIdx.x - p.retest_wgs) * 256 + threadIdx.x;
+  const int lane = threadIdx.x & 63;
   // every lane stays in the kernel (invalid pixels march zero steps): the order-key atomics below are aggregated
   // per wavefront, which needs the wave converged
   const bool in_image = idx < p.W * p.H;
@@ -209,7 +270,9 @@ __global__ __launch_bounds__(256) void k_mark(MarkParams p) {
   }
   for (int i = 0; i < wave_steps; i++) {
     bool need = false;    // this lane asks for slot h at this step
+    bool need2 = false;   // ... and the slot is the end of an occupied bucket's chain (excess request)
     int h = 0;
+    int found_h = -1;     // entry this lane's walk found at this step
     if (i < no_steps) {
       const short bx = (short)(int)floorf(pt.x), by = (short)(int)floorf(pt.y), bz = (short)(int)floorf(pt.z);
       h = hash_index(bx, by, bz, p.mask);
@@ -232,19 +295,35 @@ __global__ __launch_bounds__(256) void k_mark(MarkParams p) {
           }
         }
         need = !found;
+        need2 = e.ptr >= -1;
       }
+      if (found) found_h = h;
       pt.x += dir.x; pt.y += dir.y; pt.z += dir.z;
     }
+    // the found entry's bit in `mark`: neighbouring pixels find the same entry (a block covers hundreds of pixels), so
+    // a lane whose left neighbour found the same one leaves it to that lane, and nobody sets a bit that is already there
+    // (a stale read only costs a redundant atomic)
+    {
+      const int left = __shfl_up(found_h, 1, 64);
+      if (found_h >= 0 && !(lane > 0 && left == found_h)) {
+        const unsigned bit = 1u << (found_h & 31);
+        unsigned *word = &p.mark[found_h >> 5];
+        if (!(__builtin_nontemporal_load(word) & bit)) atomicOr(word, bit);
+      }
+    }
     const unsigned key = (unsigned)idx * (unsigned)p.step_cap + (unsigned)i + 1u;
-    // Neighbouring pixels ask for the same slot (a block covers hundreds of pixels), and same-address atomics
-    // serialise at ~10 ns each on this part.  Keys grow with the pixel index, so within a wavefront the highest
-    // lane of each group of equal slots holds the group's maximum: only that lane issues the atomicMax.
+    // Neighbouring pixels ask for the same slot, and same-address atomics serialise at ~10 ns each on this part.  Keys
+    // grow with the pixel index, so within a wavefront the highest lane of each group of equal slots holds the group's
+    // maximum: only that lane issues the atomicMax (and the request bit).
     unsigned long long todo = __ballot(need);
     while (todo) {
       const int leader = __ffsll((long long)todo) - 1;
       const int hl = __shfl(h, leader, 64);
       const unsigned long long grp = __ballot(need && h == hl);
-      if (lane == 63 - __clzll((long long)grp)) atomicMax(&p.keys[h], key);
+      if (lane == 63 - __clzll((long long)grp)) {
+        atomicMax(&p.keys[h], key);
+        atomicOr(&(need2 ? p.q2 : p.q1)[h >> 5], 1u << (h & 31));
+      }
       todo &= ~grp;
     }
   }
@@ -252,22 +331,26 @@ __global__ __launch_bounds__(256) void k_mark(MarkParams p) {
 
 struct SweepParams {
   HashEntry *hash;
-  int n_entries, num_buckets, n_tiles;
+  int n_entries, num_buckets, n_tiles, n_words;   // n_words: whole tiles
   unsigned *keys;
   unsigned char *alloc_type;
   short4 *coords;
-  int *req_list;
-  int *req_count;
   const int *alloc_list;
   const int *excess_list;
   unsigned char *vis_type;
   unsigned char *swap_state;
+  unsigned *swap1_bits;
   SceneCounters *cnt;
   RenderCounters *rc;
   int *visible_ids;
   int capacity;
-  unsigned long long *agg_req, *agg_succ, *agg_vis;
+  const unsigned *q1, *q2, *mark, *retest;   // this pass
+  unsigned *oq1, *oq2, *omark;               // the other set: zeroed here for the next pass
+  unsigned *vis_bits, *alloc_bits;
+  unsigned long long *agg_req, *agg_vis;
   unsigned epoch;
+  unsigned *ticket;
+  unsigned ticket_base;
   unsigned gen;
   int do_commit;
   // replay of a winner's walk
@@ -276,434 +359,301 @@ struct SweepParams {
   Mat4 invM;
   float inv_fx, inv_fy, cx, cy, mu, one_over_block;
   int cap_shift;  // step_cap = 1 << cap_shift
-  unsigned long long *dbg;  // diagnostics (DSLAM_DBG_SWEEP=<file>): per tile 8 timestamps
-  // frustum re-test of the entries that were visible in the previous pass
-  Mat4 M;
-  float fx, fy, voxel_size;
 };
 
-// tile_block_vis for kSweepPer entries per thread: out[k] bit 0 = visible, bit 1 = visible in the enlarged frustum
-struct SweepVisScratch {
-  short4 pos[kSweepTile];
-  unsigned short idx[kSweepTile];
-  unsigned char res[kSweepTile];
-  int n;
-};
-
-template <bool SWAPPING>
-__device__ __forceinline__ void sweep_block_vis(SweepVisScratch &s, unsigned cand_mask, const HashEntry *__restrict__ hash,
-                                                int t0, const Mat4 &M, float fx, float fy, float cx, float cy,
-                                                float voxel_size, int W, int H, unsigned char out[kSweepPer]) {
-  if (threadIdx.x == 0) s.n = 0;
-#pragma unroll
-  for (int q = 0; q < kSweepPer / 4; q++) *reinterpret_cast<unsigned *>(&s.res[threadIdx.x * kSweepPer + q * 4]) = 0u;
-  __syncthreads();
-  for (unsigned m = cand_mask; m; m &= m - 1) {
-    const int k = __ffs((int)m) - 1;
-    const HashEntry e = load_entry(hash, t0 + k);
-    const int j = atomicAdd(&s.n, 1);
-    s.pos[j] = make_short4(e.pos[0], e.pos[1], e.pos[2], 0);
-    s.idx[j] = (unsigned short)(threadIdx.x * kSweepPer + k);
+// Pools that run out during the pass (rare): which requests get a block is the sequential rule over ALL requests in
+// hash-index order -- a type-1 request at entry t succeeds iff vr(t) = c1(t) + min(c2(t), availEx) < availVBA, a type-2
+// request iff also c2(t) < availEx (c1, c2: requests before t).  A tile behind the point where the voxel pool
+// ran dry cannot tell from per-tile counts how many requests in front of it succeeded, so it walks the request bitmaps
+// itself: thread i takes a contiguous range of words, a block scan gives it (c1, c2) at the start of its range.
+//   s1q: successful type-1 requests at words < limit_word whose entry is not in (retest | mark)
+//   f1s: FAILED type-1 requests at words < limit_word whose entry is in (retest | mark) -- a request that finds no block
+//        takes the entry off the visible list even if a stale type had put it there (upstream writes the type 0)
+//   s2 : successful type-2 requests (everywhere)
+__device__ void walk_requests(const SweepParams &p, int limit_word, int avail_vba, int avail_ex, int *lds, int &s1q, int &f1s,
+                              int &s2) {
+  const int nw = p.n_words, per = (nw + 255) / 256;
+  const int w_lo = threadIdx.x * per, w_hi = (w_lo + per) < nw ? (w_lo + per) : nw;
+  int c1 = 0, c2 = 0;
+  for (int w = w_lo; w < w_hi; w++) { c1 += __popc(p.q1[w]); c2 += __popc(p.q2[w]); }
+  int tot;
+  int r1 = block_excl_scan<4>(c1, lds, tot);
+  int r2 = block_excl_scan<4>(c2, lds, tot);
+  int n1q = 0, n1f = 0, n2 = 0;
+  for (int w = w_lo; w < w_hi; w++) {
+    const unsigned a = p.q1[w], b = p.q2[w];
+    if (!(a | b)) continue;
+    const unsigned seen = p.retest[w] | p.mark[w];
+    for (unsigned m = a | b; m; m &= m - 1) {
+      const int bit = __ffs((int)m) - 1;
+      const int vr = r1 + (r2 < avail_ex ? r2 : avail_ex);
+      if ((a >> bit) & 1u) {
+        if (w < limit_word) {
+          if (vr < avail_vba) n1q += !((seen >> bit) & 1u);
+          else n1f += (seen >> bit) & 1u;
+        }
+        r1++;
+      } else {
+        if (r2 < avail_ex && vr < avail_vba) n2++;
+        r2++;
+      }
+    }
   }
-  __syncthreads();
-  const int n = s.n;
-  for (int j = threadIdx.x; j < n; j += 256) {
-    const short4 b = s.pos[j];
-    bool vis, vis_enl;
-    check_block_vis<SWAPPING>(vis, vis_enl, b.x, b.y, b.z, M, fx, fy, cx, cy, voxel_size, W, H);
-    s.res[s.idx[j]] = (unsigned char)((vis ? 1 : 0) | (vis_enl ? 2 : 0));
-  }
-  __syncthreads();
-#pragma unroll
-  for (int q = 0; q < kSweepPer / 4; q++) {
-    const unsigned r = *reinterpret_cast<const unsigned *>(&s.res[threadIdx.x * kSweepPer + q * 4]);
-    out[q * 4] = r & 0xff; out[q * 4 + 1] = (r >> 8) & 0xff; out[q * 4 + 2] = (r >> 16) & 0xff; out[q * 4 + 3] = r >> 24;
-  }
+  int v[4] = {n1q, n2, n1f, 0};
+  block_sum4(v, lds);
+  s1q = v[0];
+  s2 = v[1];
+  f1s = v[2];
 }
 
-// Per tile: [A] winners -> requests (publish) -> ranks (look-back) -> commit (publish results);
-//           [B] settle the entries that were visible before (frustum re-test), count (publish), ranks (look-back), list.
-// B's loads and its frustum test do not depend on A's result, so a workgroup that owns ONE tile (the normal case: the grid
-// covers the table) runs them while it waits for A's look-back and keeps the outcome in registers; its visible count goes
-// out right after its own commits.  Only the tiles of the excess area, where OTHER tiles' commits create entries, have to
-// wait for every tile's commit word before they can count.  A workgroup that owns several tiles (a table larger than
-// the resident grid) does A for all of them, then B for all of them, so that no tile waits for one its own workgroup
-// has not started.
 template <bool SWAPPING>
 __global__ __launch_bounds__(256) void k_alloc_sweep(SweepParams p) {
-  __shared__ int red[2][8];
-  __shared__ SweepVisScratch vis_scratch;
-  // the pool tops are not modified before every tile has finished committing (the last tile folds the results in)
-  const int base_free = p.cnt->last_free, base_free_ex = p.cnt->last_free_ex;
+  __shared__ int red[16];
+  __shared__ int s_ticket;
+  __shared__ unsigned s_newx[kBitTileWords];   // entries other tiles' commits create in this tile (excess area)
+  // (snapshot taken by k_mark)
+  const int base_free = __builtin_amdgcn_readfirstlane(p.cnt->base_free), base_free_ex = __builtin_amdgcn_readfirstlane(p.cnt->base_free_ex);
   const int avail_vba = base_free + 1, avail_ex = base_free_ex + 1;
-  const bool single = (int)gridDim.x >= p.n_tiles;  // every workgroup owns exactly one tile
-  int all_requests = 0;                             // (kept by the workgroup that owns the last tile)
-  // state a single-tile workgroup carries from A to B
-  unsigned char v[kSweepPer], ty[kSweepPer];
-  int vis_rank = 0, vis_tot = 0;
-  bool vis_published = false;
-#define STAMP(i) if (p.dbg && threadIdx.x == 0) p.dbg[(size_t)b * 8 + (i)] = __builtin_amdgcn_s_memtime()
-
-  // B, first half: types of this tile's entries after the pass (0: not visible) and their number.  `reload`: read the
-  // bytes (again) -- everything that can write them from outside this workgroup has been waited for.
-  auto load_vis = [&](int t0, bool in) {
-#pragma unroll
-    for (int k = 0; k < kSweepPer; k++) v[k] = 0;
-    if (in) {
-#pragma unroll
-      for (int q = 0; q < kSweepPer / 4; q++) {
-        const uchar4 v4 = *reinterpret_cast<const uchar4 *>(p.vis_type + t0 + q * 4);
-        v[q * 4] = v4.x; v[q * 4 + 1] = v4.y; v[q * 4 + 2] = v4.z; v[q * 4 + 3] = v4.w;
-      }
+  const int b = take_ticket(p.ticket, p.ticket_base, &s_ticket);   // (one tile per workgroup, in starting order)
+  if (b >= p.n_tiles) return;
+  {
+    const int w0 = b * kBitTileWords + threadIdx.x * 4;   // this thread's four words
+    const uint4 q1 = *reinterpret_cast<const uint4 *>(p.q1 + w0), q2 = *reinterpret_cast<const uint4 *>(p.q2 + w0);
+    const uint4 mk = *reinterpret_cast<const uint4 *>(p.mark + w0), rt = *reinterpret_cast<const uint4 *>(p.retest + w0);
+    const uint4 pold = *reinterpret_cast<const uint4 *>(p.vis_bits + w0);
+    const uint4 seen = or4v(rt, mk);
+    // ---- counts out first: nothing a tile publishes depends on another tile -------------------------------------------
+    const int c1 = popc4(q1), c2 = popc4(q2);
+    int r1, r2, tot1, tot2;
+    block_excl_scan2<4>(c1, c2, red, r1, r2, tot1, tot2);
+    int tv[4] = {popc4(seen), popc4(andn4v(q1, seen)), 0, 0};
+    block_sum4(tv, red);
+    if (threadIdx.x == 0) {
+      publish(p.agg_req, b, p.epoch, tot1, tot2);
+      publish(p.agg_vis, b, p.epoch, tv[0], tv[1]);
     }
-  };
-  auto settle = [&](int b, int t0, bool in) {
-    unsigned cand_mask = 0;
-#pragma unroll
-    for (int k = 0; k < kSweepPer; k++)  // visible in the previous pass, not marked in this one: upstream's type 3
-      if (v[k] != 0 && (v[k] & 0x80u) != p.gen) cand_mask |= 1u << k;
-    unsigned char f[kSweepPer];
-    sweep_block_vis<SWAPPING>(vis_scratch, cand_mask, p.hash, t0, p.M, p.fx, p.fy, p.cx, p.cy, p.voxel_size, p.W, p.H, f);
-#pragma unroll
-    for (int k = 0; k < kSweepPer; k++) {
-      ty[k] = 0;
-      if (v[k] == 0) continue;
-      if ((cand_mask >> k) & 1u) ty[k] = (f[k] & (SWAPPING ? 2 : 1)) ? 3 : 0;
-      else ty[k] = v[k] & 0x7f;
+    // the other set of bitmaps starts the next pass clean
+    {
+      const uint4 z = make_uint4(0, 0, 0, 0);
+      *reinterpret_cast<uint4 *>(p.oq1 + w0) = z;
+      *reinterpret_cast<uint4 *>(p.oq2 + w0) = z;
+      *reinterpret_cast<uint4 *>(p.omark + w0) = z;
     }
-  };
-  // count the visible entries of the tile, publish the count
-  auto count_and_publish = [&](int b, int t0) {
-    int c = 0;
-#pragma unroll
-    for (int k = 0; k < kSweepPer; k++) {
-      if (SWAPPING && ty[k] > 0 && p.swap_state[t0 + k] != 2) p.swap_state[t0 + k] = 1;
-      c += ty[k] > 0;
-    }
-    vis_rank = block_excl_scan<4>(c, red[0], vis_tot);
-    if (threadIdx.x == 0) publish(p.agg_vis, b, p.epoch, vis_tot >> 12, vis_tot & 0xfff);  // (<= 4096, as two fields)
-  };
-
-  // ---- A: winners -> requests -> commit -----------------------------------------------------------------------
-  for (int b = blockIdx.x; b < p.n_tiles; b += gridDim.x) {
-    STAMP(0);
-    const int t0 = b * kSweepTile + threadIdx.x * kSweepPer;
-    const bool in = t0 < p.n_entries;  // (entry counts are multiples of 16: a thread's entries are all inside or all outside)
-    const bool has_excess = (b + 1) * kSweepTile > p.num_buckets;  // other tiles' commits may create entries in this one
-    unsigned amask = 0;  // 2 bits per entry: 0 none, 1 ordered request, 2 excess request
-    int c1 = 0, c2 = 0;
-    if (in) {
-      uint4 kk[kSweepPer / 4];
-#pragma unroll
-      for (int q = 0; q < kSweepPer / 4; q++) kk[q] = *reinterpret_cast<const uint4 *>(p.keys + t0 + q * 4);
-      if (single) load_vis(t0, in);  // (in flight together with the keys)
-#pragma unroll
-      for (int q = 0; q < kSweepPer / 4; q++) {
-        if (!(kk[q].x | kk[q].y | kk[q].z | kk[q].w)) continue;
-        *reinterpret_cast<uint4 *>(p.keys + t0 + q * 4) = make_uint4(0, 0, 0, 0);  // leave the keys clean for the next pass
-        const unsigned key[4] = {kk[q].x, kk[q].y, kk[q].z, kk[q].w};
-#pragma unroll
-        for (int k = 0; k < 4; k++)
-          if (key[k]) {
-            // replay the winning pixel's walk up to the winning step: the block it asked for
-            const int t = t0 + q * 4 + k;
-            const unsigned kz = key[k] - 1u;
-            const int pix = (int)(kz >> p.cap_shift), step = (int)(kz & ((1u << p.cap_shift) - 1u));
-            const int py = pix / p.W, px = pix - py * p.W;
-            Vec3 pt, dir;
-            ray_segment(p.depth[pix], px, py, p.invM, p.inv_fx, p.inv_fy, p.cx, p.cy, p.mu, p.one_over_block, pt, dir);
-            for (int i = 0; i < step; i++) { pt.x += dir.x; pt.y += dir.y; pt.z += dir.z; }
-            // the key sits on an empty bucket head (ordered request) or on the last entry of an occupied bucket's
-            // chain (excess request)
-            const unsigned a = (p.hash[t].ptr >= -1) ? 2u : 1u;
-            p.alloc_type[t] = (unsigned char)a;
-            p.coords[t] = make_short4((short)(int)floorf(pt.x), (short)(int)floorf(pt.y), (short)(int)floorf(pt.z), 1);
-            amask |= a << (2 * (q * 4 + k));
-            c1 += a == 1u;
-            c2 += a == 2u;
-          }
-      }
-    }
-    int tot1, tot2;
-    int r1 = block_excl_scan<4>(c1, red[0], tot1);
-    int r2 = block_excl_scan<4>(c2, red[1], tot2);
-    if (threadIdx.x == 0) publish(p.agg_req, b, p.epoch, tot1, tot2);
-    STAMP(1);
-    // (single-tile workgroups) B's frustum test while the words in front of this tile arrive
-    if (single) {
-      if (!in) load_vis(t0, in);
-      settle(b, t0, in);
-    }
+    const int tile_first = b * kBitTileEntries;
     const bool last = b == p.n_tiles - 1;
-    int succ_vba = 0, succ_ex = 0;
-    bool remote = false;  // stores into another tile's entries (a new excess entry)
-    bool succ_published = false;
-    if (tot1 + tot2 > 0 || last) {
-      int pre1, pre2;
-      lookback(p.agg_req, b, p.epoch, red[0], pre1, pre2);
-      if (last) {
-        all_requests = pre1 + tot1 + pre2 + tot2;
-        if (threadIdx.x == 0) *p.req_count = all_requests;
+    const bool has_excess = tile_first + kBitTileEntries > p.num_buckets || last;   // other tiles' commits may create entries here
+    s_newx[threadIdx.x * 4] = 0; s_newx[threadIdx.x * 4 + 1] = 0; s_newx[threadIdx.x * 4 + 2] = 0; s_newx[threadIdx.x * 4 + 3] = 0;
+    // requests of the tiles behind this one: only the tiles of the excess area need them (for the totals), and there
+    // only excess requests exist -- counted straight from the bitmap
+    int later2 = 0;
+    if (has_excess)
+      for (int w = (b + 1) * kBitTileWords + threadIdx.x * 4; w < p.n_words; w += 1024) later2 += popc4(*reinterpret_cast<const uint4 *>(p.q2 + w));
+    int pre[4];  // requests (type 1, type 2) and visible entries (retest | mark; new type-1 requests) in front of this tile
+    if (!lookback2(p.agg_req, p.agg_vis, b, p.epoch, red, pre) && threadIdx.x == 0) atomicOr(&p.cnt->error_flags, 2);
+    int lv[4] = {later2, 0, 0, 0};
+    if (has_excess) block_sum4(lv, red);
+    const int all1 = pre[0] + tot1, all2 = pre[1] + tot2 + lv[0];   // (meaningful for has_excess tiles)
+    // ---- does a pool run out?  (wave-uniform decisions) --------------------------------------------------------------
+    const int vr_start = pre[0] + (pre[1] < avail_ex ? pre[1] : avail_ex);
+    int vq_before = pre[3];   // visible type-1 requests in front of this tile that are not in (retest | mark)
+    int seen_before = pre[2]; // entries in (retest | mark) in front of this tile that stay visible
+    int succ2_all = 0;        // successful type-2 requests of the whole pass (has_excess tiles)
+    if (p.do_commit) {
+      const bool dry_before = vr_start > avail_vba;
+      const bool dry_total = has_excess && all1 + (all2 < avail_ex ? all2 : avail_ex) > avail_vba;
+      if (dry_before || dry_total) {
+        int s1q, f1s, s2;
+        walk_requests(p, b * kBitTileWords, avail_vba, avail_ex, red, s1q, f1s, s2);
+        if (dry_before) { vq_before = s1q; seen_before -= f1s; }
+        succ2_all = s2;
+      } else {
+        succ2_all = all2 < avail_ex ? all2 : avail_ex;
       }
-      int rr = pre1 + pre2 + r1 + r2;  // position in the list of this pass' requests (any unique position will do)
-      r1 += pre1;
-      r2 += pre2;
-      // Which requests get a block follows from the ranks alone, so the tile's commit word can go out before its
-      // stores -- unless it creates entries in another tile (an excess request that succeeds): that store has to be
-      // visible device-wide before the word is, because the tiles of the excess area read it after seeing the word.
-      unsigned okmask = 0;
-      {
-        int q1 = r1, q2 = r2;
-        for (unsigned m = amask; m; ) {
-          const int k = (__ffs((int)m) - 1) >> 1;
-          const unsigned a = (amask >> (2 * k)) & 3u;
-          m &= ~(3u << (2 * k));
+    }
+    // ---- this tile's requests: replay, rank, commit -------------------------------------------------------------------
+    uint4 qvis = make_uint4(0, 0, 0, 0);   // type-1 requests that make their entry visible in this pass
+    uint4 qfail = make_uint4(0, 0, 0, 0);  // type-1 requests that found no block: the entry is not visible, whatever it was
+    {
+      int k1 = pre[0] + r1, k2 = pre[1] + r2;
+#pragma unroll 1
+      for (int i = 0; i < 4; i++) {
+        const unsigned a1 = sel4(q1, i), a2 = sel4(q2, i);
+        for (unsigned m = a1 | a2; m; m &= m - 1) {
+          const int bit = __ffs((int)m) - 1;
+          const int t = (w0 + i) * 32 + bit;
+          const bool is2 = (a2 >> bit) & 1u;
+          // replay the winning pixel's walk up to the winning step: the block it asked for
+          const unsigned kz = p.keys[t] - 1u;
+          p.keys[t] = 0;   // leave the keys clean for the next pass
+          const int pix = (int)(kz >> p.cap_shift), step = (int)(kz & ((1u << p.cap_shift) - 1u));
+          const int py = pix / p.W, px = pix - py * p.W;
+          Vec3 pt, dir;
+          ray_segment(p.depth[pix], px, py, p.invM, p.inv_fx, p.inv_fy, p.cx, p.cy, p.mu, p.one_over_block, pt, dir);
+          for (int s = 0; s < step; s++) { pt.x += dir.x; pt.y += dir.y; pt.z += dir.z; }
+          const short4 bc = make_short4((short)(int)floorf(pt.x), (short)(int)floorf(pt.y), (short)(int)floorf(pt.z), 1);
+          p.alloc_type[t] = is2 ? 2 : 1;
+          p.coords[t] = bc;
           // voxel-block slots consumed by all earlier requests in hash-index order (closed form)
-          const int vr = q1 + (q2 < avail_ex ? q2 : avail_ex);
-          if (a == 1u) {
-            if (p.do_commit && vr < avail_vba) { okmask |= 1u << k; succ_vba++; }
-            q1++;
-          } else {
-            if (p.do_commit && q2 < avail_ex && vr < avail_vba) { okmask |= 1u << k; succ_vba++; succ_ex++; remote = true; }
-            q2++;
-          }
-        }
-      }
-      for (int pass = 0; pass < 2; pass++) {  // pass 0: the stores into other tiles; pass 1: the rest
-        if (pass == 1 && p.do_commit) {
-          for (int d = 32; d > 0; d >>= 1) { succ_vba += __shfl_xor(succ_vba, d, 64); succ_ex += __shfl_xor(succ_ex, d, 64); }
-          const unsigned long long any_remote = __ballot(remote);
-          if (any_remote) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-          __syncthreads();
-          if ((threadIdx.x & 63) == 0) {
-            red[1][threadIdx.x >> 6] = succ_vba;
-            red[1][4 + (threadIdx.x >> 6)] = succ_ex;
-          }
-          __syncthreads();
-          if (threadIdx.x == 0) {
-            // (a tile that stored into other tiles: each of its storing waves waited for its write-through stores in
-            // front of the barrier above; no release fence -- see pass 0)
-            publish(p.agg_succ, b, p.epoch, red[1][0] + red[1][1] + red[1][2] + red[1][3], red[1][4] + red[1][5] + red[1][6] + red[1][7]);
-          }
-          succ_published = true;
-        }
-        int q1 = r1, q2 = r2, qq = rr;
-        for (unsigned m = amask; m; ) {
-          const int k = (__ffs((int)m) - 1) >> 1;
-          const unsigned a = (amask >> (2 * k)) & 3u;
-          m &= ~(3u << (2 * k));
-          const int t = t0 + k;
-          const int vr = q1 + (q2 < avail_ex ? q2 : avail_ex);
-          const bool ok = (okmask >> k) & 1u;
-          if (a == 1u) {
-            if (pass == 1) {
-              p.req_list[qq] = t;
-              if (ok) {
-                const short4 bc = p.coords[t];
-                store_entry(p.hash, t, bc.x, bc.y, bc.z, 0, p.alloc_list[base_free - vr]);
-              }
-              // without the commit (onlyUpdateVisibleList) the request alone makes the entry "visible" this pass, like
-              // upstream; with it, only if it got a block
-              const unsigned char nv = (ok || !p.do_commit) ? (unsigned char)(p.gen | 1u) : (unsigned char)0;
-              p.vis_type[t] = nv;
-              if (single) { v[k] = nv; ty[k] = nv & 0x7f; }  // (whatever an empty bucket head carried before)
+          const int vr = k1 + (k2 < avail_ex ? k2 : avail_ex);
+          if (!is2) {
+            const bool ok = p.do_commit && vr < avail_vba;
+            if (ok) {
+              store_entry(p.hash, t, bc.x, bc.y, bc.z, 0, p.alloc_list[base_free - vr]);
+              bit_set(p.alloc_bits, t);
             }
-            q1++;
-          } else {
-            if (pass == 0 && ok) {
-              const int ex_off = p.excess_list[base_free_ex - q2];
-              const short4 bc = p.coords[t];
-              p.hash[t].offset = ex_off + 1;
-              // The two stores that land in ANOTHER tile's entries go out write-through (sc1): once this wave's vmcnt is
-              // back at 0 they are in memory, so the commit word needs no agent-scope release in front of it -- that is a
-              // write-back of the XCD's L2 (1.7-6.5 us) on the critical path of every tile behind this one (the tiles of
-              // the excess area wait for EVERY commit word): last tile done at 17.5 instead of 19.3 us.  The readers keep
-              // their agent-scope acquire (MI355X_MICROARCH.md, inter-workgroup visibility: sc1 stores + the storing
-              // waves' vmcnt(0) + barrier, then the flag; acquire + plain loads on the other side).
-              {  // (relaxed agent-scope atomic stores = plain store instructions with sc1; the entry as two 8-byte halves)
-                unsigned long long *dst = reinterpret_cast<unsigned long long *>(p.hash + (p.num_buckets + ex_off));
-                const unsigned long long lo = ((unsigned long long)((unsigned)bc.z & 0xffffu) << 32) |
-                                              (((unsigned)bc.x & 0xffffu) | ((unsigned)bc.y << 16));
-                const unsigned long long hi = (unsigned long long)(unsigned)p.alloc_list[base_free - vr] << 32;  // offset 0, ptr
-                __hip_atomic_store(dst, lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(dst + 1, hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(p.vis_type + (p.num_buckets + ex_off), (unsigned char)(p.gen | 1u), __ATOMIC_RELAXED,
-                                   __HIP_MEMORY_SCOPE_AGENT);
-              }
-            }
-            if (pass == 1) p.req_list[qq] = t;
-            q2++;
-          }
-          qq++;
-        }
-      }
-    }
-    // a tile without excess-area entries knows its visible entries now
-    vis_published = false;
-    if (single && !(p.do_commit && has_excess)) {
-      count_and_publish(b, t0);
-      vis_published = true;
-    }
-    if (p.do_commit && !succ_published) {  // a tile without requests: nothing committed
-      if (threadIdx.x == 0) publish(p.agg_succ, b, p.epoch, 0, 0);
-    }
-    STAMP(2);
-  }
-
-  // (a workgroup that owns several tiles may have created an entry in one of its own later tiles)
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-
-  // ---- B: settle visibility, build the visible list -------------------------------------------------------------
-  for (int b = blockIdx.x; b < p.n_tiles; b += gridDim.x) {
-    const int t0 = b * kSweepTile + threadIdx.x * kSweepPer;
-    const bool in = t0 < p.n_entries;
-    const bool last = b == p.n_tiles - 1;
-    const bool has_excess = (b + 1) * kSweepTile > p.num_buckets;
-    STAMP(3);
-    int succ_vba_all = 0, succ_ex_all = 0;
-    if (p.do_commit && (has_excess || last)) {
-      lookback(p.agg_succ, p.n_tiles, p.epoch, red[0], succ_vba_all, succ_ex_all);
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __syncthreads();
-    }
-    STAMP(4);
-    if (!vis_published) {
-      if (!single) {
-        load_vis(t0, in);
-        settle(b, t0, in);
-      } else if (p.do_commit && has_excess && in) {
-        // other tiles' commits may have created entries here: they carry this pass' mark; everything else was settled in A.
-        // A byte that differs from what this tile last saw or wrote IS such a mark -- also where the slot still carried
-        // a stale type of an entry that no longer exists (a render state that outlived a ResetScene: the stale byte
-        // used to hide the new entry's mark; fuzz seed 70473)
-#pragma unroll
-        for (int q = 0; q < kSweepPer / 4; q++) {
-          const uchar4 v4 = *reinterpret_cast<const uchar4 *>(p.vis_type + t0 + q * 4);
-          const unsigned char nb4[4] = {v4.x, v4.y, v4.z, v4.w};
-#pragma unroll
-          for (int kk = 0; kk < 4; kk++)
-            if (nb4[kk] != v[q * 4 + kk]) { v[q * 4 + kk] = nb4[kk]; ty[q * 4 + kk] = nb4[kk] & 0x7f; }
-        }
-      }
-      count_and_publish(b, t0);
-    }
-    STAMP(5);
-    int offset = 0;
-    if (vis_tot > 0 || last) {
-      int hi, lo;
-      lookback(p.agg_vis, b, p.epoch, red[0], hi, lo);
-      offset = hi * 4096 + lo;
-    }
-    STAMP(6);
-    if (in) {
-      int r = vis_rank + offset;
-#pragma unroll
-      for (int q = 0; q < kSweepPer / 4; q++) {
-        bool changed = false;
-        unsigned char nv4[4];
-#pragma unroll
-        for (int kk = 0; kk < 4; kk++) {
-          const int k = q * 4 + kk;
-          unsigned char nv = 0;
-          if (ty[k] > 0) {
-            if (r < p.capacity) {
-              p.visible_ids[r] = t0 + k;
-              nv = (unsigned char)(p.gen | ty[k]);
+            // without the commit (onlyUpdateVisibleList) the request alone makes the entry "visible" this pass, like
+            // upstream; with it, only if it got a block
+            if (ok || !p.do_commit) {
+              p.vis_type[t] = (unsigned char)(p.gen | 1u);
+              or4(qvis, i, 1u << bit);
             } else {
-              // no room in the list: upstream leaves the type in place without the entry being re-armed next pass, so
-              // a 1 / 2 counts as marked again then (next pass' bit), a 3 is re-tested (this pass' bit)
-              nv = (unsigned char)((ty[k] == 3 ? p.gen : (p.gen ^ 0x80u)) | ty[k]);
+              or4(qfail, i, 1u << bit);
             }
-            r++;
+            k1++;
+          } else {
+            if (p.do_commit && k2 < avail_ex && vr < avail_vba) {
+              const int ex_off = p.excess_list[base_free_ex - k2];
+              p.hash[t].offset = ex_off + 1;
+              store_entry(p.hash, p.num_buckets + ex_off, bc.x, bc.y, bc.z, 0, p.alloc_list[base_free - vr]);
+              bit_set(p.alloc_bits, p.num_buckets + ex_off);
+              // (its type byte and its place in the visible list are the business of the tile that owns the new entry)
+            }
+            k2++;
           }
-          changed |= nv != v[k];
-          nv4[kk] = nv;
         }
-        if (changed) *reinterpret_cast<uchar4 *>(p.vis_type + t0 + q * 4) = make_uchar4(nv4[0], nv4[1], nv4[2], nv4[3]);
       }
     }
+    // ---- entries other tiles create in the excess area: the first succ2_all slots off the excess free list ---------------
+    int newx_before = 0;   // ... of them in front of this tile and not counted as (retest | mark) there
+    __syncthreads();       // (s_newx zeroed)
+    if (has_excess) {
+      for (int j = threadIdx.x; j < succ2_all; j += 256) {
+        const int t = p.num_buckets + p.excess_list[base_free_ex - j];
+        const int rel = t - tile_first;
+        if (rel >= 0 && rel < kBitTileEntries) atomicOr(&s_newx[rel >> 5], 1u << (rel & 31));
+        else if (rel < 0 && !(((p.retest[t >> 5] | p.mark[t >> 5]) >> (t & 31)) & 1u)) newx_before++;
+      }
+      int nv[4] = {newx_before, 0, 0, 0};
+      block_sum4(nv, red);   // (has a barrier: s_newx is complete behind it)
+      newx_before = nv[0];
+    }
+    const uint4 newx = has_excess ? *reinterpret_cast<const uint4 *>(&s_newx[threadIdx.x * 4]) : make_uint4(0, 0, 0, 0);
+    // ---- the visible list -----------------------------------------------------------------------------------------------
+    const uint4 vis = or4v(or4v(andn4v(seen, qfail), qvis), newx);
+    int vis_tot;
+    int r = block_excl_scan<4>(popc4(vis), red, vis_tot);   // (its barriers also order the request lanes' type bytes)
+    const int vis_first = seen_before + vq_before + newx_before;
+    r += vis_first;
+#pragma unroll 1
+    for (int i = 0; i < 4; i++) {
+      const unsigned v = sel4(vis, i), m_mk = sel4(mk, i), m_q = sel4(qvis, i), m_x = sel4(newx, i);
+      const int t_base = (w0 + i) * 32;
+      for (unsigned m = sel4(pold, i) & ~v; m; m &= m - 1) p.vis_type[t_base + __ffs((int)m) - 1] = 0;   // no longer visible
+      for (unsigned m = v; m; m &= m - 1) {
+        const int bit = __ffs((int)m) - 1;
+        const int t = t_base + bit;
+        const bool in_mk = (m_mk >> bit) & 1u, in_q = (m_q >> bit) & 1u, in_x = (m_x >> bit) & 1u;
+        if (r < p.capacity) {
+          p.visible_ids[r] = t;
+          if (in_x) {
+            p.vis_type[t] = (unsigned char)(p.gen | 1u);
+          } else if (!in_mk && !in_q) {
+            // visible before, not marked now, inside the frustum: upstream's 3 (a byte with this pass' bit is a 1 / 2
+            // that counts as marked again: it stays)
+            const unsigned char ty = p.vis_type[t];
+            if ((ty & 0x80u) != p.gen) p.vis_type[t] = (unsigned char)(p.gen | 3u);
+          }
+        } else {
+          // no room in the list: upstream leaves the type in place without the entry being re-armed next pass, so
+          // a 1 / 2 counts as marked again then (next pass' bit), a 3 is re-tested (this pass' bit)
+          unsigned ty = 1;
+          if (!in_x && !in_q) {
+            const unsigned char old = p.vis_type[t];
+            ty = (in_mk || (old & 0x80u) == p.gen) ? (old & 0x7fu) : 3u;
+          }
+          p.vis_type[t] = (unsigned char)((ty == 3 ? p.gen : (p.gen ^ 0x80u)) | ty);
+        }
+        if (SWAPPING) {   // a visible entry's host copy (if it has one) is wanted back: IntegrateGlobalIntoLocal's state 1
+          const unsigned char st = p.swap_state[t];
+          if (st == 0) { p.swap_state[t] = 1; bit_set(p.swap1_bits, t); }
+        }
+        r++;
+      }
+    }
+    *reinterpret_cast<uint4 *>(p.vis_bits + w0) = vis;
     if (last && threadIdx.x == 0) {
-      const int n = offset + vis_tot;
+      const int n = vis_first + vis_tot;
       p.rc->no_visible = n < p.capacity ? n : p.capacity;
       if (p.do_commit) {
-        p.cnt->last_free = base_free - succ_vba_all;
-        p.cnt->last_free_ex = base_free_ex - succ_ex_all;
-        p.cnt->alloc_failures = all_requests - succ_vba_all;
+        const int vr_all = all1 + (all2 < avail_ex ? all2 : avail_ex);
+        const int succ_vba = vr_all < avail_vba ? vr_all : avail_vba;   // every success takes exactly one voxel-block slot
+        p.cnt->last_free = base_free - succ_vba;
+        p.cnt->last_free_ex = base_free_ex - succ2_all;
+        p.cnt->alloc_failures = all1 + all2 - succ_vba;
       } else {
         p.cnt->alloc_failures = 0;
       }
     }
-    vis_published = false;
-    STAMP(7);
   }
-#undef STAMP
 }
 
 // The visible list of a render state was replaced behind its types' back (FindVisibleBlocks into this render state, an
 // uploaded list).  Upstream's next pass would leave every type as it is and set the LIST's entries to 3; in the
 // generation encoding: a 1 / 2 that is to stay "marked" gets the coming pass' bit, a 3 keeps the old bit (re-tested),
 // and the list's entries become old-bit 3s.
-__global__ __launch_bounds__(256) void k_types_keep(unsigned char *vis_type, int n_entries, unsigned new_gen) {
-  const int i = (blockIdx.x * 256 + threadIdx.x) * 4;
-  if (i >= n_entries) return;
-  uchar4 v = *reinterpret_cast<uchar4 *>(vis_type + i);
-  auto fix = [&](unsigned char x) -> unsigned char {
-    const unsigned t = x & 0x7fu;
-    if (t == 0) return 0;
-    return (unsigned char)((t == 3 ? (new_gen ^ 0x80u) : new_gen) | t);
-  };
-  v.x = fix(v.x); v.y = fix(v.y); v.z = fix(v.z); v.w = fix(v.w);
-  *reinterpret_cast<uchar4 *>(vis_type + i) = v;
+__global__ __launch_bounds__(256) void k_types_keep(unsigned char *vis_type, const unsigned *__restrict__ vis_bits, int n_words,
+                                                    unsigned new_gen) {
+  const int w = blockIdx.x * 256 + threadIdx.x;
+  if (w >= n_words) return;
+  for (unsigned m = vis_bits[w]; m; m &= m - 1) {
+    const int t = w * 32 + __ffs((int)m) - 1;
+    const unsigned ty = vis_type[t] & 0x7fu;
+    if (ty) vis_type[t] = (unsigned char)((ty == 3 ? (new_gen ^ 0x80u) : new_gen) | ty);
+  }
 }
 __global__ __launch_bounds__(256) void k_types_rearm(const int *__restrict__ ids, const RenderCounters *rc,
-                                                     unsigned char *vis_type, unsigned old_gen) {
+                                                     unsigned char *vis_type, unsigned *vis_bits, unsigned old_gen) {
   const int n = rc->no_visible;
-  for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) vis_type[ids[i]] = (unsigned char)(old_gen | 3u);
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+    const int t = ids[i];
+    vis_type[t] = (unsigned char)(old_gen | 3u);
+    if (!((vis_bits[t >> 5] >> (t & 31)) & 1u)) bit_set(vis_bits, t);
+  }
 }
 
 // reallocate swapped-out blocks that came back into view (useSwapping only): one pool, so the r-th request in
-// hash-index order succeeds iff r < available
-__global__ __launch_bounds__(256) void k_realloc_count(const unsigned char *__restrict__ vis_type,
-                                                       const HashEntry *__restrict__ hash, int n_entries,
+// hash-index order succeeds iff r < available.  Requests = visible entries (a bit in vis_bits) whose block is on the host.
+// Two small launches over the bitmap tiles: count, then place (the tile's offset is the sum of the tile counts in front).
+__global__ __launch_bounds__(256) void k_realloc_count(const unsigned *__restrict__ vis_bits, const HashEntry *__restrict__ hash,
                                                        int *__restrict__ tile_counts, SceneCounters *cnt) {
-  __shared__ int red[4];
-  const int t0 = blockIdx.x * kTileEntries + threadIdx.x * 4;
+  __shared__ int red[16];
+  const int w0 = blockIdx.x * kBitTileWords + threadIdx.x * 4;
   if (blockIdx.x == 0 && threadIdx.x == 0) cnt->base_free = cnt->last_free;  // (nothing moves the top before the apply pass ends)
+  const uint4 v = *reinterpret_cast<const uint4 *>(vis_bits + w0);
   int c = 0;
-  if (t0 < n_entries) {
-    const uchar4 v = *reinterpret_cast<const uchar4 *>(vis_type + t0);
-    const unsigned char f[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-    for (int k = 0; k < 4; k++)
-      if (f[k] > 0 && hash[t0 + k].ptr == -1) c++;
-  }
-  int tot;
-  block_excl_scan<4>(c, red, tot);
-  if (threadIdx.x == 0) tile_counts[blockIdx.x] = tot;
+#pragma unroll 1
+  for (int i = 0; i < 4; i++)
+    for (unsigned m = sel4(v, i); m; m &= m - 1) c += hash[(w0 + i) * 32 + __ffs((int)m) - 1].ptr == -1;
+  int cv[4] = {c, 0, 0, 0};
+  block_sum4(cv, red);
+  if (threadIdx.x == 0) tile_counts[blockIdx.x] = cv[0];
 }
 
-// the tile's exclusive offset is the sum of the preceding tile counts, computed here; the last tile takes the slots
-// off the pool top (every tile reads the top as it was from base_free)
-__global__ __launch_bounds__(256) void k_realloc_apply(const unsigned char *__restrict__ vis_type, HashEntry *hash,
-                                                       int n_entries, const int *__restrict__ tile_counts,
-                                                       const int *__restrict__ alloc_list, SceneCounters *cnt) {
+__global__ __launch_bounds__(256) void k_realloc_apply(const unsigned *__restrict__ vis_bits, HashEntry *hash,
+                                                       const int *__restrict__ tile_counts, const int *__restrict__ alloc_list,
+                                                       unsigned *alloc_bits, SceneCounters *cnt) {
   __shared__ int red[4];
-  const int t0 = blockIdx.x * kTileEntries + threadIdx.x * 4;
-  bool need[4] = {false, false, false, false};
-  int c = 0;
-  if (t0 < n_entries) {
-    const uchar4 v = *reinterpret_cast<const uchar4 *>(vis_type + t0);
-    const unsigned char f[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-      need[k] = f[k] > 0 && hash[t0 + k].ptr == -1;
-      c += need[k];
+  const int w0 = blockIdx.x * kBitTileWords + threadIdx.x * 4;
+  const uint4 v = *reinterpret_cast<const uint4 *>(vis_bits + w0);
+  uint4 need = make_uint4(0, 0, 0, 0);
+#pragma unroll 1
+  for (int i = 0; i < 4; i++)
+    for (unsigned m = sel4(v, i); m; m &= m - 1) {
+      const int bit = __ffs((int)m) - 1;
+      if (hash[(w0 + i) * 32 + bit].ptr == -1) or4(need, i, 1u << bit);
     }
-  }
   int tot;
-  int r = block_excl_scan<4>(c, red, tot);
+  int r = block_excl_scan<4>(popc4(need), red, tot);
   const bool last = blockIdx.x == gridDim.x - 1;
   if (tot == 0 && !last) return;
   const int offset = block_sum_strided(tile_counts, blockIdx.x, 1, red);
@@ -713,10 +663,14 @@ __global__ __launch_bounds__(256) void k_realloc_apply(const unsigned char *__re
     cnt->last_free = base_free - (total < avail ? total : avail);
   }
   r += offset;
-#pragma unroll
-  for (int k = 0; k < 4; k++)
-    if (need[k]) {
-      if (r <= base_free) hash[t0 + k].ptr = alloc_list[base_free - r];
+#pragma unroll 1
+  for (int i = 0; i < 4; i++)
+    for (unsigned m = sel4(need, i); m; m &= m - 1) {
+      const int t = (w0 + i) * 32 + __ffs((int)m) - 1;
+      if (r <= base_free) {
+        hash[t].ptr = alloc_list[base_free - r];
+        bit_set(alloc_bits, t);
+      }
       r++;
     }
 }
@@ -727,14 +681,14 @@ static inline int ceil_pow2(int v) {
   return p;
 }
 
-// workgroups of a sweep kernel that are certainly resident together (its tiles wait for each other inside the launch)
-template <typename K>
-static int resident_grid(dslam_engine *e, K kernel) {
-  int per_cu = 0;
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, 256, 0) != hipSuccess || per_cu < 1) per_cu = 1;
-  if (per_cu > 8) per_cu = 8;
-  if (per_cu > 1) per_cu -= 1;  // (the occupancy query can be one block per CU high on this part: keep a margin)
-  return per_cu * (e->sm_count > 0 ? e->sm_count : 1);
+// words [lo, hi) of one of the alternating bitmap sets back to zero, and the allocType bytes its request bits stand for
+// (only when scenes of different sizes share the engine: the pass that normally cleans a set covers its own table only)
+__global__ __launch_bounds__(256) void k_clean_bits_tail(unsigned *q1, unsigned *q2, unsigned *mark, unsigned char *alloc_type,
+                                                         int lo, int hi) {
+  const int w = lo + blockIdx.x * 256 + threadIdx.x;
+  if (w >= hi) return;
+  for (unsigned m = q1[w] | q2[w]; m; m &= m - 1) alloc_type[w * 32 + __ffs((int)m) - 1] = 0;
+  q1[w] = 0; q2[w] = 0; mark[w] = 0;
 }
 
 int launch_allocate(dslam_engine *e, dslam_scene *s, const dslam_view *v, dslam_render_state *r, const float *M_d,
@@ -744,10 +698,6 @@ int launch_allocate(dslam_engine *e, dslam_scene *s, const dslam_view *v, dslam_
   DSLAM_REQUIRE((N & 15) == 0, "num_buckets + num_excess must be a multiple of 16");
   int rc = ensure_scratch(e, N, s->p.num_local_blocks);
   if (rc) return rc;
-  if (e->sweep_grid_cap == 0) {
-    const int a = resident_grid(e, k_alloc_sweep<false>), b = resident_grid(e, k_alloc_sweep<true>);
-    e->sweep_grid_cap = a < b ? a : b;
-  }
 
   MarkParams mp;
   mp.raw = v->depth_dirty ? v->raw_src : nullptr;
@@ -760,7 +710,7 @@ int launch_allocate(dslam_engine *e, dslam_scene *s, const dslam_view *v, dslam_
   mp.hash = s->hash; mp.mask = (unsigned)(s->p.num_buckets - 1); mp.num_buckets = s->p.num_buckets;
   mp.keys = e->order_keys; mp.vis_type = r->visible_type;
   mp.cnt = s->counters;
-  mp.alloc_type = e->alloc_type; mp.req_list = e->req_list; mp.req_count = e->req_count;
+  mp.alloc_type = e->alloc_type;
   // steps along the +-mu segment: ceil(2 * |segment| in blocks) = ceil(mu / (2 * voxel_size)) for a rigid pose
   const int step_bound = (int)ceilf(s->p.mu / (2.0f * s->p.voxel_size)) + 2;
   mp.step_cap = ceil_pow2(step_bound + 1);
@@ -775,60 +725,65 @@ int launch_allocate(dslam_engine *e, dslam_scene *s, const dslam_view *v, dslam_
   const unsigned old_gen = r->gen;
   r->gen ^= 0x80u;
   mp.gen = r->gen;
+  const int n_tiles = bit_tiles(N), n_words = n_tiles * kBitTileWords;
   if (!r->types_follow_list) {
-    hipLaunchKernelGGL(k_types_keep, dim3((N / 4 + 255) / 256), dim3(256), 0, e->stream, r->visible_type, N, (unsigned)r->gen);
-    hipLaunchKernelGGL(k_types_rearm, dim3(64), dim3(256), 0, e->stream, r->visible_ids, r->counters, r->visible_type, old_gen);
+    hipLaunchKernelGGL(k_types_keep, dim3(n_words / 256), dim3(256), 0, e->stream, r->visible_type, r->vis_bits, n_words, (unsigned)r->gen);
+    hipLaunchKernelGGL(k_types_rearm, dim3(64), dim3(256), 0, e->stream, r->visible_ids, r->counters, r->visible_type, r->vis_bits, old_gen);
     r->types_follow_list = true;
   }
 
+  // the alternating bitmap sets: this pass writes `cur` (clean since the pass before last) and cleans `oth`
+  const int cur = (int)(e->alloc_pass & 1u), oth = cur ^ 1;
+  e->alloc_pass++;
+  if (e->bits_dirty[oth] > n_words) {  // the pass that dirtied `oth` ran on a larger table than this one
+    const int lo = n_words, hi = e->bits_dirty[oth];
+    hipLaunchKernelGGL(k_clean_bits_tail, dim3((hi - lo + 255) / 256), dim3(256), 0, e->stream, e->bits_q1[oth], e->bits_q2[oth],
+                       e->bits_mark[oth], e->alloc_type, lo, hi);
+  }
+  e->bits_dirty[oth] = 0;
+  e->bits_dirty[cur] = n_words;
+
+  mp.q1 = e->bits_q1[cur]; mp.q2 = e->bits_q2[cur]; mp.mark = e->bits_mark[cur];
+  mp.old_q1 = e->bits_q1[oth]; mp.old_q2 = e->bits_q2[oth];
+  mp.vis_bits = r->vis_bits; mp.retest = e->bits_retest;
+  mp.retest_wgs = n_words / 256; mp.n_words = n_words;
+  memcpy(mp.M.m, M_d, sizeof(float) * 16);
+  mp.fx = intr[0]; mp.fy = intr[1]; mp.voxel_size = s->p.voxel_size;
+  mp.swapping = s->p.use_swapping ? 1 : 0;
   const int pix_blocks = (W * H + 255) / 256;
-  hipLaunchKernelGGL(k_mark, dim3(pix_blocks), dim3(256), 0, e->stream, mp);
+  hipLaunchKernelGGL(k_mark, dim3(mp.retest_wgs + pix_blocks), dim3(256), 0, e->stream, mp);
+  dbg_sync(e, "k_mark");
   v->depth_dirty = false;
 
-  const int n_tiles = (N + kSweepTile - 1) / kSweepTile;
   SweepParams sp;
-  sp.hash = s->hash; sp.n_entries = N; sp.num_buckets = s->p.num_buckets; sp.n_tiles = n_tiles;
+  sp.hash = s->hash; sp.n_entries = N; sp.num_buckets = s->p.num_buckets; sp.n_tiles = n_tiles; sp.n_words = n_words;
   sp.keys = e->order_keys; sp.alloc_type = e->alloc_type; sp.coords = e->block_coords;
-  sp.req_list = e->req_list; sp.req_count = e->req_count;
   sp.alloc_list = s->alloc_list; sp.excess_list = s->excess_list;
-  sp.vis_type = r->visible_type; sp.swap_state = s->swap_state;
+  sp.vis_type = r->visible_type; sp.swap_state = s->swap_state; sp.swap1_bits = s->swap1_bits;
   sp.cnt = s->counters; sp.rc = r->counters; sp.visible_ids = r->visible_ids; sp.capacity = r->n_local;
-  sp.agg_req = e->agg; sp.agg_succ = e->agg + e->agg_tiles; sp.agg_vis = e->agg + 2 * (size_t)e->agg_tiles;  // (sized for 1024-entry tiles)
+  sp.q1 = mp.q1; sp.q2 = mp.q2; sp.mark = mp.mark; sp.retest = e->bits_retest;
+  sp.oq1 = e->bits_q1[oth]; sp.oq2 = e->bits_q2[oth]; sp.omark = e->bits_mark[oth];
+  sp.vis_bits = r->vis_bits; sp.alloc_bits = s->alloc_bits;
+  sp.agg_req = e->agg; sp.agg_vis = e->agg + e->agg_tiles;
   if (++e->epoch == 0) e->epoch = 1;
   sp.epoch = e->epoch;
+  const int grid = n_tiles;   // one tile per workgroup, one ticket each
+  sp.ticket = e->ticket; sp.ticket_base = e->ticket_base;
+  e->ticket_base += (unsigned)grid;
   sp.gen = r->gen;
   sp.do_commit = only_update_visible_list ? 0 : 1;
   sp.depth = v->depth; sp.W = W; sp.H = H;
   sp.invM = mp.invM; sp.inv_fx = mp.inv_fx; sp.inv_fy = mp.inv_fy; sp.cx = mp.cx; sp.cy = mp.cy;
   sp.mu = mp.mu; sp.one_over_block = mp.one_over_block; sp.cap_shift = cap_shift;
-  memcpy(sp.M.m, M_d, sizeof(float) * 16);
-  sp.fx = intr[0]; sp.fy = intr[1]; sp.voxel_size = s->p.voxel_size;
-  const int grid = n_tiles < e->sweep_grid_cap ? n_tiles : e->sweep_grid_cap;
-  sp.dbg = nullptr;
-  static const char *dbg_file = getenv("DSLAM_DBG_SWEEP");
-  static int dbg_calls = 0;
-  unsigned long long *dbg_host = nullptr;
-  if (dbg_file && ++dbg_calls == 60) {
-    DSLAM_HIP(hipHostMalloc((void **)&dbg_host, (size_t)n_tiles * 64, hipHostMallocDefault));
-    memset(dbg_host, 0, (size_t)n_tiles * 64);
-    sp.dbg = dbg_host;
-  }
   if (s->p.use_swapping) hipLaunchKernelGGL(k_alloc_sweep<true>, dim3(grid), dim3(256), 0, e->stream, sp);
   else hipLaunchKernelGGL(k_alloc_sweep<false>, dim3(grid), dim3(256), 0, e->stream, sp);
+  dbg_sync(e, "k_alloc_sweep");
   if (s->p.use_swapping) {
-    const int r_tiles = num_tiles(N);
-    hipLaunchKernelGGL(k_realloc_count, dim3(r_tiles), dim3(256), 0, e->stream, r->visible_type, s->hash, N,
-                       e->tile_counts, s->counters);
-    hipLaunchKernelGGL(k_realloc_apply, dim3(r_tiles), dim3(256), 0, e->stream, r->visible_type, s->hash, N,
-                       e->tile_counts, s->alloc_list, s->counters);
+    hipLaunchKernelGGL(k_realloc_count, dim3(n_tiles), dim3(256), 0, e->stream, r->vis_bits, s->hash, e->tile_counts, s->counters);
+    hipLaunchKernelGGL(k_realloc_apply, dim3(n_tiles), dim3(256), 0, e->stream, r->vis_bits, s->hash, e->tile_counts, s->alloc_list,
+                       s->alloc_bits, s->counters);
   }
   DSLAM_HIP(hipGetLastError());
-  if (dbg_host) {
-    DSLAM_HIP(hipStreamSynchronize(e->stream));
-    FILE *f = fopen(dbg_file, "wb");
-    if (f) { fwrite(dbg_host, 64, n_tiles, f); fclose(f); }
-    (void)hipHostFree(dbg_host);
-  }
   return DSLAM_OK;
 }
 

@@ -91,7 +91,9 @@ int ensure_scratch(dslam_engine *e, int entries, int local_blocks) {
   const int L = local_blocks > e->scratch_local_blocks ? local_blocks : e->scratch_local_blocks;
   free_dev(e->order_keys); free_dev(e->alloc_type); free_dev(e->block_coords); free_dev(e->tile_counts); free_dev(e->tile_offsets);
   free_dev(e->list_a); free_dev(e->list_b); free_dev(e->list_c); free_dev(e->list_d); free_dev(e->pos_scratch);
-  free_dev(e->req_list); free_dev(e->req_count); free_dev(e->agg);
+  free_dev(e->agg);
+  for (int k = 0; k < 2; k++) { free_dev(e->bits_q1[k]); free_dev(e->bits_q2[k]); free_dev(e->bits_mark[k]); }
+  free_dev(e->bits_retest); free_dev(e->bits_tmp);
   free_dev(e->rem_flags); free_dev(e->freed_flags); free_dev(e->rem_cand); free_dev(e->maint_flags);
   // order keys and allocType: cleared here once, kept clean by the allocation passes (scenes of different sizes share
   // them, so both start at fixed addresses: a pass only ever touches [0, its entry count) of each)
@@ -100,9 +102,22 @@ int ensure_scratch(dslam_engine *e, int entries, int local_blocks) {
   DSLAM_HIP(hipMalloc(&e->alloc_type, (size_t)N));
   DSLAM_HIP(hipMemsetAsync(e->alloc_type, 0, (size_t)N, e->stream));
   DSLAM_HIP(hipMalloc(&e->block_coords, (size_t)N * sizeof(short4)));
-  DSLAM_HIP(hipMalloc(&e->req_list, (size_t)N * sizeof(int)));
-  DSLAM_HIP(hipMalloc(&e->req_count, sizeof(int)));
-  DSLAM_HIP(hipMemsetAsync(e->req_count, 0, sizeof(int), e->stream));
+  // the bitmaps of the allocation pass (whole tiles; the alternating sets start clean and are kept clean by the passes)
+  e->bits_words = bit_tiles(N) * kBitTileWords;
+  const size_t bits_bytes = (size_t)e->bits_words * sizeof(unsigned);
+  for (int k = 0; k < 2; k++) {
+    DSLAM_HIP(hipMalloc(&e->bits_q1[k], bits_bytes));
+    DSLAM_HIP(hipMalloc(&e->bits_q2[k], bits_bytes));
+    DSLAM_HIP(hipMalloc(&e->bits_mark[k], bits_bytes));
+    DSLAM_HIP(hipMemsetAsync(e->bits_q1[k], 0, bits_bytes, e->stream));
+    DSLAM_HIP(hipMemsetAsync(e->bits_q2[k], 0, bits_bytes, e->stream));
+    DSLAM_HIP(hipMemsetAsync(e->bits_mark[k], 0, bits_bytes, e->stream));
+    e->bits_dirty[k] = 0;
+  }
+  DSLAM_HIP(hipMalloc(&e->bits_retest, bits_bytes));
+  DSLAM_HIP(hipMalloc(&e->bits_tmp, bits_bytes));
+  DSLAM_HIP(hipMemsetAsync(e->bits_retest, 0, bits_bytes, e->stream));
+  DSLAM_HIP(hipMemsetAsync(e->bits_tmp, 0, bits_bytes, e->stream));
   const int tiles = num_tiles(N > L ? N : L);
   DSLAM_HIP(hipMalloc(&e->agg, (size_t)tiles * 3 * sizeof(unsigned long long)));
   DSLAM_HIP(hipMemsetAsync(e->agg, 0, (size_t)tiles * 3 * sizeof(unsigned long long), e->stream));
@@ -156,6 +171,9 @@ static int engine_allocate(dslam_engine *e) {
   DSLAM_HIP(hipHostMalloc(&e->pinned, e->pinned_bytes, hipHostMallocDefault));
   memset(e->pinned, 0, e->pinned_bytes);
   DSLAM_HIP(hipMalloc(&e->misc_counter, 16 * sizeof(int)));
+  DSLAM_HIP(hipMalloc(&e->ticket, 16 * sizeof(unsigned)));
+  DSLAM_HIP(hipMemset(e->ticket, 0, 16 * sizeof(unsigned)));
+  e->ticket_base = 0;
   return DSLAM_OK;
 }
 
@@ -189,7 +207,9 @@ int dslam_engine_destroy(dslam_engine *e) {
   if (e->copy_stream) { (void)hipStreamSynchronize(e->copy_stream); (void)hipStreamDestroy(e->copy_stream); }
   free_dev(e->order_keys); free_dev(e->alloc_type); free_dev(e->block_coords); free_dev(e->tile_counts); free_dev(e->tile_offsets);
   free_dev(e->list_a); free_dev(e->list_b); free_dev(e->list_c); free_dev(e->list_d); free_dev(e->pos_scratch);
-  free_dev(e->req_list); free_dev(e->req_count); free_dev(e->agg);
+  free_dev(e->agg); free_dev(e->ticket);
+  for (int k = 0; k < 2; k++) { free_dev(e->bits_q1[k]); free_dev(e->bits_q2[k]); free_dev(e->bits_mark[k]); }
+  free_dev(e->bits_retest); free_dev(e->bits_tmp);
   free_dev(e->rem_flags); free_dev(e->freed_flags); free_dev(e->rem_cand); free_dev(e->maint_flags);
   if (e->staging_dev) (void)hipFree(e->staging_dev);
   if (e->staging_host) (void)hipHostFree(e->staging_host);
@@ -296,8 +316,10 @@ static int scene_allocate(dslam_engine *e, dslam_scene *s, void *ext_voxels) {
   DSLAM_HIP(hipMalloc(&s->last_seen, (size_t)s->p.num_local_blocks * sizeof(int)));
   DSLAM_HIP(hipMalloc(&s->masks, (size_t)s->p.num_local_blocks * 2 * s->history_words * sizeof(unsigned long long)));
   DSLAM_HIP(hipMalloc(&s->counters, sizeof(SceneCounters)));
+  DSLAM_HIP(hipMalloc(&s->alloc_bits, (size_t)bit_tiles(s->n_entries) * kBitTileWords * sizeof(unsigned)));
   if (s->p.use_swapping) {
     DSLAM_HIP(hipMalloc(&s->swap_state, s->n_entries));
+    DSLAM_HIP(hipMalloc(&s->swap1_bits, (size_t)bit_tiles(s->n_entries) * kBitTileWords * sizeof(unsigned)));
     DSLAM_HIP(hipMalloc(&s->slot_dev, (size_t)s->n_entries * sizeof(int)));
     DSLAM_HIP(hipMemsetAsync(s->slot_dev, 0xff, (size_t)s->n_entries * sizeof(int), e->stream));  // -1 everywhere
     DSLAM_HIP(hipHostMalloc((void **)&s->next_slot_host, 64, hipHostMallocDefault));
@@ -346,7 +368,7 @@ int dslam_scene_destroy(dslam_scene *s) {
   free_dev(s->hash);
   if (!s->voxels_external) free_dev(s->voxels);
   free_dev(s->alloc_list); free_dev(s->excess_list); free_dev(s->last_seen); free_dev(s->masks); free_dev(s->counters);
-  free_dev(s->swap_state); free_dev(s->slab_ptrs_dev);
+  free_dev(s->swap_state); free_dev(s->slab_ptrs_dev); free_dev(s->alloc_bits); free_dev(s->swap1_bits);
   free_dev(s->dirty); free_dev(s->dirty_list); free_dev(s->dirty_counts);
   for (uint4 *slab : s->slabs) (void)hipHostFree(slab);
   if (s->next_slot_host) (void)hipHostFree(s->next_slot_host);
@@ -435,6 +457,9 @@ static int render_state_allocate(dslam_engine *e, dslam_render_state *r) {
   const size_t npix = (size_t)r->w * r->h;
   DSLAM_HIP(hipMalloc(&r->visible_ids, (size_t)r->n_local * sizeof(int)));
   DSLAM_HIP(hipMalloc(&r->visible_type, r->n_entries));
+  const size_t vis_bits_bytes = (size_t)bit_tiles(r->n_entries) * kBitTileWords * sizeof(unsigned);
+  DSLAM_HIP(hipMalloc(&r->vis_bits, vis_bits_bytes));
+  DSLAM_HIP(hipMemsetAsync(r->vis_bits, 0, vis_bits_bytes, e->stream));
   DSLAM_HIP(hipMalloc(&r->range, npix * sizeof(float2)));
   DSLAM_HIP(hipMalloc(&r->raycast, npix * sizeof(float4)));
   DSLAM_HIP(hipMalloc(&r->image_rgba, npix * sizeof(uchar4)));
@@ -471,7 +496,7 @@ int dslam_render_state_create(dslam_engine *e, const dslam_scene *s, int w, int 
 int dslam_render_state_destroy(dslam_render_state *r) {
   if (!r) return DSLAM_OK;
   (void)hipStreamSynchronize(r->engine->stream);
-  free_dev(r->visible_ids); free_dev(r->visible_type); free_dev(r->range); free_dev(r->raycast);
+  free_dev(r->visible_ids); free_dev(r->visible_type); free_dev(r->vis_bits); free_dev(r->range); free_dev(r->raycast);
   free_dev(r->image_rgba); free_dev(r->image_float); free_dev(r->icp_points); free_dev(r->icp_normals);
   free_dev(r->raycast_image);
   free_dev(r->proj_boxes); free_dev(r->proj_z); free_dev(r->proj_req); free_dev(r->proj_wg_tiles); free_dev(r->counters);
@@ -1329,6 +1354,7 @@ int dslam_upload_scene_state(dslam_engine *e, dslam_scene *s, const dslam_hash_e
   int rc = 0;
   if (hash) {
     rc = h2d(e, s->hash, hash, (size_t)s->n_entries * sizeof(HashEntry));
+    if (!rc) rc = launch_build_alloc_bits(e, s);
     if (!rc) rc = finish_call(e);
   }
   SceneCounters *sc = reinterpret_cast<SceneCounters *>(e->pinned);

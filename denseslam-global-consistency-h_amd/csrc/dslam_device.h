@@ -153,45 +153,6 @@ __device__ __forceinline__ void check_block_vis(bool &vis, bool &vis_enl, int px
   check_point_vis<SWAPPING>(vis, vis_enl, pt, M, fx, fy, cx, cy, W, H);  // 1 0 1
 }
 
-// Frustum test for a SPARSE subset of a tile's entries.  In the table sweeps only ~10 % of the entries need the
-// 8-corner test, scattered over the lanes; tested in place, every wavefront would run the ~250-instruction test once
-// per entry slot (4 per lane) with a handful of lanes active.  Instead the workgroup compacts its candidates into
-// LDS and tests them densely (one candidate per lane), then hands every lane its own results back:
-// out[k] bit 0 = visible, bit 1 = visible in the enlarged frustum (0 for non-candidates).
-struct TileVisScratch {
-  short4 pos[kTileEntries];
-  unsigned short idx[kTileEntries];
-  unsigned char res[kTileEntries];
-  int n;
-};
-
-template <bool SWAPPING>
-__device__ __forceinline__ void tile_block_vis(TileVisScratch &s, const bool cand[4], const short4 pos[4], const Mat4 &M,
-                                               float fx, float fy, float cx, float cy, float voxel_size, int W, int H,
-                                               unsigned char out[4]) {
-  if (threadIdx.x == 0) s.n = 0;
-  *reinterpret_cast<unsigned *>(&s.res[threadIdx.x * 4]) = 0u;
-  __syncthreads();
-#pragma unroll
-  for (int k = 0; k < 4; k++)
-    if (cand[k]) {
-      const int j = atomicAdd(&s.n, 1);
-      s.pos[j] = pos[k];
-      s.idx[j] = (unsigned short)(threadIdx.x * 4 + k);
-    }
-  __syncthreads();
-  const int n = s.n;
-  for (int j = threadIdx.x; j < n; j += blockDim.x) {
-    const short4 b = s.pos[j];
-    bool vis, vis_enl;
-    check_block_vis<SWAPPING>(vis, vis_enl, b.x, b.y, b.z, M, fx, fy, cx, cy, voxel_size, W, H);
-    s.res[s.idx[j]] = (unsigned char)((vis ? 1 : 0) | (vis_enl ? 2 : 0));
-  }
-  __syncthreads();
-  const unsigned r = *reinterpret_cast<const unsigned *>(&s.res[threadIdx.x * 4]);
-  out[0] = r & 0xff; out[1] = (r >> 8) & 0xff; out[2] = (r >> 16) & 0xff; out[3] = r >> 24;
-}
-
 // ---- workgroup-level ordered ranks -------------------------------------------------------------------------
 // Exclusive prefix sum of one int per thread over a 256-thread workgroup (4 waves), in thread order.
 // `total` receives the workgroup sum.  Uses wave64 ballot-free shuffles + one LDS hop.
@@ -218,11 +179,38 @@ __device__ __forceinline__ int block_excl_scan(int v, int *lds_wave_sums /* [NWA
     if (w < wave) off += s;
     tot += s;
   }
-  total = tot;
+  total = __builtin_amdgcn_readfirstlane(tot);  // (uniform, and the compiler should know: loops and barriers hang off it)
   __syncthreads();
   return off + incl - v;
 }
 
+
+// the same for two ints per thread at once (one pair of barriers)
+template <int NWAVES>
+__device__ __forceinline__ void block_excl_scan2(int a, int b, int *lds /* [2 * NWAVES] */, int &ra, int &rb, int &ta, int &tb) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  int ia = a, ib = b;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const int na = __shfl_up(ia, d, 64), nb = __shfl_up(ib, d, 64);
+    if (lane >= d) { ia += na; ib += nb; }
+  }
+  if (lane == 63) { lds[wave] = ia; lds[NWAVES + wave] = ib; }
+  __syncthreads();
+  int oa = 0, ob = 0;
+  ta = 0; tb = 0;
+#pragma unroll
+  for (int w = 0; w < NWAVES; w++) {
+    const int sa = lds[w], sb = lds[NWAVES + w];
+    if (w < wave) { oa += sa; ob += sb; }
+    ta += sa; tb += sb;
+  }
+  __syncthreads();
+  ta = __builtin_amdgcn_readfirstlane(ta);
+  tb = __builtin_amdgcn_readfirstlane(tb);
+  ra = oa + ia - a;
+  rb = ob + ib - b;
+}
 
 // ---- ordered compaction over the hash table ---------------------------------------------------------------
 // Every ordered compaction is count -> scan -> apply over tiles of kTileEntries consecutive entries (one
@@ -264,14 +252,6 @@ __device__ void scan_tiles(const int *__restrict__ counts, int *__restrict__ off
   for (int c = 0; c < C; c++) totals[c] = carry[c];
 }
 
-// generic single-channel scan: offsets per tile, total (clipped to capacity) to *total_out
-static __global__ __launch_bounds__(1024) void k_scan_count(const int *tile_counts, int *tile_offsets, int n_tiles,
-                                                            int *total_out, int capacity) {
-  int totals[1];
-  scan_tiles<1>(tile_counts, tile_offsets, n_tiles, totals);
-  if (threadIdx.x == 0) *total_out = totals[0] < capacity ? totals[0] : capacity;
-}
-
 // Sum of a strided int array over [0, n) by a 256-thread workgroup (every thread gets the result).  Lets each
 // apply-workgroup derive its own exclusive tile offset from the (L2-hot, <= a few thousand) per-tile counts, which
 // removes the single-workgroup scan kernel -- one ~4.5 us kernel boundary -- from every ordered compaction.
@@ -281,42 +261,9 @@ __device__ __forceinline__ int block_sum_strided(const int *__restrict__ v, int 
   for (int d = 32; d > 0; d >>= 1) s += __shfl_xor(s, d, 64);
   if ((threadIdx.x & 63) == 0) lds4[threadIdx.x >> 6] = s;
   __syncthreads();
-  const int tot = lds4[0] + lds4[1] + lds4[2] + lds4[3];
+  const int tot = __builtin_amdgcn_readfirstlane(lds4[0] + lds4[1] + lds4[2] + lds4[3]);
   __syncthreads();
   return tot;
-}
-
-// The same sums in two halves, so that the loads can be issued before an unrelated dependent chain (a scan with
-// barriers) and reduced after it: partial_* only loads and adds per thread, reduce_* needs the whole workgroup.
-__device__ __forceinline__ int partial_sum_strided(const int *__restrict__ v, int n, int stride) {
-  int s = 0;
-  for (int i = threadIdx.x; i < n; i += 256) s += v[i * stride];
-  return s;
-}
-__device__ __forceinline__ int reduce_sum(int s, int *lds4) {
-  for (int d = 32; d > 0; d >>= 1) s += __shfl_xor(s, d, 64);
-  if ((threadIdx.x & 63) == 0) lds4[threadIdx.x >> 6] = s;
-  __syncthreads();
-  const int tot = lds4[0] + lds4[1] + lds4[2] + lds4[3];
-  __syncthreads();
-  return tot;
-}
-
-// both the sum over [0, n_prefix) and over [0, n_total) of a strided int array (n_prefix <= n_total), one pass
-__device__ __forceinline__ void block_prefix_and_total(const int *__restrict__ v, int n_prefix, int n_total, int stride,
-                                                       int *lds8, int &prefix, int &total) {
-  int sp = 0, st = 0;
-  for (int i = threadIdx.x; i < n_total; i += 256) {
-    const int x = v[i * stride];
-    st += x;
-    if (i < n_prefix) sp += x;
-  }
-  for (int d = 32; d > 0; d >>= 1) { sp += __shfl_xor(sp, d, 64); st += __shfl_xor(st, d, 64); }
-  if ((threadIdx.x & 63) == 0) { lds8[threadIdx.x >> 6] = sp; lds8[4 + (threadIdx.x >> 6)] = st; }
-  __syncthreads();
-  prefix = lds8[0] + lds8[1] + lds8[2] + lds8[3];
-  total = lds8[4] + lds8[5] + lds8[6] + lds8[7];
-  __syncthreads();
 }
 
 // ---- generic flag counting -----------------------------------------------------------------------------------
@@ -363,30 +310,6 @@ static __global__ __launch_bounds__(256) void k_compact_apply_fused(const unsign
     }
 }
 
-// pass 2 of every ordered compaction: entry index t goes to out[rank] for flags[t] > 0, ranks ascending in t
-static __global__ __launch_bounds__(256) void k_compact_apply(const unsigned char *__restrict__ flags, int n_entries,
-                                                       const int *__restrict__ tile_offsets, int *__restrict__ out,
-                                                       int capacity) {
-  __shared__ int red[4];
-  const int t0 = blockIdx.x * kTileEntries + threadIdx.x * 4;
-  unsigned char f[4] = {0, 0, 0, 0};
-  if (t0 < n_entries) {
-    const uchar4 v = *reinterpret_cast<const uchar4 *>(flags + t0);
-    f[0] = v.x; f[1] = v.y; f[2] = v.z; f[3] = v.w;
-  }
-  const int c = (f[0] > 0) + (f[1] > 0) + (f[2] > 0) + (f[3] > 0);
-  int tot;
-  int r = block_excl_scan<4>(c, red, tot);
-  if (tot == 0) return;
-  r += tile_offsets[blockIdx.x];
-#pragma unroll
-  for (int k = 0; k < 4; k++)
-    if (f[k] > 0) {
-      if (r < capacity) out[r] = t0 + k;
-      r++;
-    }
-}
-
 // ---- in-launch hand-off of per-tile counts -----------------------------------------------------------------
 // One 8-byte word per tile and channel: {epoch (high 32), a (bits 16..31), b (bits 0..15)}, written by ONE relaxed
 // agent-scope store and polled with relaxed agent-scope loads (sc1: served past the CU's L1).  The word IS the
@@ -396,51 +319,91 @@ static __device__ __forceinline__ void publish(unsigned long long *agg, int tile
                      __HIP_MEMORY_SCOPE_AGENT);
 }
 
-// sums of both fields over the tiles [0, n) (every thread of the 256-thread workgroup gets the result).  Every thread
-// has its words (up to kLookbackBatch per round) in flight TOGETHER and re-polls only those that are not there yet: a
-// look-back costs about one round trip to the memory side, not one per word.
-constexpr int kLookbackBatch = 8;
+// ---- bit-packed summaries of the hash table (round 3) --------------------------------------------------------------
+// The table has 1.18 M entries of which a frame touches a few thousand.  Every pass that used to enumerate all entries
+// (16 + 4 + 1 bytes each) to find them now walks bitmaps of one bit per entry (147 KB for the default table):
+//   scene         alloc_bits   entry holds a resident voxel block (ptr >= 0)
+//   render state  vis_bits     entriesVisibleType[entry] != 0
+//   engine        q1 / q2 / mark bits (two sets, used alternately: a pass clears the set of the pass before it), retest bits
+// A bitmap tile = kBitTileWords words = 32768 entries, one 256-thread workgroup, 4 consecutive words (one dwordx4) per
+// thread, so thread order = entry order and ordered ranks are popcounts + one block scan.  Arrays are padded to whole
+// tiles (the padding stays zero), so the loads need no bounds checks.
+constexpr int kBitTileWords = 1024;
+constexpr int kBitTileEntries = kBitTileWords * 32;
+static inline __host__ __device__ int bit_tiles(int entries) { return (entries + kBitTileEntries - 1) / kBitTileEntries; }
 
-static __device__ __forceinline__ void lookback(const unsigned long long *agg, int n, unsigned epoch, int *lds8, int &sum_a,
-                                         int &sum_b) {
-  int sa = 0, sb = 0;
-  for (int j0 = threadIdx.x; j0 < n; j0 += 256 * kLookbackBatch) {
-    unsigned long long w[kLookbackBatch];
-    unsigned pending = 0;
-#pragma unroll
-    for (int q = 0; q < kLookbackBatch; q++) {
-      const int j = j0 + 256 * q;
-      w[q] = 0;
-      if (j < n) {
-        w[q] = __hip_atomic_load(&agg[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        pending |= 1u << q;
-      }
-    }
-    while (true) {
-#pragma unroll
-      for (int q = 0; q < kLookbackBatch; q++)
-        if ((pending >> q) & 1u) {
-          if ((unsigned)(w[q] >> 32) == epoch) {
-            sa += (int)((unsigned)w[q] >> 16);
-            sb += (int)((unsigned)w[q] & 0xffffu);
-            pending &= ~(1u << q);
-          }
-        }
-      if (!pending) break;
-      __builtin_amdgcn_s_sleep(8);
-#pragma unroll
-      for (int q = 0; q < kLookbackBatch; q++)
-        if ((pending >> q) & 1u) w[q] = __hip_atomic_load(&agg[j0 + 256 * q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-  }
-  for (int d = 32; d > 0; d >>= 1) { sa += __shfl_xor(sa, d, 64); sb += __shfl_xor(sb, d, 64); }
-  if ((threadIdx.x & 63) == 0) { lds8[threadIdx.x >> 6] = sa; lds8[4 + (threadIdx.x >> 6)] = sb; }
+__device__ __forceinline__ unsigned sel4(const uint4 &v, int i) { return i == 0 ? v.x : (i == 1 ? v.y : (i == 2 ? v.z : v.w)); }
+__device__ __forceinline__ void or4(uint4 &v, int i, unsigned m) {
+  v.x |= i == 0 ? m : 0u; v.y |= i == 1 ? m : 0u; v.z |= i == 2 ? m : 0u; v.w |= i == 3 ? m : 0u;
+}
+__device__ __forceinline__ int popc4(const uint4 &v) { return __popc(v.x) + __popc(v.y) + __popc(v.z) + __popc(v.w); }
+__device__ __forceinline__ uint4 or4v(const uint4 &a, const uint4 &b) { return make_uint4(a.x | b.x, a.y | b.y, a.z | b.z, a.w | b.w); }
+__device__ __forceinline__ uint4 andn4v(const uint4 &a, const uint4 &b) { return make_uint4(a.x & ~b.x, a.y & ~b.y, a.z & ~b.z, a.w & ~b.w); }
+__device__ __forceinline__ void bit_set(unsigned *bits, int t) { atomicOr(&bits[t >> 5], 1u << (t & 31)); }
+__device__ __forceinline__ void bit_clear(unsigned *bits, int t) { atomicAnd(&bits[t >> 5], ~(1u << (t & 31))); }
+
+// Tiles are taken in the order in which workgroups START (a ticket from a device counter), not by blockIdx: a tile that
+// waits for the words of the tiles in front of it then only ever waits for workgroups that are already running, whatever
+// else occupies the device -- no co-residency assumption (round-2 ADVICE).  The counter only grows; the host passes the
+// value it had before the launch.  Every workgroup takes exactly ONE ticket (grid = number of tiles): a loop
+// "while (take_ticket() < n)" around code with barriers is what hipcc turned into nested execution-mask loops whose inner
+// one re-read the same ticket (the kernel never ended); straight-line code has no such freedom.
+__device__ __forceinline__ int take_ticket(unsigned *counter, unsigned base, int *lds_slot) {
+  if (threadIdx.x == 0) *lds_slot = (int)(atomicAdd(counter, 1u) - base);
   __syncthreads();
-  sum_a = lds8[0] + lds8[1] + lds8[2] + lds8[3];
-  sum_b = lds8[4] + lds8[5] + lds8[6] + lds8[7];
+  // (readfirstlane: the compiler must KNOW the tile index is wave-uniform -- a loop whose exit it believes to be divergent
+  // is rebuilt with execution masks, and the barriers inside then no longer match between the waves of a workgroup)
+  const int b = __builtin_amdgcn_readfirstlane(*lds_slot);
   __syncthreads();
+  return b;
 }
 
+// look-back over two channels at once: sums[0..1] = fields of agg_a, sums[2..3] = fields of agg_b over the tiles [0, n).
+// The spin is bounded (about a second): a word that never arrives is reported (returns false), not waited for forever.
+constexpr int kSpinLimit = 1 << 20;
+static __device__ __forceinline__ bool lookback2(const unsigned long long *agg_a, const unsigned long long *agg_b, int n,
+                                                 unsigned epoch, int *lds16, int sums[4]) {
+  int s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+  bool ok = true;
+  for (int j = threadIdx.x; j < n; j += 256) {
+    unsigned long long wa = __hip_atomic_load(&agg_a[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    unsigned long long wb = __hip_atomic_load(&agg_b[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    int spins = 0;
+    while ((unsigned)(wa >> 32) != epoch || (unsigned)(wb >> 32) != epoch) {
+      if (++spins > kSpinLimit) { ok = false; break; }
+      __builtin_amdgcn_s_sleep(4);
+      if ((unsigned)(wa >> 32) != epoch) wa = __hip_atomic_load(&agg_a[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if ((unsigned)(wb >> 32) != epoch) wb = __hip_atomic_load(&agg_b[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    s0 += (int)((unsigned)wa >> 16); s1 += (int)((unsigned)wa & 0xffffu);
+    s2 += (int)((unsigned)wb >> 16); s3 += (int)((unsigned)wb & 0xffffu);
+  }
+  for (int d = 32; d > 0; d >>= 1) {
+    s0 += __shfl_xor(s0, d, 64); s1 += __shfl_xor(s1, d, 64); s2 += __shfl_xor(s2, d, 64); s3 += __shfl_xor(s3, d, 64);
+  }
+  const int wv = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) { lds16[wv] = s0; lds16[4 + wv] = s1; lds16[8 + wv] = s2; lds16[12 + wv] = s3; }
+  const int all_ok = __syncthreads_and(ok ? 1 : 0);
+#pragma unroll
+  for (int c = 0; c < 4; c++) sums[c] = __builtin_amdgcn_readfirstlane(lds16[c * 4] + lds16[c * 4 + 1] + lds16[c * 4 + 2] + lds16[c * 4 + 3]);
+  __syncthreads();
+  return __builtin_amdgcn_readfirstlane(all_ok) != 0;
+}
+
+// block-wide sums of up to four ints (every thread of the 256-thread workgroup gets all of them)
+__device__ __forceinline__ void block_sum4(int v[4], int *lds16) {
+  for (int d = 32; d > 0; d >>= 1)
+#pragma unroll
+    for (int c = 0; c < 4; c++) v[c] += __shfl_xor(v[c], d, 64);
+  const int wv = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0)
+#pragma unroll
+    for (int c = 0; c < 4; c++) lds16[c * 4 + wv] = v[c];
+  __syncthreads();
+#pragma unroll
+  for (int c = 0; c < 4; c++) v[c] = __builtin_amdgcn_readfirstlane(lds16[c * 4] + lds16[c * 4 + 1] + lds16[c * 4 + 2] + lds16[c * 4 + 3]);
+  __syncthreads();
+}
 
 // A sweep tile = kSweepTile consecutive entries handled by one 256-thread workgroup, kSweepPer consecutive entries per
 // thread.  Fat tiles on purpose: the tiles of a launch wait for each other's words, and with 288 tiles instead of 1152

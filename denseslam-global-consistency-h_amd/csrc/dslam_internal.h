@@ -3,6 +3,8 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -52,8 +54,21 @@ struct dslam_engine {
                                       // sets a key clears it again, so no pass starts with a 4.7 MB memset)
   unsigned char *alloc_type = nullptr;  // [entries] entriesAllocType of the last pass (kept for the parity tests)
   short4 *block_coords = nullptr;     // [entries] blockCoords
-  int *req_list = nullptr;            // [entries] entries that got an allocType in the last pass (the next pass clears them)
-  int *req_count = nullptr;           // device: length of req_list
+  // bit-packed summaries of an allocation pass (dslam_device.h): requests on empty bucket heads (q1) / chain ends (q2),
+  // entries a pixel's walk found (mark).  Two sets used alternately: pass k sets bits in set k & 1 and zeroes set
+  // (k + 1) & 1 -- the set of the pass before it -- so no pass starts with a memset; bits_dirty[s] = words of set s that
+  // may be non-zero (scenes of different sizes share the sets).  retest: outcome of the frustum re-test of the entries
+  // that were visible before the pass (every word is written by every pass).
+  unsigned *bits_q1[2] = {nullptr, nullptr}, *bits_q2[2] = {nullptr, nullptr}, *bits_mark[2] = {nullptr, nullptr};
+  unsigned *bits_retest = nullptr;
+  unsigned *bits_tmp = nullptr;       // one more bitmap of scratch (frustum flags of FindVisibleBlocks, selections)
+  int bits_words = 0;                 // words per bitmap (whole tiles)
+  int bits_dirty[2] = {0, 0};
+  unsigned alloc_pass = 0;
+  // tickets of the single-pass ordered compactions (dslam_device.h take_ticket): one ever-growing device counter and
+  // the value the host knows it has
+  unsigned *ticket = nullptr;
+  unsigned ticket_base = 0;
   // single-pass ordered compactions: per-tile aggregates published inside one launch ({epoch, counts} in one 8-byte
   // word per tile; three channels: allocation requests, commit results, visible counts) and the launch counter that
   // tags them, so the arrays never need clearing
@@ -121,6 +136,8 @@ struct dslam_scene {
   int frame_counter = 0;
   // ITMGlobalCache
   unsigned char *swap_state = nullptr;  // device [entries]
+  unsigned *alloc_bits = nullptr;       // device [bit tiles]: bit t = entry t holds a resident block (ptr >= 0)
+  unsigned *swap1_bits = nullptr;       // device [bit tiles], swapping only: bit t = swap_state[t] == 1 (host copy to be merged)
   // host store of swapped-out blocks: page-locked slabs the kernels read and write directly over PCIe (no staging
   // copy, no host memcpy); an entry's block lives in slot slot_dev[entry]; slots are handed out by an atomic counter
   std::vector<uint4 *> slabs;           // pinned, kSlabBlocks blocks each, allocated as the store grows
@@ -146,6 +163,7 @@ struct dslam_render_state {
   int w = 0, h = 0, n_entries = 0, n_local = 0;
   int *visible_ids = nullptr;
   unsigned char *visible_type = nullptr;
+  unsigned *vis_bits = nullptr;   // bit t = visible_type[t] != 0 (kept by every kernel that writes a type)
   float2 *range = nullptr;      // renderingRangeImage (full image stride)
   float4 *raycast = nullptr;    // raycastResult
   uchar4 *image_rgba = nullptr; // RenderImage's outputImage (rgba types)
@@ -224,8 +242,20 @@ struct dslam_frame_store {
 };
 
 namespace dslam {
+// diagnostics (DSLAM_DEBUG_SYNC=1): wait for the stream after a launch and say which one it was -- finds the kernel that
+// hangs or faults without a profiler
+inline void dbg_sync(dslam_engine *e, const char *what) {
+  static const bool on = getenv("DSLAM_DEBUG_SYNC") != nullptr;
+  if (!on) return;
+  fprintf(stderr, "[dslam] %s ...", what);
+  fflush(stderr);
+  const hipError_t err = hipStreamSynchronize(e->stream);
+  fprintf(stderr, " %s\n", err == hipSuccess ? "ok" : hipGetErrorString(err));
+  fflush(stderr);
+}
 // kernels' host launchers (one translation unit per subsystem)
 int launch_scene_reset(dslam_engine *e, dslam_scene *s);
+int launch_build_alloc_bits(dslam_engine *e, dslam_scene *s);  // alloc_bits from an uploaded table
 int launch_view_convert(dslam_engine *e, dslam_view *v, const void *rgba_dev, const void *depth_dev, float a, float b);
 int launch_bgr_to_rgba(dslam_engine *e, const void *bgr_dev, uchar4 *rgba_dev, int npix);
 int launch_bilateral(dslam_engine *e, dslam_view *v);

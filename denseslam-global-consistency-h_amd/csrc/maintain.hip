@@ -23,61 +23,64 @@
 // Every flag array of this pipeline is all zero between passes: the kernel that consumes a flag clears it, so no pass
 // starts with a memset.  Round 1 spent 16 (decay) + 13 (window pop) launches per keyframe on this path; now 8 + 6, all of
 // which return at once when their device-side count is zero.
-#include "dslam_internal.h"
+#include "dslam_bits.h"
 
 #pragma clang fp contract(off)
 
 namespace dslam {
 
 // ---- candidate selection ---------------------------------------------------------------------------------------
-// MODE 0: block carries bit `bit` of ring `ring` (aged-list decay)
-// MODE 1: same, and the bit is cleared; flag only blocks no queued list references any more (sliding-window pop)
-// MODE 2: block not seen since `threshold` and not yet swept in this observation epoch (full-sweep decay)
-template <int MODE>
-__global__ __launch_bounds__(256) void k_select(const HashEntry *__restrict__ hash, int n_entries,
-                                                unsigned long long *masks, int words, int ring, int bit,
-                                                int *last_seen, int threshold, unsigned char *__restrict__ flags,
-                                                int *__restrict__ tile_counts) {
-  __shared__ int red[4];
-  const int t0 = blockIdx.x * kTileEntries + threadIdx.x * 4;
-  int c = 0;
-  if (t0 < n_entries) {
-    unsigned char f[4];
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-      const int ptr = hash[t0 + k].ptr;
-      f[k] = 0;
-      if (ptr >= 0) {
-        if (MODE == 2) {
-          const int ls = last_seen[ptr];
-          if (ls >= 0 && ls <= threshold) {
-            last_seen[ptr] = -2 - ls;
-            f[k] = 1;
-          }
-        } else {
-          unsigned long long *m = masks + ((size_t)ptr * 2) * words;
-          unsigned long long &w = m[(size_t)ring * words + (bit >> 6)];
-          const unsigned long long b = 1ull << (bit & 63);
-          if (w & b) {
-            if (MODE == 0) {
-              f[k] = 1;
-            } else {
-              w &= ~b;
-              unsigned long long any = 0;
-              for (int i = 0; i < 2 * words; i++) any |= m[i];
-              f[k] = any ? 0 : 1;
-            }
-          }
-        }
-      }
-      c += f[k];
-    }
-    *reinterpret_cast<uchar4 *>(flags + t0) = make_uchar4(f[0], f[1], f[2], f[3]);
+// Selections over the scene's alloc_bits (entries with a resident block), dslam_bits.h: ONE launch gives the ascending
+// list and its length; only entries that hold a block are looked at (round 2: two launches over all 1.18 M entries).
+//   SelDecayAged   block carries bit `bit` of ring `ring` (aged-list decay)
+//   SelSlidePop    same, and the bit is cleared; selected only if no queued list references the block any more
+//   SelDecaySweep  block not seen since `threshold` and not yet swept in this observation epoch (full-sweep decay)
+struct SelDecayAged {
+  const HashEntry *hash;
+  const unsigned long long *masks;
+  int words, ring, bit;
+  __device__ bool test(int t) const {
+    const int ptr = hash[t].ptr;
+    if (ptr < 0) return false;
+    return (masks[((size_t)ptr * 2 + ring) * words + (bit >> 6)] >> (bit & 63)) & 1ull;
   }
-  int tot;
-  block_excl_scan<4>(c, red, tot);
-  if (threadIdx.x == 0) tile_counts[blockIdx.x] = tot;
-}
+  __device__ void emit(int, int, bool) const {}
+  __device__ void finish(int) const {}
+};
+struct SelSlidePop {
+  const HashEntry *hash;
+  unsigned long long *masks;
+  int words, ring, bit;
+  unsigned char *flags;   // (optional) byte flag per selected entry: the release pipeline's removal flags
+  __device__ bool test(int t) const {
+    const int ptr = hash[t].ptr;
+    if (ptr < 0) return false;
+    unsigned long long *m = masks + ((size_t)ptr * 2) * words;
+    unsigned long long &w = m[(size_t)ring * words + (bit >> 6)];
+    const unsigned long long b = 1ull << (bit & 63);
+    if (!(w & b)) return false;
+    w &= ~b;
+    unsigned long long any = 0;
+    for (int i = 0; i < 2 * words; i++) any |= m[i];
+    return any == 0;
+  }
+  __device__ void emit(int t, int, bool) const { if (flags) flags[t] = 1; }
+  __device__ void finish(int) const {}
+};
+struct SelDecaySweep {
+  const HashEntry *hash;
+  int *last_seen;
+  int threshold;
+  __device__ bool test(int t) const {
+    const int ptr = hash[t].ptr;
+    if (ptr < 0) return false;
+    const int ls = last_seen[ptr];
+    if (ls >= 0 && ls <= threshold) { last_seen[ptr] = -2 - ls; return true; }
+    return false;
+  }
+  __device__ void emit(int, int, bool) const {}
+  __device__ void finish(int) const {}
+};
 
 // ---- decay: one wavefront per candidate block ---------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_decay_blocks(const int *__restrict__ cand, const int *count_ptr,
@@ -110,14 +113,17 @@ __global__ __launch_bounds__(256) void k_decay_blocks(const int *__restrict__ ca
 
 // ---- removal list of a decay pass: ordered compaction over the CANDIDATE list -----------------------------------------
 // cand[0..n) ascending in entry index; flag[i] = 1 for the candidates to release.  One launch: tiles of kSweepTile
-// candidates, counts exchanged in-launch (dslam_device.h look-back).  The grid covers the largest possible list; tiles
-// past the end publish zero and leave.  Consumes (clears) the flags.
+// candidates taken by ticket, counts exchanged in-launch (dslam_bits.h look-back).  Tiles past the end publish zero and
+// leave.  Consumes (clears) the flags.
 __global__ __launch_bounds__(256) void k_compact_candidates(const int *__restrict__ cand, const int *count_ptr,
                                                             unsigned char *flag, int *__restrict__ out, int *total_out,
-                                                            unsigned long long *agg, unsigned epoch, int n_tiles) {
+                                                            TileChain ch, int *error_flags) {
   __shared__ int red[8];
-  const int n = *count_ptr;
-  for (int b = blockIdx.x; b < n_tiles; b += gridDim.x) {
+  __shared__ int s_ticket;
+  const int n = __builtin_amdgcn_readfirstlane(*count_ptr);
+  const int b = take_ticket(ch.ticket, ch.ticket_base, &s_ticket);   // (one tile per workgroup)
+  if (b >= ch.n_tiles) return;
+  {
     const int i0 = b * kSweepTile + threadIdx.x * kSweepPer;
     unsigned m = 0;
     if (i0 < n) {
@@ -134,12 +140,11 @@ __global__ __launch_bounds__(256) void k_compact_candidates(const int *__restric
     }
     int tot;
     int r = block_excl_scan<4>(__popc(m), red, tot);
-    if (threadIdx.x == 0) publish(agg, b, epoch, tot >> 12, tot & 0xfff);
-    const bool last = b == n_tiles - 1;
+    if (threadIdx.x == 0) publish1(ch.agg, b, ch.epoch, tot);
+    const bool last = b == ch.n_tiles - 1;
     if (tot > 0 || last) {
-      int hi, lo;
-      lookback(agg, b, epoch, red, hi, lo);
-      const int offset = hi * 4096 + lo;
+      int offset;
+      if (!lookback1(ch.agg, b, ch.epoch, red, offset) && threadIdx.x == 0) atomicOr(error_flags, 2);
       if (last && threadIdx.x == 0) *total_out = offset + tot;
       r += offset;
       for (; m; m &= m - 1) out[r++] = cand[i0 + __ffs((int)m) - 1];
@@ -200,8 +205,8 @@ __global__ __launch_bounds__(256) void k_release_and_leaders(const int *__restri
 // leaders rewrite their bucket chain once (DESIGN.md "batch release"); consumes (clears) the removal flags
 __global__ __launch_bounds__(256) void k_unlink(const int *__restrict__ leader_bucket, const SceneCounters *cnt,
                                                 HashEntry *hash, int num_buckets, unsigned char *remove_flags,
-                                                unsigned char *freed_flags, unsigned char *vis_type, int *maint_flags,
-                                                int list_is_foreign) {
+                                                unsigned char *freed_flags, unsigned char *vis_type, unsigned *vis_bits,
+                                                unsigned *alloc_bits, int *maint_flags, int list_is_foreign) {
   // list_is_foreign: the render state's visible list is not "the entries with a type" at the moment (FindVisibleBlocks
   // wrote it, or it was uploaded): any release then rebuilds it from the types, as the batch release is defined --
   // a released or moved entry may sit in that list without having a type (found by the fuzz test, seed 60045)
@@ -219,13 +224,22 @@ __global__ __launch_bounds__(256) void k_unlink(const int *__restrict__ leader_b
         remove_flags[c] = 0;
         if (c != head) freed_flags[c - num_buckets] = 1;
         store_entry(hash, c, 0, 0, 0, 0, -2);
-        if (vis_type) { touched_visible |= vis_type[c] != 0; vis_type[c] = 0; }
+        bit_clear(alloc_bits, c);
+        if (vis_type && vis_type[c] != 0) { touched_visible = true; vis_type[c] = 0; bit_clear(vis_bits, c); }
       } else {
         int cur = c;
         if (prev == -1) {
           if (c != head) {  // first survivor moves into the released bucket head
             store_entry(hash, head, e.pos[0], e.pos[1], e.pos[2], e.offset, e.ptr);
-            if (vis_type) { touched_visible |= vis_type[c] != 0; vis_type[head] = vis_type[c]; vis_type[c] = 0; }
+            if (e.ptr >= 0) bit_set(alloc_bits, head);
+            bit_clear(alloc_bits, c);
+            if (vis_type && vis_type[c] != 0) {  // (the released head's own type went to 0 a moment ago, by this lane)
+              touched_visible = true;
+              vis_type[head] = vis_type[c];
+              bit_set(vis_bits, head);
+              vis_type[c] = 0;
+              bit_clear(vis_bits, c);
+            }
             store_entry(hash, c, 0, 0, 0, 0, -2);
             freed_flags[c - num_buckets] = 1;
             cur = head;
@@ -243,15 +257,18 @@ __global__ __launch_bounds__(256) void k_unlink(const int *__restrict__ leader_b
 }
 
 // Freed excess slots back onto the excess free list in ascending slot order (single-pass ordered compaction: tile counts
-// exchanged in-launch), flags consumed; the last tile folds the whole removal pass into the pool counters.
+// exchanged in-launch, tiles taken by ticket), flags consumed; the tile that ends the list folds the whole removal pass
+// into the pool counters.
 __global__ __launch_bounds__(256) void k_push_freed_finalize(unsigned char *freed_flags, int n_excess, int *excess_list,
-                                                             SceneCounters *cnt, int count_as_slid, unsigned long long *agg,
-                                                             unsigned epoch, int n_tiles) {
+                                                             SceneCounters *cnt, int count_as_slid, TileChain ch) {
   __shared__ int red[8];
-  const int removed = cnt->remove_count;
-  if (removed == 0) return;  // (nothing was released, so no slot came free and no flag is set)
-  const int base_ex = cnt->last_free_ex;  // (only the last tile, after everything else, changes it)
-  for (int b = blockIdx.x; b < n_tiles; b += gridDim.x) {
+  __shared__ int s_ticket;
+  // (read before this workgroup publishes anything; only the last tile changes them)
+  const int removed = __builtin_amdgcn_readfirstlane(cnt->remove_count);
+  const int base_ex = __builtin_amdgcn_readfirstlane(cnt->last_free_ex);
+  const int b = take_ticket(ch.ticket, ch.ticket_base, &s_ticket);   // (one tile per workgroup)
+  if (removed == 0 || b >= ch.n_tiles) return;  // (nothing was released: no slot came free and no flag is set)
+  {
     const int i0 = b * kSweepTile + threadIdx.x * kSweepPer;
     unsigned m = 0;
     if (i0 < n_excess) {
@@ -268,16 +285,16 @@ __global__ __launch_bounds__(256) void k_push_freed_finalize(unsigned char *free
     }
     int tot;
     int r = block_excl_scan<4>(__popc(m), red, tot);
-    if (threadIdx.x == 0) publish(agg, b, epoch, tot >> 12, tot & 0xfff);
-    const bool last = b == n_tiles - 1;
+    if (threadIdx.x == 0) publish1(ch.agg, b, ch.epoch, tot);
+    const bool last = b == ch.n_tiles - 1;
     if (tot > 0 || last) {
-      int hi, lo;
-      lookback(agg, b, epoch, red, hi, lo);
-      const int offset = hi * 4096 + lo;
+      int offset;
+      if (!lookback1(ch.agg, b, ch.epoch, red, offset) && threadIdx.x == 0) atomicOr(&cnt->error_flags, 2);
       r += offset + base_ex + 1;
       for (; m; m &= m - 1) excess_list[r++] = i0 + __ffs((int)m) - 1;
       if (last) {
-        // every other tile's pushes target slots above the old top and do not read the counters again
+        // every other tile's pushes target slots above the old top, and every other workgroup read the counters before it
+        // published (this tile has just seen all their counts)
         __syncthreads();
         if (threadIdx.x == 0) {
           cnt->last_free += removed;
@@ -291,65 +308,34 @@ __global__ __launch_bounds__(256) void k_push_freed_finalize(unsigned char *free
   }
 }
 
-// rebuild of a render state's visible list from its types, only when the pass took an entry out of it: single-pass
-// ordered compaction over the type bytes (4096-entry tiles).
+// rebuild of a render state's visible list from its types, only when the pass took an entry out of it: an ordered
+// selection over the render state's vis_bits (every entry with a type).
 // `gen` = the generation bit of the render state's last allocation pass.  An entry that did not fit into the list of that
 // pass (a visible list is capped at the pool size) kept its 1 / 2 with the NEXT pass' bit -- upstream leaves such a type in
 // place without re-arming it, so it counts as marked again.  Once the rebuilt, shorter list has room for it, it is an
 // ordinary listed entry, which upstream's next pass re-arms as 3: its byte gets the last pass' bit here (found by the
 // fuzz test, seed 10744: list full after an allocation-only pass, then a window pop, then a fusion).
-__global__ __launch_bounds__(256) void k_rebuild_visible(unsigned char *__restrict__ vis_type, int n_entries, int *ids,
-                                                         int capacity, RenderCounters *rc, int *maint_flags,
-                                                         unsigned long long *agg, unsigned epoch, int n_tiles, unsigned gen,
-                                                         int force) {
-  __shared__ int red[8];
-  if (maint_flags[0] == 0 && !force) return;  // (force: the host knows the list has to be rebuilt -- the swapping paths)
-  for (int b = blockIdx.x; b < n_tiles; b += gridDim.x) {
-    const int t0 = b * kSweepTile + threadIdx.x * kSweepPer;
-    unsigned m = 0;
-    if (t0 < n_entries) {
-#pragma unroll
-      for (int q = 0; q < kSweepPer / 4; q++) {
-        const unsigned w = *reinterpret_cast<const unsigned *>(vis_type + t0 + q * 4);
-        for (int k = 0; k < 4; k++)
-          if ((w >> (8 * k)) & 0xffu) m |= 1u << (q * 4 + k);
-      }
-    }
-    int tot;
-    int r = block_excl_scan<4>(__popc(m), red, tot);
-    if (threadIdx.x == 0) publish(agg, b, epoch, tot >> 12, tot & 0xfff);
-    const bool last = b == n_tiles - 1;
-    if (tot > 0 || last) {
-      int hi, lo;
-      lookback(agg, b, epoch, red, hi, lo);
-      const int offset = hi * 4096 + lo;
-      if (last && threadIdx.x == 0) {
-        rc->no_visible = (offset + tot) < capacity ? (offset + tot) : capacity;
-        // every other tile has read the flag by now (the last tile has just seen all their counts): re-arm it
-        maint_flags[0] = 0;
-      }
-      r += offset;
-      for (; m; m &= m - 1) {
-        if (r < capacity) {
-          const int t = t0 + __ffs((int)m) - 1;
-          ids[r] = t;
-          const unsigned char ty = vis_type[t];  // (this thread owns the bytes of its entries)
-          if ((ty & 0x80u) != gen) vis_type[t] = (unsigned char)(gen | (ty & 0x7fu));
-        }
-        r++;
-      }
-    }
+struct SelRebuildVisible {
+  unsigned char *vis_type;
+  unsigned gen;
+  int *maint_flags;
+  __device__ bool test(int) const { return true; }
+  __device__ void emit(int t, int, bool listed) const {
+    if (!listed) return;
+    const unsigned char ty = vis_type[t];
+    if ((ty & 0x80u) != gen) vis_type[t] = (unsigned char)(gen | (ty & 0x7fu));
   }
-}
+  // every other tile has read the flag by now (the tile that ends the table has just seen all their counts): re-arm it
+  __device__ void finish(int) const { maint_flags[0] = 0; }
+};
 
 // scratch: candidate flags (table sized, overwritten whole by every selection), the lists
 struct MaintScratch {
-  unsigned char *cand_flags, *rem_flags, *freed_flags, *rem_cand;
+  unsigned char *rem_flags, *freed_flags, *rem_cand;
   int *cand_list, *rem_list, *leaders;
 };
 static MaintScratch carve(dslam_engine *e, int N) {
   MaintScratch m;
-  m.cand_flags = reinterpret_cast<unsigned char *>(e->list_c);
   m.rem_flags = e->rem_flags;
   m.freed_flags = e->freed_flags;
   m.rem_cand = e->rem_cand;
@@ -360,26 +346,13 @@ static MaintScratch carve(dslam_engine *e, int N) {
   return m;
 }
 
-static unsigned next_epoch(dslam_engine *e) {
-  if (++e->epoch == 0) e->epoch = 1;
-  return e->epoch;
-}
-
-// grid of the single-pass compaction kernels: all tiles resident together (they wait for each other's counts); tiles
-// are taken in ascending order, so fewer workgroups than tiles is fine as well
-static int lookback_grid(dslam_engine *e, int n_tiles) {
-  const int cap = (e->sm_count > 0 ? e->sm_count : 1) * 2;
-  return n_tiles < cap ? (n_tiles > 0 ? n_tiles : 1) : cap;
-}
-
-static int rebuild_visible_list(dslam_engine *e, dslam_render_state *r) {
-  // (the swapping paths call this directly after they have changed types themselves: the same single-pass rebuild as
-  // the release pipeline's, forced -- it also takes the "marked again" bit off entries that had not fitted into the last
-  // pass' list and are listed now, see k_rebuild_visible)
-  const int v_tiles = (r->n_entries + kSweepTile - 1) / kSweepTile;
-  hipLaunchKernelGGL(k_rebuild_visible, dim3(lookback_grid(e, v_tiles)), dim3(256), 0, e->stream, r->visible_type,
-                     r->n_entries, r->visible_ids, r->n_local, r->counters, e->maint_flags, e->agg, next_epoch(e), v_tiles,
-                     (unsigned)r->gen, 1);
+// force: the host knows the list has to be rebuilt (the swapping paths, after they changed types themselves); else only
+// if the release pipeline's flag says that an entry with a type went
+static int rebuild_visible_list(dslam_engine *e, dslam_render_state *r, bool force = true) {
+  SelRebuildVisible sel{r->visible_type, (unsigned)r->gen, e->maint_flags};
+  launch_bits_select(e, r->vis_bits, r->n_entries, sel, r->visible_ids, r->n_local, &r->counters->no_visible, nullptr, nullptr,
+                     force ? nullptr : e->maint_flags);
+  dbg_sync(e, "rebuild_visible_list");
   DSLAM_HIP(hipGetLastError());
   return DSLAM_OK;
 }
@@ -390,59 +363,74 @@ static int release_listed(dslam_engine *e, dslam_scene *s, dslam_render_state *r
   hipLaunchKernelGGL(k_release_and_leaders, dim3(kReleaseWgs + kLeaderWgs), dim3(256), 0, e->stream, m.rem_list, s->counters,
                      s->hash, reinterpret_cast<uint4 *>(s->voxels), s->alloc_list, s->masks, s->last_seen, s->history_words,
                      s->p.num_buckets, (unsigned)(s->p.num_buckets - 1), m.rem_flags, m.leaders);
+  dbg_sync(e, "k_release_and_leaders");
   hipLaunchKernelGGL(k_unlink, dim3(256), dim3(256), 0, e->stream, m.leaders, s->counters, s->hash, s->p.num_buckets,
-                     m.rem_flags, m.freed_flags, r ? r->visible_type : (unsigned char *)nullptr, e->maint_flags,
-                     (r && !r->types_follow_list) ? 1 : 0);
-  const int x_tiles = (s->p.num_excess + kSweepTile - 1) / kSweepTile;
-  hipLaunchKernelGGL(k_push_freed_finalize, dim3(lookback_grid(e, x_tiles)), dim3(256), 0, e->stream, m.freed_flags,
-                     s->p.num_excess, s->excess_list, s->counters, count_as_slid, e->agg, next_epoch(e), x_tiles);
-  if (r) {
-    const int v_tiles = (r->n_entries + kSweepTile - 1) / kSweepTile;
-    hipLaunchKernelGGL(k_rebuild_visible, dim3(lookback_grid(e, v_tiles)), dim3(256), 0, e->stream, r->visible_type,
-                       r->n_entries, r->visible_ids, r->n_local, r->counters, e->maint_flags, e->agg, next_epoch(e), v_tiles,
-                       (unsigned)r->gen, 0);
+                     m.rem_flags, m.freed_flags, r ? r->visible_type : (unsigned char *)nullptr,
+                     r ? r->vis_bits : (unsigned *)nullptr, s->alloc_bits, e->maint_flags, (r && !r->types_follow_list) ? 1 : 0);
+  dbg_sync(e, "k_unlink");
+  if (getenv("DSLAM_DEBUG_SYNC")) {
+    unsigned tk = 0;
+    SceneCounters sc;
+    (void)hipMemcpy(&tk, e->ticket, 4, hipMemcpyDeviceToHost);
+    (void)hipMemcpy(&sc, s->counters, sizeof(sc), hipMemcpyDeviceToHost);
+    fprintf(stderr, "[dslam] ticket dev %u host %u  remove_count %d last_free %d last_free_ex %d err %d epoch %u\n", tk, e->ticket_base,
+            sc.remove_count, sc.last_free, sc.last_free_ex, sc.error_flags, e->epoch);
   }
+  {
+    int grid;
+    const TileChain ch = next_chain(e, (s->p.num_excess + kSweepTile - 1) / kSweepTile, &grid);
+    hipLaunchKernelGGL(k_push_freed_finalize, dim3(grid), dim3(256), 0, e->stream, m.freed_flags, s->p.num_excess,
+                       s->excess_list, s->counters, count_as_slid, ch);
+  }
+  dbg_sync(e, "k_push_freed_finalize");
   DSLAM_HIP(hipGetLastError());
+  if (r) return rebuild_visible_list(e, r, false);
   return DSLAM_OK;
 }
 
+// m.cand_list[0 .. swap_count) holds the selection: decay those blocks, release the ones left without a measured voxel
 static int decay_candidates(dslam_engine *e, dslam_scene *s, dslam_render_state *r, const MaintScratch &m,
                             int max_weight) {
-  // cand_flags / tile_counts hold the selection; turn it into the candidate list, decay, release empties
-  const int N = s->n_entries, n_tiles = num_tiles(N);
-  hipLaunchKernelGGL(k_compact_apply_fused, dim3(n_tiles), dim3(256), 0, e->stream, m.cand_flags, N, e->tile_counts,
-                     m.cand_list, s->p.num_local_blocks, &s->counters->swap_count);  // swap_count doubles as candidate count
   hipLaunchKernelGGL(k_decay_blocks, dim3(1024), dim3(256), 0, e->stream, m.cand_list, &s->counters->swap_count, s->hash,
                      reinterpret_cast<uint4 *>(s->voxels), max_weight, m.rem_flags, m.rem_cand, s->p.use_swapping ? 0 : 1);
+  dbg_sync(e, "k_decay_blocks");
   DSLAM_HIP(hipGetLastError());
   if (s->p.use_swapping) return DSLAM_OK;  // entries of a swapping scene are never unlinked (ITMGlobalCache keys)
-  const int c_tiles = (s->p.num_local_blocks + kSweepTile - 1) / kSweepTile;
-  hipLaunchKernelGGL(k_compact_candidates, dim3(lookback_grid(e, c_tiles)), dim3(256), 0, e->stream, m.cand_list,
-                     &s->counters->swap_count, m.rem_cand, m.rem_list, &s->counters->remove_count, e->agg, next_epoch(e), c_tiles);
+  {
+    int grid;
+    const TileChain ch = next_chain(e, (s->p.num_local_blocks + kSweepTile - 1) / kSweepTile, &grid);
+    hipLaunchKernelGGL(k_compact_candidates, dim3(grid), dim3(256), 0, e->stream, m.cand_list, &s->counters->swap_count,
+                       m.rem_cand, m.rem_list, &s->counters->remove_count, ch, &s->counters->error_flags);
+  }
+  dbg_sync(e, "k_compact_candidates");
   return release_listed(e, s, r, m, 0);
 }
 
 int launch_decay(dslam_engine *e, dslam_scene *s, dslam_render_state *r, int max_weight, int min_age, int force_all,
                  int q) {
   DSLAM_REQUIRE(!r || r->n_entries == s->n_entries, "render state was created for a different scene size");
-  const int N = s->n_entries, n_tiles = num_tiles(N);
+  const int N = s->n_entries;
   int rc = ensure_scratch(e, N, s->p.num_local_blocks);
   if (rc) return rc;
   const MaintScratch m = carve(e, N);
+  // swap_count doubles as the candidate count
   if (!force_all) {
     const int bits = 64 * s->history_words;
     const int newest = s->ring_next[q] - 1;
     int k = s->decay_cursor[q] > s->ring_head[q] ? s->decay_cursor[q] : s->ring_head[q];
     for (; k <= newest - min_age; k++) {
-      hipLaunchKernelGGL(k_select<0>, dim3(n_tiles), dim3(256), 0, e->stream, s->hash, N, s->masks, s->history_words, q,
-                         k % bits, s->last_seen, 0, m.cand_flags, e->tile_counts);
+      SelDecayAged sel{s->hash, s->masks, s->history_words, q, k % bits};
+      launch_bits_select(e, s->alloc_bits, N, sel, m.cand_list, s->p.num_local_blocks, &s->counters->swap_count, nullptr,
+                         &s->counters->error_flags);
       if ((rc = decay_candidates(e, s, r, m, max_weight))) return rc;
     }
     if (k > s->decay_cursor[q]) s->decay_cursor[q] = k;
   } else {
     const int threshold = (s->frame_counter - 1) - min_age;
-    hipLaunchKernelGGL(k_select<2>, dim3(n_tiles), dim3(256), 0, e->stream, s->hash, N, s->masks, s->history_words, q, 0,
-                       s->last_seen, threshold, m.cand_flags, e->tile_counts);
+    SelDecaySweep sel{s->hash, s->last_seen, threshold};
+    launch_bits_select(e, s->alloc_bits, N, sel, m.cand_list, s->p.num_local_blocks, &s->counters->swap_count, nullptr,
+                       &s->counters->error_flags);
+    dbg_sync(e, "select decay sweep");
     if ((rc = decay_candidates(e, s, r, m, max_weight))) return rc;
   }
   return DSLAM_OK;
@@ -454,36 +442,30 @@ int launch_decay(dslam_engine *e, dslam_scene *s, dslam_render_state *r, int max
 // steps of a ProcessFrame are kernels only (the host's part is to keep enough slabs mapped, ensure_slots).  The flush
 // (SaveToGlobalMemory) and the window pop of a swapping scene still loop on host-read counts.
 // ---------------------------------------------------------------------------------------------------------------
-// MODE 0: swap state == 1 (needs the host copy merged)     -- IntegrateGlobalIntoLocal
-// MODE 1: resident with state 0 (never visible since allocation) -- flush promotion
-// MODE 2: state == 2, resident, not visible (or any visibility) -- SaveToGlobalMemory
-template <int MODE>
-__global__ __launch_bounds__(256) void k_swap_select(const HashEntry *__restrict__ hash, int n_entries,
-                                                     const unsigned char *__restrict__ swap_state,
-                                                     const unsigned char *__restrict__ vis_type,
-                                                     unsigned char *__restrict__ flags, int *__restrict__ tile_counts) {
-  __shared__ int red[4];
-  const int t0 = blockIdx.x * kTileEntries + threadIdx.x * 4;
-  int c = 0;
-  if (t0 < n_entries) {
-    unsigned char f[4];
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-      const int t = t0 + k;
-      const unsigned char st = swap_state[t];
-      bool sel;
-      if (MODE == 0) sel = st == 1;
-      else if (MODE == 1) sel = st == 0 && hash[t].ptr >= 0;
-      else sel = st == 2 && hash[t].ptr >= 0 && (vis_type == nullptr || vis_type[t] == 0);
-      f[k] = sel ? 1 : 0;
-      c += f[k];
-    }
-    *reinterpret_cast<uchar4 *>(flags + t0) = make_uchar4(f[0], f[1], f[2], f[3]);
-  }
-  int tot;
-  block_excl_scan<4>(c, red, tot);
-  if (threadIdx.x == 0) tile_counts[blockIdx.x] = tot;
-}
+// SelSwapPending   swap state == 1 (needs the host copy merged): over the scene's swap1_bits   -- IntegrateGlobalIntoLocal
+// SelSwapFresh     resident with state 0 (never visible since allocation): over alloc_bits      -- flush promotion
+// SelSwapOut       state == 2, resident, not visible (or any visibility): over alloc_bits        -- SaveToGlobalMemory
+struct SelSwapPending {
+  const unsigned char *swap_state;
+  __device__ bool test(int t) const { return swap_state[t] == 1; }
+  __device__ void emit(int, int, bool) const {}
+  __device__ void finish(int) const {}
+};
+struct SelSwapFresh {
+  const HashEntry *hash;
+  const unsigned char *swap_state;
+  __device__ bool test(int t) const { return swap_state[t] == 0 && hash[t].ptr >= 0; }
+  __device__ void emit(int, int, bool) const {}
+  __device__ void finish(int) const {}
+};
+struct SelSwapOut {
+  const HashEntry *hash;
+  const unsigned char *swap_state;
+  const unsigned char *vis_type;   // null: whatever the visibility
+  __device__ bool test(int t) const { return swap_state[t] == 2 && hash[t].ptr >= 0 && (vis_type == nullptr || vis_type[t] == 0); }
+  __device__ void emit(int, int, bool) const {}
+  __device__ void finish(int) const {}
+};
 
 // CombineVoxelInformation: merge the host copy (src) into the resident voxel (dst)
 __device__ __forceinline__ void combine_voxel(unsigned slo, unsigned shi, unsigned &dlo, unsigned &dhi, int maxW) {
@@ -533,7 +515,8 @@ __global__ __launch_bounds__(256) void k_swap_merge(const int *__restrict__ ids,
                                                     const int *__restrict__ n_dev, int n_host,
                                                     const HashEntry *__restrict__ hash, uint4 *voxels16,
                                                     uint4 *const *__restrict__ slabs, unsigned char *swap_state,
-                                                    int maxW, SceneCounters *stats) {
+                                                    unsigned *swap1_bits, int only_unmerged, int maxW,
+                                                    SceneCounters *stats) {
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane((int)((blockIdx.x * 256 + threadIdx.x) >> 6));
   const int n_waves = gridDim.x * 4;
@@ -541,6 +524,8 @@ __global__ __launch_bounds__(256) void k_swap_merge(const int *__restrict__ ids,
   if (stats && blockIdx.x == 0 && threadIdx.x == 0) stats->swapped_in = n;
   for (int i = wave; i < n; i += n_waves) {
     const int t = ids[i];
+    const unsigned char st = swap_state[t];
+    if (only_unmerged && st == 2) continue;   // (a block leaving the window whose host copy is merged already)
     const int ptr = hash[t].ptr;
     const int slot = slot_of_entry[t];
     if (slot >= 0 && ptr >= 0) {
@@ -557,7 +542,10 @@ __global__ __launch_bounds__(256) void k_swap_merge(const int *__restrict__ ids,
         blk[j * 64 + lane] = d;
       }
     }
-    if (lane == 0) swap_state[t] = 2;
+    if (lane == 0) {
+      swap_state[t] = 2;
+      if (st == 1) bit_clear(swap1_bits, t);
+    }
   }
 }
 
@@ -568,8 +556,8 @@ __global__ __launch_bounds__(256) void k_swap_pack(const int *__restrict__ ids, 
                                                    const int *__restrict__ n_dev, int n_host, HashEntry *hash,
                                                    uint4 *voxels16, uint4 *const *__restrict__ slabs, int *alloc_list,
                                                    unsigned long long *masks, int *last_seen, int words,
-                                                   unsigned char *swap_state, unsigned char *vis_type,
-                                                   SceneCounters *cnt) {
+                                                   unsigned char *swap_state, unsigned *swap1_bits, unsigned *alloc_bits,
+                                                   unsigned char *vis_type, unsigned *vis_bits, SceneCounters *cnt) {
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane((int)((blockIdx.x * 256 + threadIdx.x) >> 6));
   const int n_waves = gridDim.x * 4;
@@ -600,8 +588,10 @@ __global__ __launch_bounds__(256) void k_swap_pack(const int *__restrict__ ids, 
       alloc_list[base + 1 + i] = ptr;
       last_seen[ptr] = -1;
       hash[t].ptr = -1;
+      bit_clear(alloc_bits, t);
+      if (swap_state[t] == 1) bit_clear(swap1_bits, t);
       swap_state[t] = 0;
-      if (vis_type) vis_type[t] = 0;
+      if (vis_type && vis_type[t] != 0) { vis_type[t] = 0; bit_clear(vis_bits, t); }
     }
   }
 }
@@ -620,13 +610,14 @@ __global__ void k_set_swap_stats(SceneCounters *cnt, int in, int out) {
 }
 
 // select (ordered, capped at the transfer size): the list in m.cand_list, its length in counters->swap_count
+// MODE 0 / 1 / 2 = SelSwapPending / SelSwapFresh / SelSwapOut
 template <int MODE>
 static int swap_select(dslam_engine *e, dslam_scene *s, const unsigned char *vis_type, const MaintScratch &m) {
-  const int N = s->n_entries, n_tiles = num_tiles(N);
-  hipLaunchKernelGGL(k_swap_select<MODE>, dim3(n_tiles), dim3(256), 0, e->stream, s->hash, N, s->swap_state, vis_type,
-                     m.cand_flags, e->tile_counts);
-  hipLaunchKernelGGL(k_compact_apply_fused, dim3(n_tiles), dim3(256), 0, e->stream, m.cand_flags, N, e->tile_counts,
-                     m.cand_list, kTransferBlocks, &s->counters->swap_count);
+  const int N = s->n_entries;
+  int *count = &s->counters->swap_count, *err = &s->counters->error_flags;
+  if (MODE == 0) launch_bits_select(e, s->swap1_bits, N, SelSwapPending{s->swap_state}, m.cand_list, kTransferBlocks, count, nullptr, err);
+  else if (MODE == 1) launch_bits_select(e, s->alloc_bits, N, SelSwapFresh{s->hash, s->swap_state}, m.cand_list, kTransferBlocks, count, nullptr, err);
+  else launch_bits_select(e, s->alloc_bits, N, SelSwapOut{s->hash, s->swap_state, vis_type}, m.cand_list, kTransferBlocks, count, nullptr, err);
   DSLAM_HIP(hipGetLastError());
   return DSLAM_OK;
 }
@@ -671,24 +662,25 @@ static int ensure_slots(dslam_engine *e, dslam_scene *s, int need) {
   return DSLAM_OK;
 }
 
-// merge the host copies of the listed entries (m.cand_list) into the map; n_dev: length on the device, else n_host
-static int merge_from_host(dslam_engine *e, dslam_scene *s, const MaintScratch &m, const int *n_dev, int n_host,
-                           bool set_stats) {
-  hipLaunchKernelGGL(k_swap_merge, dim3(1024), dim3(256), 0, e->stream, m.cand_list, s->slot_dev, n_dev, n_host, s->hash,
-                     reinterpret_cast<uint4 *>(s->voxels), s->slab_ptrs_dev, s->swap_state, s->p.max_w,
-                     set_stats ? s->counters : nullptr);
+// merge the host copies of the listed entries into the map; n_dev: length on the device, else n_host
+static int merge_from_host(dslam_engine *e, dslam_scene *s, const int *ids, const int *n_dev, int n_host, bool set_stats,
+                           bool only_unmerged = false) {
+  hipLaunchKernelGGL(k_swap_merge, dim3(1024), dim3(256), 0, e->stream, ids, s->slot_dev, n_dev, n_host, s->hash,
+                     reinterpret_cast<uint4 *>(s->voxels), s->slab_ptrs_dev, s->swap_state, s->swap1_bits, only_unmerged ? 1 : 0,
+                     s->p.max_w, set_stats ? s->counters : nullptr);
   DSLAM_HIP(hipGetLastError());
   return DSLAM_OK;
 }
 
 // write the listed entries' blocks to the host store and release their voxel blocks (at most `upper` of them)
-static int pack_to_host(dslam_engine *e, dslam_scene *s, unsigned char *vis_type, const MaintScratch &m, const int *n_dev,
+static int pack_to_host(dslam_engine *e, dslam_scene *s, dslam_render_state *r, const int *ids, const int *n_dev,
                         int n_host, int upper, int add_slid, bool set_stats) {
   int rc = ensure_slots(e, s, upper);
   if (rc) return rc;
-  hipLaunchKernelGGL(k_swap_pack, dim3(1024), dim3(256), 0, e->stream, m.cand_list, s->slot_dev, n_dev, n_host, s->hash,
+  hipLaunchKernelGGL(k_swap_pack, dim3(1024), dim3(256), 0, e->stream, ids, s->slot_dev, n_dev, n_host, s->hash,
                      reinterpret_cast<uint4 *>(s->voxels), s->slab_ptrs_dev, s->alloc_list, s->masks,
-                     s->last_seen, s->history_words, s->swap_state, vis_type, s->counters);
+                     s->last_seen, s->history_words, s->swap_state, s->swap1_bits, s->alloc_bits,
+                     r ? r->visible_type : (unsigned char *)nullptr, r ? r->vis_bits : (unsigned *)nullptr, s->counters);
   hipLaunchKernelGGL(k_add_last_free, dim3(1), dim3(64), 0, e->stream, s->counters, n_dev, n_host, add_slid,
                      set_stats ? 1 : 0);
   DSLAM_HIP(hipGetLastError());
@@ -704,7 +696,7 @@ int launch_swap_in(dslam_engine *e, dslam_scene *s, dslam_render_state *) {
   if (rc) return rc;
   const MaintScratch m = carve(e, s->n_entries);
   if ((rc = swap_select<0>(e, s, nullptr, m))) return rc;
-  return merge_from_host(e, s, m, &s->counters->swap_count, 0, true);
+  return merge_from_host(e, s, m.cand_list, &s->counters->swap_count, 0, true);
 }
 
 int launch_swap_out(dslam_engine *e, dslam_scene *s, dslam_render_state *r, bool ignore_visibility) {
@@ -712,7 +704,7 @@ int launch_swap_out(dslam_engine *e, dslam_scene *s, dslam_render_state *r, bool
   if (rc) return rc;
   const MaintScratch m = carve(e, s->n_entries);
   if ((rc = swap_select<2>(e, s, ignore_visibility ? nullptr : r->visible_type, m))) return rc;
-  return pack_to_host(e, s, nullptr, m, &s->counters->swap_count, 0, kTransferBlocks, 0, true);
+  return pack_to_host(e, s, nullptr, m.cand_list, &s->counters->swap_count, 0, kTransferBlocks, 0, true);
 }
 
 // Hansry's SaveToGlobalMemory(scene): merge everything pending, promote never-visible resident blocks, flush all
@@ -724,18 +716,18 @@ int launch_save_to_global(dslam_engine *e, dslam_scene *s) {
   while (true) {
     if ((rc = swap_select_to_host<0>(e, s, nullptr, m, &n))) return rc;
     if (n == 0) break;
-    if ((rc = merge_from_host(e, s, m, nullptr, n, false))) return rc;
+    if ((rc = merge_from_host(e, s, m.cand_list, nullptr, n, false))) return rc;
   }
   while (true) {
     if ((rc = swap_select_to_host<1>(e, s, nullptr, m, &n))) return rc;
     if (n == 0) break;
-    if ((rc = merge_from_host(e, s, m, nullptr, n, false))) return rc;
+    if ((rc = merge_from_host(e, s, m.cand_list, nullptr, n, false))) return rc;
   }
   int total = 0;
   while (true) {
     if ((rc = swap_select_to_host<2>(e, s, nullptr, m, &n))) return rc;
     if (n == 0) break;
-    if ((rc = pack_to_host(e, s, nullptr, m, nullptr, n, n, 0, false))) return rc;
+    if ((rc = pack_to_host(e, s, nullptr, m.cand_list, nullptr, n, n, 0, false))) return rc;
     total += n;
   }
   hipLaunchKernelGGL(k_set_swap_stats, dim3(1), dim3(64), 0, e->stream, s->counters, 0, total);
@@ -746,124 +738,40 @@ int launch_save_to_global(dslam_engine *e, dslam_scene *s) {
 // ---------------------------------------------------------------------------------------------------------------
 // sliding window: pop the oldest list of ring q
 // ---------------------------------------------------------------------------------------------------------------
-// entries flagged for leaving (swapping scene) whose host copy is not merged yet: state != 2
-__global__ __launch_bounds__(256) void k_slide_split(const unsigned char *__restrict__ leave_flags, int n_entries,
-                                                     const unsigned char *__restrict__ swap_state,
-                                                     unsigned char *__restrict__ need_merge_flags,
-                                                     int *__restrict__ tile_counts) {
-  __shared__ int red[4];
-  const int t0 = blockIdx.x * kTileEntries + threadIdx.x * 4;
-  int c = 0;
-  if (t0 < n_entries) {
-    unsigned char f[4];
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-      f[k] = (leave_flags[t0 + k] && swap_state[t0 + k] != 2) ? 1 : 0;
-      c += f[k];
-    }
-    *reinterpret_cast<uchar4 *>(need_merge_flags + t0) = make_uchar4(f[0], f[1], f[2], f[3]);
-  }
-  int tot;
-  block_excl_scan<4>(c, red, tot);
-  if (threadIdx.x == 0) tile_counts[blockIdx.x] = tot;
-}
-
-// compaction of `flags` skipping the first `skip` hits, at most kTransferBlocks outputs (batched host transfers)
-__global__ __launch_bounds__(256) void k_compact_window(const unsigned char *__restrict__ flags, int n_entries,
-                                                        const int *__restrict__ tile_offsets, int *__restrict__ out,
-                                                        int skip, int capacity) {
-  __shared__ int red[4];
-  const int t0 = blockIdx.x * kTileEntries + threadIdx.x * 4;
-  unsigned char f[4] = {0, 0, 0, 0};
-  if (t0 < n_entries) {
-    const uchar4 v = *reinterpret_cast<const uchar4 *>(flags + t0);
-    f[0] = v.x; f[1] = v.y; f[2] = v.z; f[3] = v.w;
-  }
-  const int c = (f[0] > 0) + (f[1] > 0) + (f[2] > 0) + (f[3] > 0);
-  int tot;
-  int r = block_excl_scan<4>(c, red, tot);
-  if (tot == 0) return;
-  r += tile_offsets[blockIdx.x] - skip;
-#pragma unroll
-  for (int k = 0; k < 4; k++)
-    if (f[k] > 0) {
-      if (r >= 0 && r < capacity) out[r] = t0 + k;
-      r++;
-    }
-}
-
-static int flags_to_host_batches(dslam_engine *e, dslam_scene *s, const unsigned char *flags, const MaintScratch &m,
-                                 int *total_out) {
-  const int N = s->n_entries, n_tiles = num_tiles(N);
-  hipLaunchKernelGGL(k_flag_count, dim3(n_tiles), dim3(256), 0, e->stream, flags, N, e->tile_counts);
-  hipLaunchKernelGGL(k_scan_count, dim3(1), dim3(1024), 0, e->stream, e->tile_counts, e->tile_offsets, n_tiles,
-                     &s->counters->swap_count, s->p.num_local_blocks);
-  DSLAM_HIP(hipGetLastError());
-  int *host_count = reinterpret_cast<int *>(e->pinned) + 48;
-  DSLAM_HIP(hipMemcpyAsync(host_count, &s->counters->swap_count, sizeof(int), hipMemcpyDeviceToHost, e->stream));
-  DSLAM_HIP(hipStreamSynchronize(e->stream));
-  *total_out = *host_count;
-  return DSLAM_OK;
-}
-
-// the next batch of the flagged entries (hits skip .. skip + kTransferBlocks) into m.cand_list
-static int batch_ids(dslam_engine *e, dslam_scene *s, const unsigned char *flags, const MaintScratch &m, int skip) {
-  const int N = s->n_entries, n_tiles = num_tiles(N);
-  hipLaunchKernelGGL(k_compact_window, dim3(n_tiles), dim3(256), 0, e->stream, flags, N, e->tile_offsets, m.cand_list, skip,
-                     kTransferBlocks);
-  DSLAM_HIP(hipGetLastError());
-  return DSLAM_OK;
-}
-
 int launch_slide_pop(dslam_engine *e, dslam_scene *s, dslam_render_state *r, int q) {
   DSLAM_REQUIRE(!r || r->n_entries == s->n_entries, "render state was created for a different scene size");
-  const int N = s->n_entries, n_tiles = num_tiles(N);
+  const int N = s->n_entries;
   int rc = ensure_scratch(e, N, s->p.num_local_blocks);
   if (rc) return rc;
   const MaintScratch m = carve(e, N);
   const int bits = 64 * s->history_words;
   const int bit = (s->ring_head[q]++) % bits;
   if (s->decay_cursor[q] < s->ring_head[q]) s->decay_cursor[q] = s->ring_head[q];
-  // leave[t] = 1 for blocks whose rings are empty after clearing this list's bit (the selection writes every entry's
-  // flag).  A scene without swapping releases them: the release pipeline's own flag array (it clears what it consumes);
-  // a scene with swapping parks them on the host and needs the flags for several batches: scratch of its own
-  unsigned char *leave = s->p.use_swapping ? reinterpret_cast<unsigned char *>(e->list_d) : m.rem_flags;
-  hipLaunchKernelGGL(k_select<1>, dim3(n_tiles), dim3(256), 0, e->stream, s->hash, N, s->masks, s->history_words, q, bit,
-                     s->last_seen, 0, leave, e->tile_counts);
-  DSLAM_HIP(hipGetLastError());
+  // the blocks whose rings are empty after clearing this list's bit leave the device, in ascending entry order
   if (!s->p.use_swapping) {
-    hipLaunchKernelGGL(k_compact_apply_fused, dim3(n_tiles), dim3(256), 0, e->stream, leave, N, e->tile_counts, m.rem_list,
-                       s->p.num_local_blocks, &s->counters->remove_count);
+    // released: the list and the release pipeline's removal flags come out of one selection
+    SelSlidePop sel{s->hash, s->masks, s->history_words, q, bit, m.rem_flags};
+    launch_bits_select(e, s->alloc_bits, N, sel, m.rem_list, s->p.num_local_blocks, &s->counters->remove_count, nullptr,
+                       &s->counters->error_flags);
+    DSLAM_HIP(hipGetLastError());
     return release_listed(e, s, r, m, 1);
   }
 
   // scene with swapping: the blocks move to the host store, their entries stay (ptr = -1)
-  int total = 0;
-  // (1) leaving blocks whose host copy was never merged (state != 2): merge it first
-  hipLaunchKernelGGL(k_slide_split, dim3(n_tiles), dim3(256), 0, e->stream, leave, N, s->swap_state, m.cand_flags,
-                     e->tile_counts);
-  hipLaunchKernelGGL(k_scan_count, dim3(1), dim3(1024), 0, e->stream, e->tile_counts, e->tile_offsets, n_tiles,
-                     &s->counters->swap_count, s->p.num_local_blocks);
+  SelSlidePop sel{s->hash, s->masks, s->history_words, q, bit, nullptr};
+  launch_bits_select(e, s->alloc_bits, N, sel, m.cand_list, s->p.num_local_blocks, &s->counters->swap_count, nullptr,
+                     &s->counters->error_flags);
   DSLAM_HIP(hipGetLastError());
   int *host_count = reinterpret_cast<int *>(e->pinned) + 48;
   DSLAM_HIP(hipMemcpyAsync(host_count, &s->counters->swap_count, sizeof(int), hipMemcpyDeviceToHost, e->stream));
-  DSLAM_HIP(hipStreamSynchronize(e->stream));
-  total = *host_count;
-  for (int done = 0; done < total; done += kTransferBlocks) {
-    const int n = (total - done) < kTransferBlocks ? (total - done) : kTransferBlocks;
-    // tile_offsets still hold the scan of the need-merge flags
-    if ((rc = batch_ids(e, s, m.cand_flags, m, done))) return rc;
-    if ((rc = merge_from_host(e, s, m, nullptr, n, false))) return rc;
-    // tile scan of cand_flags is unchanged by the merge; keep going
-  }
-  // (2) pack every leaving block to the host in batches
-  if ((rc = flags_to_host_batches(e, s, leave, m, &total))) return rc;
-  for (int done = 0; done < total; done += kTransferBlocks) {
-    const int n = (total - done) < kTransferBlocks ? (total - done) : kTransferBlocks;
-    if ((rc = batch_ids(e, s, leave, m, done))) return rc;
-    if ((rc = pack_to_host(e, s, r ? r->visible_type : nullptr, m, nullptr, n, n, 1, false))) return rc;
-  }
-  if (r && total > 0) return rebuild_visible_list(e, r);
+  DSLAM_HIP(hipStreamSynchronize(e->stream));   // (the host store must have slabs for every leaving block)
+  const int total = *host_count;
+  if (total == 0) return DSLAM_OK;
+  // (1) leaving blocks whose host copy was never merged (state != 2): merge it first; (2) pack every leaving block.  The
+  // kernels reach the page-locked store directly, so neither step needs upstream's transfer-sized batches.
+  if ((rc = merge_from_host(e, s, m.cand_list, nullptr, total, false, true))) return rc;
+  if ((rc = pack_to_host(e, s, r, m.cand_list, nullptr, total, total, 1, false))) return rc;
+  if (r) return rebuild_visible_list(e, r);
   return DSLAM_OK;
 }
 

@@ -4,7 +4,7 @@
 // Upstream's CPU engine walks the hash table in entry order, each block in z, y, x order, and appends each cube's
 // triangles in table order; its CUDA engine appends with one atomicAdd per triangle, so its output order changes
 // from run to run.  Here the order is the CPU engine's, reproduced without atomics:
-//   live list   ordered compaction of the entries with ptr >= 0                (count -> scan -> apply over tiles)
+//   live list   the entries with ptr >= 0, ascending: one ordered selection over the scene's alloc_bits
 //   count       one 512-thread workgroup per live block, one voxel per thread: cube case -> triangles per block
 //   scan        exclusive scan of the per-block counts (one workgroup)
 //   emit        same cube evaluation; an in-workgroup scan in voxel order gives every triangle its final slot
@@ -15,8 +15,7 @@
 // path -- no roofline claim.
 #include <hip/hip_runtime.h>
 
-#include "dslam_device.h"
-#include "dslam_internal.h"
+#include "dslam_bits.h"
 #include "mc_tables.h"
 
 #pragma clang fp contract(off)
@@ -41,22 +40,13 @@ struct MeshParams {
   int limit;               // triangles with rank >= limit are dropped (upstream: noMaxTriangles - 1)
 };
 
-// tile pass of the live-list compaction: flag = (ptr >= 0), per-tile count
-__global__ __launch_bounds__(256) void k_mesh_flag_live(const HashEntry *__restrict__ hash, int n_entries,
-                                                        unsigned char *__restrict__ flags, int *__restrict__ tile_counts) {
-  __shared__ int red[4];
-  const int t0 = blockIdx.x * kTileEntries + threadIdx.x * 4;
-  int c = 0;
-  uchar4 f = make_uchar4(0, 0, 0, 0);
-  if (t0 < n_entries) {  // n_entries is a multiple of 4 (pool sizes are)
-    f.x = hash[t0].ptr >= 0; f.y = hash[t0 + 1].ptr >= 0; f.z = hash[t0 + 2].ptr >= 0; f.w = hash[t0 + 3].ptr >= 0;
-    c = f.x + f.y + f.z + f.w;
-    *reinterpret_cast<uchar4 *>(flags + t0) = f;
-  }
-  int tot;
-  block_excl_scan<4>(c, red, tot);
-  if (threadIdx.x == 0) tile_counts[blockIdx.x] = tot;
-}
+// the live list: every entry with a resident block, ascending -- the scene's alloc_bits as a list (dslam_bits.h)
+struct SelLive {
+  const HashEntry *hash;
+  __device__ bool test(int t) const { return hash[t].ptr >= 0; }
+  __device__ void emit(int, int, bool) const {}
+  __device__ void finish(int) const {}
+};
 
 // findVoxel's block search: walk the bucket's chain for a resident block at (bx, by, bz); -1 when there is none
 __device__ __forceinline__ int find_block_ptr(const HashEntry *hash, int num_buckets, unsigned mask, int bx, int by, int bz) {
@@ -202,14 +192,11 @@ int launch_mesh_scene(dslam_engine *e, const dslam_scene *s, int max_triangles, 
     DSLAM_HIP(hipMemcpyToSymbol(HIP_SYMBOL(d_mc_triangles), kMcTriangles, sizeof(kMcTriangles)));
     e->mesh_table_ready = true;
   }
-  const int N = s->n_entries, n_tiles = num_tiles(N);
+  const int N = s->n_entries;
   int rc = ensure_scratch(e, N, s->p.num_local_blocks);
   if (rc) return rc;
-  unsigned char *flags = reinterpret_cast<unsigned char *>(e->list_d);  // >= N bytes
   int *live_count = e->misc_counter + 8, *total = e->misc_counter + 9;
-  hipLaunchKernelGGL(k_mesh_flag_live, dim3(n_tiles), dim3(256), 0, e->stream, s->hash, N, flags, e->tile_counts);
-  hipLaunchKernelGGL(k_scan_count, dim3(1), dim3(1024), 0, e->stream, e->tile_counts, e->tile_offsets, n_tiles, live_count, N);
-  hipLaunchKernelGGL(k_compact_apply, dim3(n_tiles), dim3(256), 0, e->stream, flags, N, e->tile_offsets, e->list_a, N);
+  launch_bits_select(e, s->alloc_bits, N, SelLive{s->hash}, e->list_a, N, live_count, nullptr, nullptr);
   MeshParams p;
   p.hash = s->hash; p.voxels = s->voxels; p.num_buckets = s->p.num_buckets; p.mask = (unsigned)(s->p.num_buckets - 1);
   p.live_list = e->list_a; p.live_count = live_count; p.block_counts = e->list_b; p.block_offsets = e->list_c;

@@ -11,7 +11,7 @@
 #include <cstdio>
 #include <cstdlib>
 
-#include "dslam_internal.h"
+#include "dslam_bits.h"
 
 #pragma clang fp contract(off)
 
@@ -20,62 +20,17 @@ namespace dslam {
 // ---------------------------------------------------------------------------------------------------------
 // FindVisibleBlocks: ordered compaction of entries with ptr >= 0 that pass the 8-corner frustum test
 // ---------------------------------------------------------------------------------------------------------
+// ONE launch over the scene's alloc_bits (round 2: a frustum-flag sweep over all 1.18 M entries and a compaction sweep
+// over the flags): lane = one bitmap word = 32 entries, tile = 256 words, taken by ticket; only entries that hold a
+// block are read and tested; ranks = popcounts + block scan + one in-launch look-back.  PROJECT: the lane that lists
+// visible entry number r also projects it (CreateExpectedDepths' ProjectSingleBlock; GetImage runs both with one pose),
+// the launch resets the range image, and every tile leaves its render-tile total for k_fill_range_tiles.
 struct FrustumParams {
   Mat4 M;
   float fx, fy, cx, cy, voxel_size;
   int W, H;
 };
-
-__global__ __launch_bounds__(256) void k_frustum_flags(const HashEntry *__restrict__ hash, int n_entries,
-                                                       FrustumParams p, unsigned char *__restrict__ flags,
-                                                       int *__restrict__ tile_counts) {
-  __shared__ int red[4];
-  __shared__ TileVisScratch vis_scratch;
-  // entry k of a lane is tile_base + k * 256 + lane: each of the four loads of a wavefront covers one contiguous KiB
-  // (only the tile's total is needed here, so the order in which lanes see entries is free)
-  const int tile_base = blockIdx.x * kTileEntries;
-  bool cand[4] = {false, false, false, false};
-  short4 pos[4];
-#pragma unroll
-  for (int k = 0; k < 4; k++) {
-    const int t = tile_base + k * 256 + threadIdx.x;
-    if (t < n_entries) {
-      const HashEntry e = load_entry(hash, t);
-      cand[k] = e.ptr >= 0;
-      pos[k] = make_short4(e.pos[0], e.pos[1], e.pos[2], 0);
-    }
-  }
-  unsigned char f[4];
-  tile_block_vis<false>(vis_scratch, cand, pos, p.M, p.fx, p.fy, p.cx, p.cy, p.voxel_size, p.W, p.H, f);
-  int c = 0;
-#pragma unroll
-  for (int k = 0; k < 4; k++) {
-    const int t = tile_base + k * 256 + threadIdx.x;
-    if (t < n_entries) { f[k] &= 1; c += f[k]; flags[t] = f[k]; }
-  }
-  int tot;
-  block_excl_scan<4>(c, red, tot);
-  if (threadIdx.x == 0) tile_counts[blockIdx.x] = tot;
-}
-
-int launch_find_visible(dslam_engine *e, const dslam_scene *s, dslam_render_state *r, const float *M,
-                        const float *intr) {
-  const int N = s->n_entries;
-  DSLAM_REQUIRE(r->n_entries == N, "render state was created for a different scene size");
-  int rc = ensure_scratch(e, N, s->p.num_local_blocks);
-  if (rc) return rc;
-  FrustumParams fp;
-  memcpy(fp.M.m, M, 64);
-  fp.fx = intr[0]; fp.fy = intr[1]; fp.cx = intr[2]; fp.cy = intr[3]; fp.voxel_size = s->p.voxel_size;
-  fp.W = r->w; fp.H = r->h;
-  const int n_tiles = num_tiles(N);
-  unsigned char *flags = reinterpret_cast<unsigned char *>(e->list_c);  // byte flags, N <= sizeof(list_c)
-  hipLaunchKernelGGL(k_frustum_flags, dim3(n_tiles), dim3(256), 0, e->stream, s->hash, N, fp, flags, e->tile_counts);
-  hipLaunchKernelGGL(k_compact_apply_fused, dim3(n_tiles), dim3(256), 0, e->stream, flags, N, e->tile_counts,
-                     r->visible_ids, r->n_local, &r->counters->no_visible);
-  DSLAM_HIP(hipGetLastError());
-  return DSLAM_OK;
-}
+constexpr int kFindTileWords = 256;
 
 // ---------------------------------------------------------------------------------------------------------
 // CountVisibleBlocks
@@ -153,6 +108,99 @@ __device__ __forceinline__ int project_single_block(const HashEntry &e, const Pr
   return rx * ry;
 }
 
+template <bool PROJECT>
+__global__ __launch_bounds__(256) void k_find_visible(const unsigned *__restrict__ alloc_bits, TileChain ch,
+                                                      const HashEntry *__restrict__ hash, FrustumParams fp, int *__restrict__ ids,
+                                                      int capacity, RenderCounters *rc, int4 *__restrict__ boxes,
+                                                      float2 *__restrict__ zr_out, int *req_out, float2 *range, int npix,
+                                                      int *wg_tiles) {
+  __shared__ int red[4];
+  __shared__ int s_ticket;
+  if (PROJECT)   // (independent job) reset the range image to (FAR_AWAY, VERY_CLOSE)
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < npix; i += gridDim.x * 256) range[i] = make_float2(kFarAway, kVeryClose);
+  ProjParams pp;
+  pp.M = fp.M; pp.fx = fp.fx; pp.fy = fp.fy; pp.cx = fp.cx; pp.cy = fp.cy; pp.voxel_size = fp.voxel_size; pp.W = fp.W; pp.H = fp.H;
+  const int b = take_ticket(ch.ticket, ch.ticket_base, &s_ticket);   // (one tile per workgroup)
+  if (b >= ch.n_tiles) return;
+  {
+    const int w = b * kFindTileWords + threadIdx.x;
+    unsigned pick = 0;
+    for (unsigned m = alloc_bits[w]; m; m &= m - 1) {
+      const int bit = __ffs((int)m) - 1;
+      const HashEntry e = load_entry(hash, w * 32 + bit);
+      if (e.ptr < 0) continue;
+      bool vis, vis_enl;
+      check_block_vis<false>(vis, vis_enl, e.pos[0], e.pos[1], e.pos[2], fp.M, fp.fx, fp.fy, fp.cx, fp.cy, fp.voxel_size, fp.W, fp.H);
+      if (vis) pick |= 1u << bit;
+    }
+    int tot;
+    int r = block_excl_scan<4>(__popc(pick), red, tot);
+    if (threadIdx.x == 0) publish1(ch.agg, b, ch.epoch, tot);
+    const bool last = b == ch.n_tiles - 1;
+    if (tot == 0 && !last) {
+      if (PROJECT && threadIdx.x == 0) wg_tiles[b] = 0;
+      return;
+    }
+    int before;
+    if (!lookback1(ch.agg, b, ch.epoch, red, before)) { /* (cannot happen while the device makes progress) */ }
+    if (last && threadIdx.x == 0) rc->no_visible = (before + tot) < capacity ? (before + tot) : capacity;
+    r += before;
+    int local_tiles = 0;
+    for (unsigned m = pick; m; m &= m - 1) {
+      const int t = w * 32 + __ffs((int)m) - 1;
+      if (r < capacity) {
+        ids[r] = t;
+        if (PROJECT) {
+          const HashEntry e = load_entry(hash, t);
+          int4 box;
+          float2 zr;
+          const int req = project_single_block(e, pp, box, zr);
+          if (req) { boxes[r] = box; zr_out[r] = zr; }
+          req_out[r] = req;
+          local_tiles += req;
+        }
+      }
+      r++;
+    }
+    if (PROJECT) {
+      // per-tile totals instead of one contended global counter; the range-image kernel sums them
+      for (int d = 32; d > 0; d >>= 1) local_tiles += __shfl_xor(local_tiles, d, 64);
+      if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = local_tiles;
+      __syncthreads();
+      if (threadIdx.x == 0) wg_tiles[b] = red[0] + red[1] + red[2] + red[3];
+      __syncthreads();
+    }
+  }
+}
+
+static FrustumParams make_frustum_params(const dslam_scene *s, const dslam_render_state *r, const float *M, const float *intr) {
+  FrustumParams fp;
+  memcpy(fp.M.m, M, 64);
+  fp.fx = intr[0]; fp.fy = intr[1]; fp.cx = intr[2]; fp.cy = intr[3]; fp.voxel_size = s->p.voxel_size;
+  fp.W = r->w; fp.H = r->h;
+  return fp;
+}
+
+// the chain of a k_find_visible launch: tiles of kFindTileWords words
+static TileChain find_chain(dslam_engine *e, int n_entries, int *grid_out) {
+  return next_chain(e, bit_tiles(n_entries) * (kBitTileWords / kFindTileWords), grid_out);
+}
+
+int launch_find_visible(dslam_engine *e, const dslam_scene *s, dslam_render_state *r, const float *M,
+                        const float *intr) {
+  const int N = s->n_entries;
+  DSLAM_REQUIRE(r->n_entries == N, "render state was created for a different scene size");
+  int rc = ensure_scratch(e, N, s->p.num_local_blocks);
+  if (rc) return rc;
+  int grid;
+  const TileChain ch = find_chain(e, N, &grid);
+  hipLaunchKernelGGL(k_find_visible<false>, dim3(grid), dim3(256), 0, e->stream, s->alloc_bits, ch, s->hash,
+                     make_frustum_params(s, r, M, intr), r->visible_ids, r->n_local, r->counters, (int4 *)nullptr, (float2 *)nullptr,
+                     (int *)nullptr, (float2 *)nullptr, 0, (int *)nullptr);
+  DSLAM_HIP(hipGetLastError());
+  return DSLAM_OK;
+}
+
 // ProjectSingleBlock for every visible block; records bbox / z-range / required render tiles
 __global__ __launch_bounds__(256) void k_project_blocks(const int *__restrict__ ids, RenderCounters *rc,
                                                         const HashEntry *__restrict__ hash, ProjParams p,
@@ -179,65 +227,6 @@ __global__ __launch_bounds__(256) void k_project_blocks(const int *__restrict__ 
   if ((threadIdx.x & 63) == 0 && local_tiles) atomicAdd(&s_tiles, local_tiles);
   __syncthreads();
   // per-workgroup totals instead of one contended global counter; the range-image kernel sums them
-  if (threadIdx.x == 0) wg_tiles[blockIdx.x] = s_tiles;
-}
-
-// FindVisibleBlocks' ordered compaction and CreateExpectedDepths' projection in one pass (GetImage runs them back
-// to back with the same pose): the lane that emits visible entry number r also projects it.  The handful of
-// visible entries of a tile are first gathered in LDS so that the projection runs once, densely.
-__global__ __launch_bounds__(256) void k_compact_project(const unsigned char *__restrict__ flags, int n_entries,
-                                                         const int *__restrict__ tile_counts, int *__restrict__ ids,
-                                                         int capacity, RenderCounters *rc,
-                                                         const HashEntry *__restrict__ hash, ProjParams p,
-                                                         int4 *__restrict__ boxes, float2 *__restrict__ zr_out,
-                                                         int *req_out, float2 *range, int npix, int *wg_tiles) {
-  __shared__ int red[4];
-  __shared__ int s_tiles;
-  __shared__ int s_entry[kTileEntries];
-  if (threadIdx.x == 0) s_tiles = 0;
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < npix; i += gridDim.x * blockDim.x)
-    range[i] = make_float2(kFarAway, kVeryClose);
-  const int t0 = blockIdx.x * kTileEntries + threadIdx.x * 4;
-  unsigned char f[4] = {0, 0, 0, 0};
-  if (t0 < n_entries) {
-    const uchar4 v = *reinterpret_cast<const uchar4 *>(flags + t0);
-    f[0] = v.x; f[1] = v.y; f[2] = v.z; f[3] = v.w;
-  }
-  const int c = (f[0] > 0) + (f[1] > 0) + (f[2] > 0) + (f[3] > 0);
-  // (the loads of the preceding tiles' counts are in flight while the scan runs its barriers)
-  const int offset_part = partial_sum_strided(tile_counts, blockIdx.x, 1);
-  int tot;
-  int r = block_excl_scan<4>(c, red, tot);
-  const bool last = blockIdx.x == gridDim.x - 1;
-  if (tot == 0 && !last) {
-    if (threadIdx.x == 0) wg_tiles[blockIdx.x] = 0;
-    return;
-  }
-  {
-    const int offset = reduce_sum(offset_part, red);
-    if (last && threadIdx.x == 0) rc->no_visible = (offset + tot) < capacity ? (offset + tot) : capacity;
-#pragma unroll
-    for (int k = 0; k < 4; k++)
-      if (f[k] > 0) s_entry[r++] = t0 + k;
-    __syncthreads();
-    int local_tiles = 0;
-    for (int j = threadIdx.x; j < tot; j += blockDim.x) {
-      const int i = offset + j;
-      if (i >= capacity) break;
-      const int id = s_entry[j];
-      ids[i] = id;
-      const HashEntry e = load_entry(hash, id);
-      int4 box;
-      float2 zr;
-      const int req = project_single_block(e, p, box, zr);
-      if (req) { boxes[i] = box; zr_out[i] = zr; }
-      req_out[i] = req;
-      local_tiles += req;
-    }
-    for (int d = 32; d > 0; d >>= 1) local_tiles += __shfl_down(local_tiles, d, 64);
-    if ((threadIdx.x & 63) == 0 && local_tiles) atomicAdd(&s_tiles, local_tiles);
-  }
-  __syncthreads();
   if (threadIdx.x == 0) wg_tiles[blockIdx.x] = s_tiles;
 }
 
@@ -369,29 +358,20 @@ int launch_expected_depths(dslam_engine *e, const dslam_scene *s, dslam_render_s
   return launch_fill_range(e, r, kProjectGrid);
 }
 
-// FindVisibleBlocks + CreateExpectedDepths for the same pose (ITMMainEngine::GetImage's FREECAMERA path): three
-// launches instead of five.  (A single-launch form -- frustum test, single-pass ordered compaction with in-launch
-// look-back as in the allocation sweep, and projection, 4096-entry tiles -- measured 17.3 us against 8.8 + 7.2 us for
-// these two kernels on the 1.18 M-entry table with 113 k allocated entries: the table read is bandwidth work that wants
-// the 1152 small workgroups, the look-back wants few fat ones; profiles/r02_launch_collapse.md.)
+// FindVisibleBlocks + CreateExpectedDepths for the same pose (ITMMainEngine::GetImage's FREECAMERA path): two launches
+// (round 1: five; round 2: three, two of them sweeps over the whole table).
 int launch_find_visible_and_depths(dslam_engine *e, const dslam_scene *s, dslam_render_state *r, const float *M,
                                    const float *intr) {
   const int N = s->n_entries;
   DSLAM_REQUIRE(r->n_entries == N, "render state was created for a different scene size");
   int rc = ensure_scratch(e, N, s->p.num_local_blocks);
   if (rc) return rc;
-  FrustumParams fp;
-  memcpy(fp.M.m, M, 64);
-  fp.fx = intr[0]; fp.fy = intr[1]; fp.cx = intr[2]; fp.cy = intr[3]; fp.voxel_size = s->p.voxel_size;
-  fp.W = r->w; fp.H = r->h;
-  const int n_tiles = num_tiles(N);
-  unsigned char *flags = reinterpret_cast<unsigned char *>(e->list_c);
-  hipLaunchKernelGGL(k_frustum_flags, dim3(n_tiles), dim3(256), 0, e->stream, s->hash, N, fp, flags, e->tile_counts);
-  const ProjParams pp = make_proj_params(s, r, M, intr);
-  hipLaunchKernelGGL(k_compact_project, dim3(n_tiles), dim3(256), 0, e->stream, flags, N, e->tile_counts, r->visible_ids,
-                     r->n_local, r->counters, s->hash, pp, r->proj_boxes, r->proj_z, r->proj_req, r->range, r->w * r->h,
-                     r->proj_wg_tiles);
-  return launch_fill_range(e, r, n_tiles);
+  int grid;
+  const TileChain ch = find_chain(e, N, &grid);
+  hipLaunchKernelGGL(k_find_visible<true>, dim3(grid), dim3(256), 0, e->stream, s->alloc_bits, ch, s->hash,
+                     make_frustum_params(s, r, M, intr), r->visible_ids, r->n_local, r->counters, r->proj_boxes, r->proj_z,
+                     r->proj_req, r->range, r->w * r->h, r->proj_wg_tiles);
+  return launch_fill_range(e, r, ch.n_tiles);
 }
 
 // ---------------------------------------------------------------------------------------------------------
