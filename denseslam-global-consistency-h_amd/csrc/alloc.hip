@@ -18,7 +18,7 @@
 #include <cstdio>
 #include <cstdlib>
 
-#include "dslam_internal.h"
+#include "dslam_bits.h"
 
 #pragma clang fp contract(off)
 
@@ -197,33 +197,50 @@ __device__ __forceinline__ int ray_segment(float d, int x, int y, const Mat4 &in
   return no_steps;
 }
 
-// The re-test job of k_mark: lane = one word of the render state's visible bits.  An entry whose type byte carries the
-// OTHER generation bit was visible in the previous pass (upstream re-arms it as 3 and tests it against the frustum); a
-// byte with THIS pass' bit is visible whatever the test says (marked by a pixel of this launch, or a 1 / 2 that did not
-// fit into the previous list and counts as marked again, see k_alloc_sweep).  The job only reads types: the bytes
-// belong to the pixel lanes of this launch; the sweep writes the 3s.
+// The re-test job of k_mark: workgroup = 256 words of the render state's visible bits (8192 entries).  An entry whose
+// type byte carries the OTHER generation bit was visible in the previous pass (upstream re-arms it as 3 and tests it
+// against the frustum); a byte with THIS pass' bit is visible whatever the test says (marked by a pixel of this launch, or
+// a 1 / 2 that did not fit into the previous list and counts as marked again, see k_alloc_sweep).  The job only reads
+// types: the bytes belong to the pixel lanes of this launch; the sweep writes the 3s.
+// The set bits are expanded into an LDS list and tested one per lane and round: visible entries of the excess area sit
+// in a few full words (excess slots are handed out contiguously), and a lane walking its own word would test 32 of them
+// one after the other while its neighbours idle.
 __device__ __forceinline__ void retest_job(const MarkParams &p) {
-  const int w = blockIdx.x * 256 + threadIdx.x;
+  __shared__ int red[4];
+  __shared__ unsigned short s_list[8192];
+  __shared__ unsigned s_res[256];
+  const int w = blockIdx.x * 256 + threadIdx.x;   // (the job's workgroups cover the whole tiles of the bitmap)
   if (w == 0) {  // the pool tops as they are before this pass' commits (the sweep's last tile moves them)
     p.cnt->base_free = p.cnt->last_free;
     p.cnt->base_free_ex = p.cnt->last_free_ex;
   }
-  if (w >= p.n_words) return;
   for (unsigned m = p.old_q1[w] | p.old_q2[w]; m; m &= m - 1) p.alloc_type[w * 32 + __ffs((int)m) - 1] = 0;
-  unsigned out = 0;
-  for (unsigned m = p.vis_bits[w]; m; m &= m - 1) {
-    const int bit = __ffs((int)m) - 1;
-    const int t = w * 32 + bit;
+  const unsigned bits = p.vis_bits[w];
+  s_res[threadIdx.x] = 0;
+  int tot;
+  const int rank = block_excl_scan<4>(__popc(bits), red, tot);
+  expand_bits(bits, threadIdx.x * 32, rank, s_list);
+  __syncthreads();
+  const int t0 = blockIdx.x * 8192;
+  for (int j = threadIdx.x; j < tot; j += 256) {
+    const int rel = s_list[j], t = t0 + rel;
     const unsigned char ty = p.vis_type[t];
-    if (ty == 0) continue;
-    if ((ty & 0x80u) == p.gen) { out |= 1u << bit; continue; }
-    const HashEntry e = load_entry(p.hash, t);
-    bool vis, vis_enl;
-    if (p.swapping) check_block_vis<true>(vis, vis_enl, e.pos[0], e.pos[1], e.pos[2], p.M, p.fx, p.fy, p.cx, p.cy, p.voxel_size, p.W, p.H);
-    else check_block_vis<false>(vis, vis_enl, e.pos[0], e.pos[1], e.pos[2], p.M, p.fx, p.fy, p.cx, p.cy, p.voxel_size, p.W, p.H);
-    if (p.swapping ? vis_enl : vis) out |= 1u << bit;
+    bool keep = false;
+    if (ty != 0) {
+      if ((ty & 0x80u) == p.gen) {
+        keep = true;
+      } else {
+        const HashEntry e = load_entry(p.hash, t);
+        bool vis, vis_enl;
+        if (p.swapping) check_block_vis<true>(vis, vis_enl, e.pos[0], e.pos[1], e.pos[2], p.M, p.fx, p.fy, p.cx, p.cy, p.voxel_size, p.W, p.H);
+        else check_block_vis<false>(vis, vis_enl, e.pos[0], e.pos[1], e.pos[2], p.M, p.fx, p.fy, p.cx, p.cy, p.voxel_size, p.W, p.H);
+        keep = p.swapping ? vis_enl : vis;
+      }
+    }
+    if (keep) atomicOr(&s_res[rel >> 5], 1u << (rel & 31));
   }
-  p.retest[w] = out;
+  __syncthreads();
+  p.retest[w] = s_res[threadIdx.x];
 }
 
 __global__ __launch_bounds__(256) void k_mark(MarkParams p) {
@@ -300,15 +317,17 @@ __global__ __launch_bounds__(256) void k_mark(MarkParams p) {
       if (found) found_h = h;
       pt.x += dir.x; pt.y += dir.y; pt.z += dir.z;
     }
-    // the found entry's bit in `mark`: neighbouring pixels find the same entry (a block covers hundreds of pixels), so
-    // a lane whose left neighbour found the same one leaves it to that lane, and nobody sets a bit that is already there
-    // (a stale read only costs a redundant atomic)
+    // A found entry that the render state did NOT hold visible before the pass gets a bit in `mark` (the sweep learns of
+    // the others from vis_bits + their type bytes).  Only those: global atomics are dear on this part -- a bit for every
+    // found entry made this kernel 48 us instead of 11 (137 us with a "bit already set?" load in front, which reads a line
+    // the atomics keep taking away), and entries entering the view are a few hundred per frame.  vis_bits does not change
+    // during this launch, so the test in front of the atomic is an ordinary cached load.  Neighbouring pixels find the
+    // same entry: a lane whose left neighbour found it too leaves the bit to that lane.
     {
       const int left = __shfl_up(found_h, 1, 64);
       if (found_h >= 0 && !(lane > 0 && left == found_h)) {
         const unsigned bit = 1u << (found_h & 31);
-        unsigned *word = &p.mark[found_h >> 5];
-        if (!(__builtin_nontemporal_load(word) & bit)) atomicOr(word, bit);
+        if (!(p.vis_bits[found_h >> 5] & bit)) atomicOr(&p.mark[found_h >> 5], bit);
       }
     }
     const unsigned key = (unsigned)idx * (unsigned)p.step_cap + (unsigned)i + 1u;
@@ -411,6 +430,9 @@ __global__ __launch_bounds__(256) void k_alloc_sweep(SweepParams p) {
   __shared__ int red[16];
   __shared__ int s_ticket;
   __shared__ unsigned s_newx[kBitTileWords];   // entries other tiles' commits create in this tile (excess area)
+  __shared__ unsigned s_mk[kBitTileWords], s_qx[kBitTileWords];   // the tile's mark bits / entries this pass made visible
+  constexpr int kEmitWindow = 8192;
+  __shared__ unsigned short s_list[kEmitWindow];
   // (snapshot taken by k_mark)
   const int base_free = __builtin_amdgcn_readfirstlane(p.cnt->base_free), base_free_ex = __builtin_amdgcn_readfirstlane(p.cnt->base_free_ex);
   const int avail_vba = base_free + 1, avail_ex = base_free_ex + 1;
@@ -421,7 +443,43 @@ __global__ __launch_bounds__(256) void k_alloc_sweep(SweepParams p) {
     const uint4 q1 = *reinterpret_cast<const uint4 *>(p.q1 + w0), q2 = *reinterpret_cast<const uint4 *>(p.q2 + w0);
     const uint4 mk = *reinterpret_cast<const uint4 *>(p.mark + w0), rt = *reinterpret_cast<const uint4 *>(p.retest + w0);
     const uint4 pold = *reinterpret_cast<const uint4 *>(p.vis_bits + w0);
-    const uint4 seen = or4v(rt, mk);
+    const int tile_first = b * kBitTileEntries;
+    // `mark` only holds found entries that were not visible before (see k_mark); one that was is known by its type byte,
+    // which carries this pass' generation bit.  The re-test job has accepted every such byte it saw -- but it ran while
+    // the pixels were still marking, and an entry that fails the block frustum test can be marked all the same (a block
+    // that cuts a corner of the image without one of its own corners inside).  So the bytes of the entries the job turned
+    // down are looked at once more, now that the marking is over; dense, through the LDS list, because those entries
+    // cluster like the visible ones do.  Usually there are none to a few dozen per tile.
+    uint4 late = make_uint4(0, 0, 0, 0);
+    {
+      const uint4 cand = andn4v(pold, rt);
+      *reinterpret_cast<uint4 *>(&s_qx[threadIdx.x * 4]) = make_uint4(0, 0, 0, 0);
+      int ctot;
+      const int crank = block_excl_scan<4>(popc4(cand), red, ctot);
+      if (ctot > 0) {
+        for (int win = 0; win < ctot; win += kEmitWindow) {
+          __syncthreads();
+          int r = crank - win;
+#pragma unroll 1
+          for (int i = 0; i < 4; i++)
+            for (unsigned m = sel4(cand, i); m; m &= m - 1) {
+              if (r >= 0 && r < kEmitWindow) s_list[r] = (unsigned short)((threadIdx.x * 4 + i) * 32 + __ffs((int)m) - 1);
+              r++;
+            }
+          __syncthreads();
+          const int n_win = (ctot - win) < kEmitWindow ? (ctot - win) : kEmitWindow;
+          for (int j = threadIdx.x; j < n_win; j += 256) {
+            const int rel = s_list[j];
+            const unsigned char ty = p.vis_type[tile_first + rel];
+            if (ty != 0 && (ty & 0x80u) == p.gen) atomicOr(&s_qx[rel >> 5], 1u << (rel & 31));
+          }
+        }
+        __syncthreads();
+        late = *reinterpret_cast<const uint4 *>(&s_qx[threadIdx.x * 4]);
+        __syncthreads();   // (s_qx is used again further down)
+      }
+    }
+    const uint4 seen = or4v(or4v(rt, mk), late);
     // ---- counts out first: nothing a tile publishes depends on another tile -------------------------------------------
     const int c1 = popc4(q1), c2 = popc4(q2);
     int r1, r2, tot1, tot2;
@@ -439,7 +497,6 @@ __global__ __launch_bounds__(256) void k_alloc_sweep(SweepParams p) {
       *reinterpret_cast<uint4 *>(p.oq2 + w0) = z;
       *reinterpret_cast<uint4 *>(p.omark + w0) = z;
     }
-    const int tile_first = b * kBitTileEntries;
     const bool last = b == p.n_tiles - 1;
     const bool has_excess = tile_first + kBitTileEntries > p.num_buckets || last;   // other tiles' commits may create entries here
     s_newx[threadIdx.x * 4] = 0; s_newx[threadIdx.x * 4 + 1] = 0; s_newx[threadIdx.x * 4 + 2] = 0; s_newx[threadIdx.x * 4 + 3] = 0;
@@ -541,23 +598,39 @@ __global__ __launch_bounds__(256) void k_alloc_sweep(SweepParams p) {
     // ---- the visible list -----------------------------------------------------------------------------------------------
     const uint4 vis = or4v(or4v(andn4v(seen, qfail), qvis), newx);
     int vis_tot;
-    int r = block_excl_scan<4>(popc4(vis), red, vis_tot);   // (its barriers also order the request lanes' type bytes)
+    const int vis_rank = block_excl_scan<4>(popc4(vis), red, vis_tot);   // (its barriers also order the request lanes' type bytes)
     const int vis_first = seen_before + vq_before + newx_before;
-    r += vis_first;
+    // entries that are no longer visible (stores only: nothing to wait for)
 #pragma unroll 1
-    for (int i = 0; i < 4; i++) {
-      const unsigned v = sel4(vis, i), m_mk = sel4(mk, i), m_q = sel4(qvis, i), m_x = sel4(newx, i);
-      const int t_base = (w0 + i) * 32;
-      for (unsigned m = sel4(pold, i) & ~v; m; m &= m - 1) p.vis_type[t_base + __ffs((int)m) - 1] = 0;   // no longer visible
-      for (unsigned m = v; m; m &= m - 1) {
-        const int bit = __ffs((int)m) - 1;
-        const int t = t_base + bit;
-        const bool in_mk = (m_mk >> bit) & 1u, in_q = (m_q >> bit) & 1u, in_x = (m_x >> bit) & 1u;
+    for (int i = 0; i < 4; i++)
+      for (unsigned m = sel4(pold, i) & ~sel4(vis, i); m; m &= m - 1) p.vis_type[(w0 + i) * 32 + __ffs((int)m) - 1] = 0;
+    // The visible entries are written densely: expanded into an LDS list (a window of kEmitWindow ranks at a time), then
+    // one entry per lane and round -- coalesced list stores, and the visible entries of the excess area, which fill a few
+    // words completely (excess slots are handed out contiguously), do not queue up behind a single lane.
+    *reinterpret_cast<uint4 *>(&s_mk[threadIdx.x * 4]) = mk;
+    *reinterpret_cast<uint4 *>(&s_qx[threadIdx.x * 4]) = or4v(qvis, newx);   // (the pass made these visible itself: type 1)
+    for (int win = 0; win < vis_tot; win += kEmitWindow) {
+      __syncthreads();   // (s_mk / s_qx written; the previous window read)
+      {
+        int r = vis_rank - win;
+#pragma unroll 1
+        for (int i = 0; i < 4; i++)
+          for (unsigned m = sel4(vis, i); m; m &= m - 1) {
+            if (r >= 0 && r < kEmitWindow) s_list[r] = (unsigned short)((threadIdx.x * 4 + i) * 32 + __ffs((int)m) - 1);
+            r++;
+          }
+      }
+      __syncthreads();
+      const int n_win = (vis_tot - win) < kEmitWindow ? (vis_tot - win) : kEmitWindow;
+      for (int j = threadIdx.x; j < n_win; j += 256) {
+        const int rel = s_list[j], t = tile_first + rel, r = vis_first + win + j;
+        const bool in_mk = (s_mk[rel >> 5] >> (rel & 31)) & 1u, in_qx = (s_qx[rel >> 5] >> (rel & 31)) & 1u;
+        const bool in_x = has_excess && ((s_newx[rel >> 5] >> (rel & 31)) & 1u);
         if (r < p.capacity) {
           p.visible_ids[r] = t;
           if (in_x) {
-            p.vis_type[t] = (unsigned char)(p.gen | 1u);
-          } else if (!in_mk && !in_q) {
+            p.vis_type[t] = (unsigned char)(p.gen | 1u);   // (an entry another tile's commit created here)
+          } else if (!in_mk && !in_qx) {
             // visible before, not marked now, inside the frustum: upstream's 3 (a byte with this pass' bit is a 1 / 2
             // that counts as marked again: it stays)
             const unsigned char ty = p.vis_type[t];
@@ -567,7 +640,7 @@ __global__ __launch_bounds__(256) void k_alloc_sweep(SweepParams p) {
           // no room in the list: upstream leaves the type in place without the entry being re-armed next pass, so
           // a 1 / 2 counts as marked again then (next pass' bit), a 3 is re-tested (this pass' bit)
           unsigned ty = 1;
-          if (!in_x && !in_q) {
+          if (!in_qx) {
             const unsigned char old = p.vis_type[t];
             ty = (in_mk || (old & 0x80u) == p.gen) ? (old & 0x7fu) : 3u;
           }
@@ -577,7 +650,6 @@ __global__ __launch_bounds__(256) void k_alloc_sweep(SweepParams p) {
           const unsigned char st = p.swap_state[t];
           if (st == 0) { p.swap_state[t] = 1; bit_set(p.swap1_bits, t); }
         }
-        r++;
       }
     }
     *reinterpret_cast<uint4 *>(p.vis_bits + w0) = vis;

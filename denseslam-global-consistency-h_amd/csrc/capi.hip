@@ -118,7 +118,8 @@ int ensure_scratch(dslam_engine *e, int entries, int local_blocks) {
   DSLAM_HIP(hipMalloc(&e->bits_tmp, bits_bytes));
   DSLAM_HIP(hipMemsetAsync(e->bits_retest, 0, bits_bytes, e->stream));
   DSLAM_HIP(hipMemsetAsync(e->bits_tmp, 0, bits_bytes, e->stream));
-  const int tiles = num_tiles(N > L ? N : L);
+  int tiles = num_tiles(N > L ? N : L);
+  if (tiles < bit_tiles(N) * (kBitTileWords / 32)) tiles = bit_tiles(N) * (kBitTileWords / 32);  // (per-tile counts of k_bits_test)
   DSLAM_HIP(hipMalloc(&e->agg, (size_t)tiles * 3 * sizeof(unsigned long long)));
   DSLAM_HIP(hipMemsetAsync(e->agg, 0, (size_t)tiles * 3 * sizeof(unsigned long long), e->stream));
   e->agg_tiles = tiles;

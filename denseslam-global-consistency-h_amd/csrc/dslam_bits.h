@@ -1,25 +1,132 @@
-// dslam_bits.h -- ordered selection over a bitmap of the hash table (dslam_device.h, "bit-packed summaries"), in ONE launch.
+// dslam_bits.h -- ordered selection over a bitmap of the hash table (dslam_device.h, "bit-packed summaries").
 //
 // Every maintenance pass of the reference's engines is "for every hash entry in index order: if <condition> then ..."
 // (decay candidates, blocks leaving the window, blocks to swap, live blocks to mesh, FindVisibleBlocks, the rebuild of a
 // visible list).  On the device that is an ordered compaction; up to round 2 each one read all 1.18 M entries (19 MB, plus
-// byte flags and a second launch for the ranks).  Here the candidates come from a bitmap -- allocated entries, entries
-// with a type -- of which a set bit costs one sparse 16-byte read and a clear one nothing:
-//   tile = 1024 words = 32768 entries, one 256-thread workgroup, 4 consecutive words per thread (thread order = entry order)
-//   rank = popcounts + block scan + the counts of the tiles in front, exchanged inside the launch (one look-back; tiles are
-//          taken by ticket, so a tile only waits for workgroups that are already running)
+// byte flags).  Here the candidates come from a bitmap -- allocated entries, entries with a type -- of which a set bit
+// costs one sparse read and a clear one nothing.  Two launches, both balanced:
+//   k_bits_test     tile = 32 words = 1024 entries per 256-thread workgroup.  The set bits of the tile are expanded into an
+//                   LDS list and tested DENSELY, one candidate per lane and round: excess entries are handed out
+//                   contiguously, so some bitmap words are full while most are nearly empty -- a lane that walks "its" word
+//                   bit by bit ends up with 32 dependent gathers where its neighbours have none (measured: 100 us for
+//                   FindVisibleBlocks that way).  Out: the selection as a bitmap + the tile's count.
+//   k_bits_compact  tile = 256 words = 8192 entries.  Rank = sum of the test tiles' counts in front + popcounts; the
+//                   selected entries are again expanded into LDS and emitted densely (coalesced list stores).
+// No look-back, no spin, no ticket: the only hand-off is the kernel boundary.
 // A selection is a functor with
+//   void prologue()                          an independent grid-stride job run by the compaction launch (optional work)
 //   bool test(int t)                         is entry t (its bit is set in the source bitmap) selected?  May have side
 //                                            effects on state that belongs to entry t alone.
-//   void emit(int t, int rank, bool listed)  called for every selected entry in ascending order (listed: rank < capacity)
-//   void finish(int total)                   called once (one thread of the tile that ends the table), behind every test
+//   int  emit(int t, int rank, bool listed)  called for every selected entry (listed: rank < capacity; rank ascending with
+//                                            t); the return values are summed per compaction tile (tile_sum_out)
+//   void finish(int total)                   called once (one thread of the tile that ends the table), behind every emit of
+//                                            that tile
 // `gate` (optional device flag): the selection runs only if *gate != 0 -- for passes that are needed only if an earlier
-// kernel of the same call found work (the launch itself is unconditional: no host round trip).
+// kernel of the same call found work (the launches themselves are unconditional: no host round trip).  The test launch
+// copies the flag to gate[1], which the compaction launch obeys, so that finish() may re-arm gate[0].
 #pragma once
 #include "dslam_internal.h"
 
 namespace dslam {
 
+constexpr int kTestTileWords = 32;      // k_bits_test: 1024 entries per workgroup
+constexpr int kCompactTileWords = 256;  // k_bits_compact: 8192 entries per workgroup
+
+// the set bits of `w` as entry indices relative to the tile, ascending, to list[rank ...]
+__device__ __forceinline__ int expand_bits(unsigned w, int rel0, int rank, unsigned short *list) {
+  for (; w; w &= w - 1) list[rank++] = (unsigned short)(rel0 + __ffs((int)w) - 1);
+  return rank;
+}
+
+template <class Sel>
+__global__ __launch_bounds__(256) void k_bits_test(const unsigned *__restrict__ src_bits, Sel sel, unsigned *__restrict__ pick_bits,
+                                                   int *__restrict__ tile_counts, int *gate) {
+  __shared__ int red[4];
+  __shared__ unsigned short s_list[kTestTileWords * 32];
+  __shared__ unsigned s_pick[kTestTileWords];
+  if (gate) {
+    const int g = __builtin_amdgcn_readfirstlane(gate[0]);
+    if (blockIdx.x == 0 && threadIdx.x == 0) gate[1] = g;
+    if (g == 0) return;
+  }
+  // thread = 4 entries: nibble (tid & 7) of word (tid >> 3)
+  const int word = blockIdx.x * kTestTileWords + (threadIdx.x >> 3);
+  const unsigned nib = (src_bits[word] >> ((threadIdx.x & 7) * 4)) & 0xfu;
+  if (threadIdx.x < kTestTileWords) s_pick[threadIdx.x] = 0;
+  int tot;
+  const int rank = block_excl_scan<4>(__popc(nib), red, tot);   // (its barriers also cover s_pick)
+  expand_bits(nib, threadIdx.x * 4, rank, s_list);
+  __syncthreads();
+  const int t0 = blockIdx.x * (kTestTileWords * 32);
+  for (int j = threadIdx.x; j < tot; j += 256) {
+    const int rel = s_list[j];
+    if (sel.test(t0 + rel)) atomicOr(&s_pick[rel >> 5], 1u << (rel & 31));
+  }
+  __syncthreads();
+  if (threadIdx.x < kTestTileWords) {
+    const unsigned p = s_pick[threadIdx.x];
+    pick_bits[blockIdx.x * kTestTileWords + threadIdx.x] = p;
+    int c = __popc(p);
+    for (int d = 16; d > 0; d >>= 1) c += __shfl_xor(c, d, 64);   // (kTestTileWords = 32 lanes of wave 0)
+    if (threadIdx.x == 0) tile_counts[blockIdx.x] = c;
+  }
+}
+
+template <class Sel>
+__global__ __launch_bounds__(256) void k_bits_compact(const unsigned *__restrict__ pick_bits, const int *__restrict__ tile_counts,
+                                                      Sel sel, int *__restrict__ out, int capacity, int *total_out,
+                                                      int *tile_sum_out, const int *gate) {
+  __shared__ int red[4];
+  __shared__ unsigned short s_list[kCompactTileWords * 32];
+  if (gate && __builtin_amdgcn_readfirstlane(gate[1]) == 0) return;
+  sel.prologue();
+  const unsigned w = pick_bits[blockIdx.x * kCompactTileWords + threadIdx.x];
+  // the test tiles in front of this tile: (kCompactTileWords / kTestTileWords) per compaction tile
+  const int before = block_sum_strided(tile_counts, blockIdx.x * (kCompactTileWords / kTestTileWords), 1, red);
+  int tot;
+  const int rank = block_excl_scan<4>(__popc(w), red, tot);
+  const bool last = blockIdx.x == gridDim.x - 1;
+  if (tot == 0 && !last) {
+    if (tile_sum_out && threadIdx.x == 0) tile_sum_out[blockIdx.x] = 0;
+    return;
+  }
+  expand_bits(w, threadIdx.x * 32, rank, s_list);
+  __syncthreads();
+  const int t0 = blockIdx.x * (kCompactTileWords * 32);
+  int sum = 0;
+  for (int j = threadIdx.x; j < tot; j += 256) {
+    const int t = t0 + s_list[j], r = before + j;
+    if (r < capacity && out) out[r] = t;
+    sum += sel.emit(t, r, r < capacity);
+  }
+  if (tile_sum_out) {
+    for (int d = 32; d > 0; d >>= 1) sum += __shfl_xor(sum, d, 64);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = sum;
+    __syncthreads();
+    if (threadIdx.x == 0) tile_sum_out[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+  }
+  if (last) {
+    __syncthreads();   // (every emit of this tile is behind us)
+    if (threadIdx.x == 0) {
+      if (total_out) *total_out = (before + tot) < capacity ? (before + tot) : capacity;
+      sel.finish(before + tot);
+    }
+  }
+}
+
+// out[0 .. min(total, capacity)) = the selected entries, ascending; *total_out = min(total, capacity)
+template <class Sel>
+inline void launch_bits_select(dslam_engine *e, const unsigned *src_bits, int n_entries, const Sel &sel, int *out, int capacity,
+                               int *total_out, int *tile_sum_out = nullptr, int *gate = nullptr) {
+  const int n_words = bit_tiles(n_entries) * kBitTileWords;
+  hipLaunchKernelGGL(k_bits_test<Sel>, dim3(n_words / kTestTileWords), dim3(256), 0, e->stream, src_bits, sel, e->bits_tmp,
+                     e->tile_counts, gate);
+  hipLaunchKernelGGL(k_bits_compact<Sel>, dim3(n_words / kCompactTileWords), dim3(256), 0, e->stream, e->bits_tmp, e->tile_counts,
+                     sel, out, capacity, total_out, tile_sum_out, gate);
+}
+
+// ---- tiles taken by ticket + one in-launch look-back (list-tile compactions of the release pipeline) ---------------------
 struct TileChain {
   unsigned long long *agg;
   unsigned epoch;
@@ -53,53 +160,6 @@ static __device__ __forceinline__ void publish1(unsigned long long *agg, int til
   __hip_atomic_store(&agg[tile], ((unsigned long long)epoch << 32) | (unsigned)count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-// out[0 .. min(total, capacity)) = the selected entries, ascending; *total_out = min(total, capacity) (written by the
-// tile that ends the table).  `sel_bits` (optional): the selection as a bitmap as well.  *error_flags |= 2 if a count
-// never arrived (cannot happen while the device makes progress; reported instead of spinning forever).
-template <class Sel>
-__global__ __launch_bounds__(256) void k_bits_select(const unsigned *__restrict__ src_bits, TileChain ch, Sel sel,
-                                                     int *__restrict__ out, int capacity, int *total_out, unsigned *sel_bits,
-                                                     int *error_flags, const int *gate) {
-  __shared__ int red[4];
-  __shared__ int s_ticket;
-  const bool open = !gate || __builtin_amdgcn_readfirstlane(*gate) != 0;   // (every tile reads the flag before it publishes; finish() may re-arm it)
-  // one tile per workgroup (the grid is the number of tiles): no loop around the barriers below
-  const int b = take_ticket(ch.ticket, ch.ticket_base, &s_ticket);   // (taken even if the gate is shut: the host counts on it)
-  if (!open || b >= ch.n_tiles) return;
-  {
-    const int w0 = b * kBitTileWords + threadIdx.x * 4;
-    const uint4 src = *reinterpret_cast<const uint4 *>(src_bits + w0);
-    uint4 pick = make_uint4(0, 0, 0, 0);
-#pragma unroll 1
-    for (int i = 0; i < 4; i++)
-      for (unsigned m = sel4(src, i); m; m &= m - 1) {
-        const int bit = __ffs((int)m) - 1;
-        if (sel.test((w0 + i) * 32 + bit)) or4(pick, i, 1u << bit);
-      }
-    int tot;
-    int r = block_excl_scan<4>(popc4(pick), red, tot);
-    if (threadIdx.x == 0) publish1(ch.agg, b, ch.epoch, tot);
-    if (sel_bits) *reinterpret_cast<uint4 *>(sel_bits + w0) = pick;
-    const bool last = b == ch.n_tiles - 1;
-    if (tot == 0 && !last) return;
-    int before;
-    if (!lookback1(ch.agg, b, ch.epoch, red, before) && threadIdx.x == 0 && error_flags) atomicOr(error_flags, 2);
-    if (last && threadIdx.x == 0) {
-      if (total_out) *total_out = (before + tot) < capacity ? (before + tot) : capacity;
-      sel.finish(before + tot);
-    }
-    r += before;
-#pragma unroll 1
-    for (int i = 0; i < 4; i++)
-      for (unsigned m = sel4(pick, i); m; m &= m - 1) {
-        const int t = (w0 + i) * 32 + __ffs((int)m) - 1;
-        if (r < capacity && out) out[r] = t;
-        sel.emit(t, r, r < capacity);
-        r++;
-      }
-  }
-}
-
 // host side: the chain of one launch (epoch + tickets); grid = one workgroup per tile, each takes exactly one ticket
 inline TileChain next_chain(dslam_engine *e, int n_tiles, int *grid_out) {
   TileChain ch;
@@ -113,15 +173,6 @@ inline TileChain next_chain(dslam_engine *e, int n_tiles, int *grid_out) {
   e->ticket_base += (unsigned)grid;
   *grid_out = grid;
   return ch;
-}
-
-template <class Sel>
-inline void launch_bits_select(dslam_engine *e, const unsigned *src_bits, int n_entries, const Sel &sel, int *out, int capacity,
-                               int *total_out, unsigned *sel_bits, int *error_flags, const int *gate = nullptr) {
-  int grid;
-  const TileChain ch = next_chain(e, bit_tiles(n_entries), &grid);
-  hipLaunchKernelGGL(k_bits_select<Sel>, dim3(grid), dim3(256), 0, e->stream, src_bits, ch, sel, out, capacity, total_out,
-                     sel_bits, error_flags, gate);
 }
 
 }  // namespace dslam

@@ -44,7 +44,8 @@ struct SelDecayAged {
     if (ptr < 0) return false;
     return (masks[((size_t)ptr * 2 + ring) * words + (bit >> 6)] >> (bit & 63)) & 1ull;
   }
-  __device__ void emit(int, int, bool) const {}
+  __device__ void prologue() const {}
+  __device__ int emit(int, int, bool) const { return 0; }
   __device__ void finish(int) const {}
 };
 struct SelSlidePop {
@@ -64,7 +65,8 @@ struct SelSlidePop {
     for (int i = 0; i < 2 * words; i++) any |= m[i];
     return any == 0;
   }
-  __device__ void emit(int t, int, bool) const { if (flags) flags[t] = 1; }
+  __device__ void prologue() const {}
+  __device__ int emit(int t, int, bool) const { if (flags) flags[t] = 1; return 0; }
   __device__ void finish(int) const {}
 };
 struct SelDecaySweep {
@@ -78,7 +80,8 @@ struct SelDecaySweep {
     if (ls >= 0 && ls <= threshold) { last_seen[ptr] = -2 - ls; return true; }
     return false;
   }
-  __device__ void emit(int, int, bool) const {}
+  __device__ void prologue() const {}
+  __device__ int emit(int, int, bool) const { return 0; }
   __device__ void finish(int) const {}
 };
 
@@ -319,11 +322,13 @@ struct SelRebuildVisible {
   unsigned char *vis_type;
   unsigned gen;
   int *maint_flags;
+  __device__ void prologue() const {}
   __device__ bool test(int) const { return true; }
-  __device__ void emit(int t, int, bool listed) const {
-    if (!listed) return;
+  __device__ int emit(int t, int, bool listed) const {
+    if (!listed) return 0;
     const unsigned char ty = vis_type[t];
     if ((ty & 0x80u) != gen) vis_type[t] = (unsigned char)(gen | (ty & 0x7fu));
+    return 0;
   }
   // every other tile has read the flag by now (the tile that ends the table has just seen all their counts): re-arm it
   __device__ void finish(int) const { maint_flags[0] = 0; }
@@ -350,7 +355,7 @@ static MaintScratch carve(dslam_engine *e, int N) {
 // if the release pipeline's flag says that an entry with a type went
 static int rebuild_visible_list(dslam_engine *e, dslam_render_state *r, bool force = true) {
   SelRebuildVisible sel{r->visible_type, (unsigned)r->gen, e->maint_flags};
-  launch_bits_select(e, r->vis_bits, r->n_entries, sel, r->visible_ids, r->n_local, &r->counters->no_visible, nullptr, nullptr,
+  launch_bits_select(e, r->vis_bits, r->n_entries, sel, r->visible_ids, r->n_local, &r->counters->no_visible, nullptr,
                      force ? nullptr : e->maint_flags);
   dbg_sync(e, "rebuild_visible_list");
   DSLAM_HIP(hipGetLastError());
@@ -420,16 +425,14 @@ int launch_decay(dslam_engine *e, dslam_scene *s, dslam_render_state *r, int max
     int k = s->decay_cursor[q] > s->ring_head[q] ? s->decay_cursor[q] : s->ring_head[q];
     for (; k <= newest - min_age; k++) {
       SelDecayAged sel{s->hash, s->masks, s->history_words, q, k % bits};
-      launch_bits_select(e, s->alloc_bits, N, sel, m.cand_list, s->p.num_local_blocks, &s->counters->swap_count, nullptr,
-                         &s->counters->error_flags);
+      launch_bits_select(e, s->alloc_bits, N, sel, m.cand_list, s->p.num_local_blocks, &s->counters->swap_count);
       if ((rc = decay_candidates(e, s, r, m, max_weight))) return rc;
     }
     if (k > s->decay_cursor[q]) s->decay_cursor[q] = k;
   } else {
     const int threshold = (s->frame_counter - 1) - min_age;
     SelDecaySweep sel{s->hash, s->last_seen, threshold};
-    launch_bits_select(e, s->alloc_bits, N, sel, m.cand_list, s->p.num_local_blocks, &s->counters->swap_count, nullptr,
-                       &s->counters->error_flags);
+    launch_bits_select(e, s->alloc_bits, N, sel, m.cand_list, s->p.num_local_blocks, &s->counters->swap_count);
     dbg_sync(e, "select decay sweep");
     if ((rc = decay_candidates(e, s, r, m, max_weight))) return rc;
   }
@@ -448,14 +451,16 @@ int launch_decay(dslam_engine *e, dslam_scene *s, dslam_render_state *r, int max
 struct SelSwapPending {
   const unsigned char *swap_state;
   __device__ bool test(int t) const { return swap_state[t] == 1; }
-  __device__ void emit(int, int, bool) const {}
+  __device__ void prologue() const {}
+  __device__ int emit(int, int, bool) const { return 0; }
   __device__ void finish(int) const {}
 };
 struct SelSwapFresh {
   const HashEntry *hash;
   const unsigned char *swap_state;
   __device__ bool test(int t) const { return swap_state[t] == 0 && hash[t].ptr >= 0; }
-  __device__ void emit(int, int, bool) const {}
+  __device__ void prologue() const {}
+  __device__ int emit(int, int, bool) const { return 0; }
   __device__ void finish(int) const {}
 };
 struct SelSwapOut {
@@ -463,7 +468,8 @@ struct SelSwapOut {
   const unsigned char *swap_state;
   const unsigned char *vis_type;   // null: whatever the visibility
   __device__ bool test(int t) const { return swap_state[t] == 2 && hash[t].ptr >= 0 && (vis_type == nullptr || vis_type[t] == 0); }
-  __device__ void emit(int, int, bool) const {}
+  __device__ void prologue() const {}
+  __device__ int emit(int, int, bool) const { return 0; }
   __device__ void finish(int) const {}
 };
 
@@ -614,10 +620,10 @@ __global__ void k_set_swap_stats(SceneCounters *cnt, int in, int out) {
 template <int MODE>
 static int swap_select(dslam_engine *e, dslam_scene *s, const unsigned char *vis_type, const MaintScratch &m) {
   const int N = s->n_entries;
-  int *count = &s->counters->swap_count, *err = &s->counters->error_flags;
-  if (MODE == 0) launch_bits_select(e, s->swap1_bits, N, SelSwapPending{s->swap_state}, m.cand_list, kTransferBlocks, count, nullptr, err);
-  else if (MODE == 1) launch_bits_select(e, s->alloc_bits, N, SelSwapFresh{s->hash, s->swap_state}, m.cand_list, kTransferBlocks, count, nullptr, err);
-  else launch_bits_select(e, s->alloc_bits, N, SelSwapOut{s->hash, s->swap_state, vis_type}, m.cand_list, kTransferBlocks, count, nullptr, err);
+  int *count = &s->counters->swap_count;
+  if (MODE == 0) launch_bits_select(e, s->swap1_bits, N, SelSwapPending{s->swap_state}, m.cand_list, kTransferBlocks, count);
+  else if (MODE == 1) launch_bits_select(e, s->alloc_bits, N, SelSwapFresh{s->hash, s->swap_state}, m.cand_list, kTransferBlocks, count);
+  else launch_bits_select(e, s->alloc_bits, N, SelSwapOut{s->hash, s->swap_state, vis_type}, m.cand_list, kTransferBlocks, count);
   DSLAM_HIP(hipGetLastError());
   return DSLAM_OK;
 }
@@ -751,16 +757,14 @@ int launch_slide_pop(dslam_engine *e, dslam_scene *s, dslam_render_state *r, int
   if (!s->p.use_swapping) {
     // released: the list and the release pipeline's removal flags come out of one selection
     SelSlidePop sel{s->hash, s->masks, s->history_words, q, bit, m.rem_flags};
-    launch_bits_select(e, s->alloc_bits, N, sel, m.rem_list, s->p.num_local_blocks, &s->counters->remove_count, nullptr,
-                       &s->counters->error_flags);
+    launch_bits_select(e, s->alloc_bits, N, sel, m.rem_list, s->p.num_local_blocks, &s->counters->remove_count);
     DSLAM_HIP(hipGetLastError());
     return release_listed(e, s, r, m, 1);
   }
 
   // scene with swapping: the blocks move to the host store, their entries stay (ptr = -1)
   SelSlidePop sel{s->hash, s->masks, s->history_words, q, bit, nullptr};
-  launch_bits_select(e, s->alloc_bits, N, sel, m.cand_list, s->p.num_local_blocks, &s->counters->swap_count, nullptr,
-                     &s->counters->error_flags);
+  launch_bits_select(e, s->alloc_bits, N, sel, m.cand_list, s->p.num_local_blocks, &s->counters->swap_count);
   DSLAM_HIP(hipGetLastError());
   int *host_count = reinterpret_cast<int *>(e->pinned) + 48;
   DSLAM_HIP(hipMemcpyAsync(host_count, &s->counters->swap_count, sizeof(int), hipMemcpyDeviceToHost, e->stream));

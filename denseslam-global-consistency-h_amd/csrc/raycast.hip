@@ -20,17 +20,13 @@ namespace dslam {
 // ---------------------------------------------------------------------------------------------------------
 // FindVisibleBlocks: ordered compaction of entries with ptr >= 0 that pass the 8-corner frustum test
 // ---------------------------------------------------------------------------------------------------------
-// ONE launch over the scene's alloc_bits (round 2: a frustum-flag sweep over all 1.18 M entries and a compaction sweep
-// over the flags): lane = one bitmap word = 32 entries, tile = 256 words, taken by ticket; only entries that hold a
-// block are read and tested; ranks = popcounts + block scan + one in-launch look-back.  PROJECT: the lane that lists
-// visible entry number r also projects it (CreateExpectedDepths' ProjectSingleBlock; GetImage runs both with one pose),
-// the launch resets the range image, and every tile leaves its render-tile total for k_fill_range_tiles.
+// An ordered selection over the scene's alloc_bits (dslam_bits.h): only entries that hold a block are read and tested
+// (round 2: a frustum-flag sweep over all 1.18 M entries and a compaction sweep over 1.18 M byte flags).
 struct FrustumParams {
   Mat4 M;
   float fx, fy, cx, cy, voxel_size;
   int W, H;
 };
-constexpr int kFindTileWords = 256;
 
 // ---------------------------------------------------------------------------------------------------------
 // CountVisibleBlocks
@@ -108,70 +104,43 @@ __device__ __forceinline__ int project_single_block(const HashEntry &e, const Pr
   return rx * ry;
 }
 
+// PROJECT: the lane that lists visible entry number r also projects it (CreateExpectedDepths' ProjectSingleBlock; GetImage
+// runs both with one pose), the compaction launch resets the range image, and every compaction tile leaves its
+// render-tile total for k_fill_range_tiles.
 template <bool PROJECT>
-__global__ __launch_bounds__(256) void k_find_visible(const unsigned *__restrict__ alloc_bits, TileChain ch,
-                                                      const HashEntry *__restrict__ hash, FrustumParams fp, int *__restrict__ ids,
-                                                      int capacity, RenderCounters *rc, int4 *__restrict__ boxes,
-                                                      float2 *__restrict__ zr_out, int *req_out, float2 *range, int npix,
-                                                      int *wg_tiles) {
-  __shared__ int red[4];
-  __shared__ int s_ticket;
-  if (PROJECT)   // (independent job) reset the range image to (FAR_AWAY, VERY_CLOSE)
-    for (int i = blockIdx.x * 256 + threadIdx.x; i < npix; i += gridDim.x * 256) range[i] = make_float2(kFarAway, kVeryClose);
-  ProjParams pp;
-  pp.M = fp.M; pp.fx = fp.fx; pp.fy = fp.fy; pp.cx = fp.cx; pp.cy = fp.cy; pp.voxel_size = fp.voxel_size; pp.W = fp.W; pp.H = fp.H;
-  const int b = take_ticket(ch.ticket, ch.ticket_base, &s_ticket);   // (one tile per workgroup)
-  if (b >= ch.n_tiles) return;
-  {
-    const int w = b * kFindTileWords + threadIdx.x;
-    unsigned pick = 0;
-    for (unsigned m = alloc_bits[w]; m; m &= m - 1) {
-      const int bit = __ffs((int)m) - 1;
-      const HashEntry e = load_entry(hash, w * 32 + bit);
-      if (e.ptr < 0) continue;
-      bool vis, vis_enl;
-      check_block_vis<false>(vis, vis_enl, e.pos[0], e.pos[1], e.pos[2], fp.M, fp.fx, fp.fy, fp.cx, fp.cy, fp.voxel_size, fp.W, fp.H);
-      if (vis) pick |= 1u << bit;
-    }
-    int tot;
-    int r = block_excl_scan<4>(__popc(pick), red, tot);
-    if (threadIdx.x == 0) publish1(ch.agg, b, ch.epoch, tot);
-    const bool last = b == ch.n_tiles - 1;
-    if (tot == 0 && !last) {
-      if (PROJECT && threadIdx.x == 0) wg_tiles[b] = 0;
-      return;
-    }
-    int before;
-    if (!lookback1(ch.agg, b, ch.epoch, red, before)) { /* (cannot happen while the device makes progress) */ }
-    if (last && threadIdx.x == 0) rc->no_visible = (before + tot) < capacity ? (before + tot) : capacity;
-    r += before;
-    int local_tiles = 0;
-    for (unsigned m = pick; m; m &= m - 1) {
-      const int t = w * 32 + __ffs((int)m) - 1;
-      if (r < capacity) {
-        ids[r] = t;
-        if (PROJECT) {
-          const HashEntry e = load_entry(hash, t);
-          int4 box;
-          float2 zr;
-          const int req = project_single_block(e, pp, box, zr);
-          if (req) { boxes[r] = box; zr_out[r] = zr; }
-          req_out[r] = req;
-          local_tiles += req;
-        }
-      }
-      r++;
-    }
-    if (PROJECT) {
-      // per-tile totals instead of one contended global counter; the range-image kernel sums them
-      for (int d = 32; d > 0; d >>= 1) local_tiles += __shfl_xor(local_tiles, d, 64);
-      if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = local_tiles;
-      __syncthreads();
-      if (threadIdx.x == 0) wg_tiles[b] = red[0] + red[1] + red[2] + red[3];
-      __syncthreads();
-    }
+struct SelFrustum {
+  const HashEntry *hash;
+  FrustumParams fp;
+  int4 *boxes;
+  float2 *zr_out;
+  int *req_out;
+  float2 *range;
+  int npix;
+  __device__ void prologue() const {
+    if (PROJECT)   // (independent job) reset the range image to (FAR_AWAY, VERY_CLOSE)
+      for (int i = blockIdx.x * 256 + threadIdx.x; i < npix; i += gridDim.x * 256) range[i] = make_float2(kFarAway, kVeryClose);
   }
-}
+  __device__ bool test(int t) const {
+    const HashEntry e = load_entry(hash, t);
+    if (e.ptr < 0) return false;
+    bool vis, vis_enl;
+    check_block_vis<false>(vis, vis_enl, e.pos[0], e.pos[1], e.pos[2], fp.M, fp.fx, fp.fy, fp.cx, fp.cy, fp.voxel_size, fp.W, fp.H);
+    return vis;
+  }
+  __device__ int emit(int t, int r, bool listed) const {
+    if (!PROJECT || !listed) return 0;
+    ProjParams pp;
+    pp.M = fp.M; pp.fx = fp.fx; pp.fy = fp.fy; pp.cx = fp.cx; pp.cy = fp.cy; pp.voxel_size = fp.voxel_size; pp.W = fp.W; pp.H = fp.H;
+    const HashEntry e = load_entry(hash, t);
+    int4 box;
+    float2 zr;
+    const int req = project_single_block(e, pp, box, zr);
+    if (req) { boxes[r] = box; zr_out[r] = zr; }
+    req_out[r] = req;
+    return req;
+  }
+  __device__ void finish(int) const {}
+};
 
 static FrustumParams make_frustum_params(const dslam_scene *s, const dslam_render_state *r, const float *M, const float *intr) {
   FrustumParams fp;
@@ -181,22 +150,14 @@ static FrustumParams make_frustum_params(const dslam_scene *s, const dslam_rende
   return fp;
 }
 
-// the chain of a k_find_visible launch: tiles of kFindTileWords words
-static TileChain find_chain(dslam_engine *e, int n_entries, int *grid_out) {
-  return next_chain(e, bit_tiles(n_entries) * (kBitTileWords / kFindTileWords), grid_out);
-}
-
 int launch_find_visible(dslam_engine *e, const dslam_scene *s, dslam_render_state *r, const float *M,
                         const float *intr) {
   const int N = s->n_entries;
   DSLAM_REQUIRE(r->n_entries == N, "render state was created for a different scene size");
   int rc = ensure_scratch(e, N, s->p.num_local_blocks);
   if (rc) return rc;
-  int grid;
-  const TileChain ch = find_chain(e, N, &grid);
-  hipLaunchKernelGGL(k_find_visible<false>, dim3(grid), dim3(256), 0, e->stream, s->alloc_bits, ch, s->hash,
-                     make_frustum_params(s, r, M, intr), r->visible_ids, r->n_local, r->counters, (int4 *)nullptr, (float2 *)nullptr,
-                     (int *)nullptr, (float2 *)nullptr, 0, (int *)nullptr);
+  SelFrustum<false> sel{s->hash, make_frustum_params(s, r, M, intr), nullptr, nullptr, nullptr, nullptr, 0};
+  launch_bits_select(e, s->alloc_bits, N, sel, r->visible_ids, r->n_local, &r->counters->no_visible);
   DSLAM_HIP(hipGetLastError());
   return DSLAM_OK;
 }
@@ -358,20 +319,17 @@ int launch_expected_depths(dslam_engine *e, const dslam_scene *s, dslam_render_s
   return launch_fill_range(e, r, kProjectGrid);
 }
 
-// FindVisibleBlocks + CreateExpectedDepths for the same pose (ITMMainEngine::GetImage's FREECAMERA path): two launches
-// (round 1: five; round 2: three, two of them sweeps over the whole table).
+// FindVisibleBlocks + CreateExpectedDepths for the same pose (ITMMainEngine::GetImage's FREECAMERA path): three launches
+// (round 1: five), none of which reads the table as a whole any more.
 int launch_find_visible_and_depths(dslam_engine *e, const dslam_scene *s, dslam_render_state *r, const float *M,
                                    const float *intr) {
   const int N = s->n_entries;
   DSLAM_REQUIRE(r->n_entries == N, "render state was created for a different scene size");
   int rc = ensure_scratch(e, N, s->p.num_local_blocks);
   if (rc) return rc;
-  int grid;
-  const TileChain ch = find_chain(e, N, &grid);
-  hipLaunchKernelGGL(k_find_visible<true>, dim3(grid), dim3(256), 0, e->stream, s->alloc_bits, ch, s->hash,
-                     make_frustum_params(s, r, M, intr), r->visible_ids, r->n_local, r->counters, r->proj_boxes, r->proj_z,
-                     r->proj_req, r->range, r->w * r->h, r->proj_wg_tiles);
-  return launch_fill_range(e, r, ch.n_tiles);
+  SelFrustum<true> sel{s->hash, make_frustum_params(s, r, M, intr), r->proj_boxes, r->proj_z, r->proj_req, r->range, r->w * r->h};
+  launch_bits_select(e, s->alloc_bits, N, sel, r->visible_ids, r->n_local, &r->counters->no_visible, r->proj_wg_tiles);
+  return launch_fill_range(e, r, bit_tiles(N) * (kBitTileWords / kCompactTileWords));
 }
 
 // ---------------------------------------------------------------------------------------------------------
