@@ -220,7 +220,11 @@ int dslam_engine_destroy(dslam_engine *e) {
   free_dev(e->mesh_positions); free_dev(e->mesh_colours);
   if (e->icp_partials_host) (void)hipHostFree(e->icp_partials_host);  // (icp_partials is its device alias)
   for (auto ev : e->ev_pool) (void)hipEventDestroy(ev);
-  for (auto ev : e->retired_events) (void)hipEventDestroy(ev);
+  for (dslam_fence *f : e->fences) {
+    if (f->zombie) { if (f->ev) (void)hipEventDestroy(f->ev); delete f; }
+    else f->engine = nullptr;   // the caller still holds it: its destroy call must not look for this engine
+  }
+  e->fences.clear();
   if (e->stream) (void)hipStreamDestroy(e->stream);
   delete e;
   return DSLAM_OK;
@@ -262,17 +266,29 @@ int dslam_fence_create(dslam_engine *e, dslam_fence **out) {
   f->engine = e;
   const hipError_t err = hipEventCreateWithFlags(&f->ev, hipEventDisableTiming);
   if (err != hipSuccess) { delete f; return hip_fail(err, "hipEventCreateWithFlags", __FILE__, __LINE__); }
+  e->fences.push_back(f);
   *out = f;
   return DSLAM_OK;
+}
+static void fence_free(dslam_fence *f) {
+  if (f->engine) {
+    auto &v = f->engine->fences;
+    v.erase(std::remove(v.begin(), v.end(), f), v.end());
+  }
+  if (f->ev) (void)hipEventDestroy(f->ev);
+  delete f;
+}
+// a view stops waiting on the fence event it had borrowed for landing buffer b
+static void release_lender(dslam_view *v, int b) {
+  dslam_fence *f = v->up_lender[b];
+  v->up_lender[b] = nullptr;
+  if (f && --f->lent_count == 0 && f->zombie) fence_free(f);
 }
 int dslam_fence_destroy(dslam_fence *f) {
   if (!f) return DSLAM_OK;
   if (f->engine && f->engine->last_fence == f) f->engine->last_fence = nullptr;
-  if (f->ev) {
-    if (f->lent && f->engine) f->engine->retired_events.push_back(f->ev);  // destroyed with the engine
-    else (void)hipEventDestroy(f->ev);
-  }
-  delete f;
+  if (f->engine && f->lent_count > 0) { f->zombie = true; return DSLAM_OK; }  // (a view still waits on its event)
+  fence_free(f);
   return DSLAM_OK;
 }
 int dslam_fence_record(dslam_engine *e, dslam_fence *f) {
@@ -538,6 +554,7 @@ int dslam_view_destroy(dslam_view *v) {
   if (v->engine->copy_stream) (void)hipStreamSynchronize(v->engine->copy_stream);
   free_dev(v->rgba); free_dev(v->depth); free_dev(v->raw_depth); free_dev(v->pyramid);
   for (int b = 0; b < 2; b++) {
+    release_lender(v, b);
     free_dev(v->up_rgba[b]);  // (up_raw[b] points into the same allocation)
     if (v->up_done[b]) (void)hipEventDestroy(v->up_done[b]);
     if (v->up_consumed[b]) (void)hipEventDestroy(v->up_consumed[b]);
@@ -555,6 +572,7 @@ static int finish_view_update(dslam_engine *e, dslam_view *v, const void *rgba_d
   if (use_bilateral) {
     DSLAM_REQUIRE(v->w_d >= 5 && v->h_d >= 5, "bilateral filter needs an image of at least 5x5");
     if ((rc = launch_bilateral(e, v))) return rc;
+    e->view_reads++;  // (the filter reads the landing buffer: a fence recorded before it does not cover it)
   }
   v->timestamp = timestamp;
   return finish_call(e);
@@ -627,9 +645,11 @@ static int upload_view_pipelined(dslam_engine *e, dslam_view *v, const uint8_t *
   v->up_next ^= 1;
   if (v->up_used[b ^ 1]) {
     dslam_fence *f = e->last_fence;
+    release_lender(v, b ^ 1);
     if (f && f->recorded && f->view_reads_at_record == e->view_reads) {
       // the caller's fence sits behind every kernel that read buffer b ^ 1 (no view was read since it was recorded)
-      f->lent = true;
+      f->lent_count++;
+      v->up_lender[b ^ 1] = f;
       v->up_consumed_by[b ^ 1] = f->ev;
     } else {
       DSLAM_HIP(hipEventRecord(v->up_consumed[b ^ 1], e->stream));
@@ -1256,6 +1276,10 @@ int dslam_get_stats(dslam_engine *e, const dslam_scene *s, const dslam_render_st
   out->alloc_failures = sc->alloc_failures;
   out->last_swapped_in = sc->swapped_in;
   out->last_swapped_out = sc->swapped_out;
+  if (sc->error_flags & 2) {
+    set_last_error("a tile count of an ordered compaction never arrived (device made no progress?): the map state is undefined");
+    return DSLAM_ERR_HIP;
+  }
   if (sc->error_flags & 1) {
     set_last_error("allocation ray needed more steps than the order key encodes (non-rigid pose or mu/voxel_size changed?)");
     return DSLAM_ERR_UNSUPPORTED;

@@ -161,16 +161,18 @@ static __device__ __forceinline__ void publish1(unsigned long long *agg, int til
 }
 
 // host side: the chain of one launch (epoch + tickets); grid = one workgroup per tile, each takes exactly one ticket
-inline TileChain next_chain(dslam_engine *e, int n_tiles, int *grid_out) {
+// `second`: the chain runs next to another one in the same launch (own counter, own channel of per-tile words)
+inline TileChain next_chain(dslam_engine *e, int n_tiles, int *grid_out, bool second = false) {
   TileChain ch;
   if (++e->epoch == 0) e->epoch = 1;
-  ch.agg = e->agg;
+  ch.agg = second ? e->agg + e->agg_tiles : e->agg;
   ch.epoch = e->epoch;
-  ch.ticket = e->ticket;
-  ch.ticket_base = e->ticket_base;
+  ch.ticket = second ? e->ticket + 1 : e->ticket;
+  unsigned &base = second ? e->ticket_base2 : e->ticket_base;
+  ch.ticket_base = base;
   ch.n_tiles = n_tiles;
   const int grid = n_tiles > 0 ? n_tiles : 1;
-  e->ticket_base += (unsigned)grid;
+  base += (unsigned)grid;
   *grid_out = grid;
   return ch;
 }

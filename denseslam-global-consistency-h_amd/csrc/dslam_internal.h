@@ -43,7 +43,8 @@ struct dslam_engine {
   // upload then records no event of its own (an event record costs the compute stream ~3.5 us per frame, measured).
   unsigned long long view_reads = 0;   // calls that enqueued kernels reading a view's images, so far
   dslam_fence *last_fence = nullptr;   // most recently recorded fence
-  std::vector<hipEvent_t> retired_events;  // events of destroyed fences that a view may still wait on
+  std::vector<dslam_fence *> fences;   // every fence of this engine that still exists: live ones, and destroyed ones whose
+                                       // event a view still waits on (they go when the last such view lets go)
   hipStream_t copy_stream = nullptr;  // pipelined uploads (async mode, page-locked sources): H2D of frame i + 1 under frame i's kernels
   bool async_mode = false;
   dslam_weight_params wp{0, 1, 1.0f};
@@ -67,8 +68,9 @@ struct dslam_engine {
   unsigned alloc_pass = 0;
   // tickets of the single-pass ordered compactions (dslam_device.h take_ticket): one ever-growing device counter and
   // the value the host knows it has
-  unsigned *ticket = nullptr;
-  unsigned ticket_base = 0;
+  unsigned *ticket = nullptr;         // device [16]: counter k is ticket + k
+  unsigned ticket_base = 0;           // counter 0
+  unsigned ticket_base2 = 0;          // counter 1 (a second, independent chain inside the same launch)
   // single-pass ordered compactions: per-tile aggregates published inside one launch ({epoch, counts} in one 8-byte
   // word per tile; three channels: allocation requests, commit results, visible counts) and the launch counter that
   // tags them, so the arrays never need clearing
@@ -209,6 +211,7 @@ struct dslam_view {
   hipEvent_t up_done[2] = {nullptr, nullptr};      // copy stream: buffer b has landed
   hipEvent_t up_consumed[2] = {nullptr, nullptr};  // compute stream: every kernel that reads buffer b has been passed
   hipEvent_t up_consumed_by[2] = {nullptr, nullptr};  // the event that says so for the current contents: up_consumed[b] or a caller's fence
+  dslam_fence *up_lender[2] = {nullptr, nullptr};     // ... the fence that event belongs to, if it is a caller's
   bool up_used[2] = {false, false};
   int up_next = 0;
   float affine_a = 0.001f, affine_b = 0.0f;
@@ -222,7 +225,8 @@ struct dslam_fence {
   hipEvent_t ev = nullptr;
   bool recorded = false;
   unsigned long long view_reads_at_record = 0;  // engine->view_reads when it was recorded
-  bool lent = false;  // some view waits on `ev` as its "landing buffer consumed" mark: the event outlives the fence
+  int lent_count = 0;   // views that wait on `ev` as their "landing buffer consumed" mark at the moment
+  bool zombie = false;  // destroyed by the caller while lent: the object and its event live until the last view lets go
 };
 
 // mfusionFrameDataBase's image payload (fusionFrameInfo::rgbinfo / depthinfo, DenseSlam.h:431-433) kept in HBM:

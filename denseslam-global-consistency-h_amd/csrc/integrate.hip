@@ -797,12 +797,16 @@ __global__ __launch_bounds__(kWgWaves * 64, 8) void k_integrate(IntegrateParams 
         if (q_n > 0) {
           // the queued colour updates, one per lane; every result goes back to the place of its voxel
           ColQueue &Q = col_q[threadIdx.x >> 6];
+          // (the queue passes data between the lanes of ONE wave through LDS: program order + lockstep make that work; the
+          // wave barriers say so to the compiler, which may otherwise move the LDS accesses of different lanes' data)
+          __builtin_amdgcn_wave_barrier();
           for (int i = lane; i < q_n; i += 64) {
             const int o = Q.list[i];
             // (texels through a buffer resource where the variant has scalar registers to spare for a second one)
             if constexpr (DEINT) Q.r[o] = defuse_colour_word<false>(Q.c[o], Q.u[o], Q.w[o], p, inv_tab);
             else Q.r[o] = fuse_colour_word<PLAIN>(Q.c[o], Q.u[o], Q.w[o], p, inv_tab);
           }
+          __builtin_amdgcn_wave_barrier();
 #pragma unroll
           for (int jj = 0; jj < 2; jj++)
 #pragma unroll

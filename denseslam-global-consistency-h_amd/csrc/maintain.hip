@@ -262,10 +262,8 @@ __global__ __launch_bounds__(256) void k_unlink(const int *__restrict__ leader_b
 // Freed excess slots back onto the excess free list in ascending slot order (single-pass ordered compaction: tile counts
 // exchanged in-launch, tiles taken by ticket), flags consumed; the tile that ends the list folds the whole removal pass
 // into the pool counters.
-__global__ __launch_bounds__(256) void k_push_freed_finalize(unsigned char *freed_flags, int n_excess, int *excess_list,
-                                                             SceneCounters *cnt, int count_as_slid, TileChain ch) {
-  __shared__ int red[8];
-  __shared__ int s_ticket;
+__device__ __forceinline__ void push_freed_job(unsigned char *freed_flags, int n_excess, int *excess_list, SceneCounters *cnt,
+                                               int count_as_slid, const TileChain &ch, int *red, int &s_ticket) {
   // (read before this workgroup publishes anything; only the last tile changes them)
   const int removed = __builtin_amdgcn_readfirstlane(cnt->remove_count);
   const int base_ex = __builtin_amdgcn_readfirstlane(cnt->last_free_ex);
@@ -311,28 +309,70 @@ __global__ __launch_bounds__(256) void k_push_freed_finalize(unsigned char *free
   }
 }
 
-// rebuild of a render state's visible list from its types, only when the pass took an entry out of it: an ordered
-// selection over the render state's vis_bits (every entry with a type).
+// rebuild of a render state's visible list from its types, only when the pass took an entry out of it: the entries with
+// a bit in the render state's vis_bits, ascending.  Tile = 256 words, taken by ticket; counts exchanged in one look-back;
+// the entries leave through an LDS list, one per lane and round (coalesced stores, full words of the excess area spread
+// over the workgroup).
 // `gen` = the generation bit of the render state's last allocation pass.  An entry that did not fit into the list of that
 // pass (a visible list is capped at the pool size) kept its 1 / 2 with the NEXT pass' bit -- upstream leaves such a type in
 // place without re-arming it, so it counts as marked again.  Once the rebuilt, shorter list has room for it, it is an
 // ordinary listed entry, which upstream's next pass re-arms as 3: its byte gets the last pass' bit here (found by the
 // fuzz test, seed 10744: list full after an allocation-only pass, then a window pop, then a fusion).
-struct SelRebuildVisible {
+struct RebuildParams {
+  const unsigned *vis_bits;   // null: no render state, nothing to rebuild
   unsigned char *vis_type;
-  unsigned gen;
+  int *ids;
+  int capacity;
+  RenderCounters *rc;
   int *maint_flags;
-  __device__ void prologue() const {}
-  __device__ bool test(int) const { return true; }
-  __device__ int emit(int t, int, bool listed) const {
-    if (!listed) return 0;
-    const unsigned char ty = vis_type[t];
-    if ((ty & 0x80u) != gen) vis_type[t] = (unsigned char)(gen | (ty & 0x7fu));
-    return 0;
-  }
-  // every other tile has read the flag by now (the tile that ends the table has just seen all their counts): re-arm it
-  __device__ void finish(int) const { maint_flags[0] = 0; }
+  unsigned gen;
+  int force;
+  SceneCounters *cnt;         // (error flag) may be null
 };
+
+__device__ __forceinline__ void rebuild_visible_job(const RebuildParams &q, const TileChain &ch, int *red, int &s_ticket,
+                                                    unsigned short *s_list) {
+  // (every workgroup reads the flag before it takes its tile, hence before anything is published; the last tile re-arms it)
+  const bool open = q.force || __builtin_amdgcn_readfirstlane(q.maint_flags[0]) != 0;
+  const int b = take_ticket(ch.ticket, ch.ticket_base, &s_ticket);
+  if (!open || b >= ch.n_tiles) return;
+  const unsigned w = q.vis_bits[b * kCompactTileWords + threadIdx.x];
+  int tot;
+  const int rank = block_excl_scan<4>(__popc(w), red, tot);
+  if (threadIdx.x == 0) publish1(ch.agg, b, ch.epoch, tot);
+  const bool last = b == ch.n_tiles - 1;
+  if (tot == 0 && !last) return;
+  int before;
+  if (!lookback1(ch.agg, b, ch.epoch, red, before) && threadIdx.x == 0 && q.cnt) atomicOr(&q.cnt->error_flags, 2);
+  expand_bits(w, threadIdx.x * 32, rank, s_list);
+  __syncthreads();
+  const int t0 = b * (kCompactTileWords * 32);
+  for (int j = threadIdx.x; j < tot; j += 256) {
+    const int r = before + j;
+    if (r >= q.capacity) break;
+    const int t = t0 + s_list[j];
+    q.ids[r] = t;
+    const unsigned char ty = q.vis_type[t];
+    if ((ty & 0x80u) != q.gen) q.vis_type[t] = (unsigned char)(q.gen | (ty & 0x7fu));
+  }
+  if (last && threadIdx.x == 0) {
+    q.rc->no_visible = (before + tot) < q.capacity ? (before + tot) : q.capacity;
+    q.maint_flags[0] = 0;
+  }
+}
+
+// One launch, two independent jobs (each with its own ticket counter and its own channel of per-tile words): workgroups
+// [0, push_wgs) put the freed excess slots back and fold the removal pass into the pool counters; the others rebuild the
+// render state's visible list if the pass took an entry with a type.
+__global__ __launch_bounds__(256) void k_push_freed_and_rebuild(unsigned char *freed_flags, int n_excess, int *excess_list,
+                                                                SceneCounters *cnt, int count_as_slid, TileChain push_ch,
+                                                                int push_wgs, RebuildParams q, TileChain vis_ch) {
+  __shared__ int red[8];
+  __shared__ int s_ticket;
+  __shared__ unsigned short s_list[kCompactTileWords * 32];
+  if ((int)blockIdx.x < push_wgs) push_freed_job(freed_flags, n_excess, excess_list, cnt, count_as_slid, push_ch, red, s_ticket);
+  else rebuild_visible_job(q, vis_ch, red, s_ticket, s_list);
+}
 
 // scratch: candidate flags (table sized, overwritten whole by every selection), the lists
 struct MaintScratch {
@@ -351,19 +391,37 @@ static MaintScratch carve(dslam_engine *e, int N) {
   return m;
 }
 
-// force: the host knows the list has to be rebuilt (the swapping paths, after they changed types themselves); else only
-// if the release pipeline's flag says that an entry with a type went
-static int rebuild_visible_list(dslam_engine *e, dslam_render_state *r, bool force = true) {
-  SelRebuildVisible sel{r->visible_type, (unsigned)r->gen, e->maint_flags};
-  launch_bits_select(e, r->vis_bits, r->n_entries, sel, r->visible_ids, r->n_local, &r->counters->no_visible, nullptr,
-                     force ? nullptr : e->maint_flags);
+static RebuildParams rebuild_params(dslam_engine *e, dslam_render_state *r, bool force, SceneCounters *cnt) {
+  RebuildParams q;
+  q.vis_bits = r ? r->vis_bits : nullptr;
+  q.vis_type = r ? r->visible_type : nullptr;
+  q.ids = r ? r->visible_ids : nullptr;
+  q.capacity = r ? r->n_local : 0;
+  q.rc = r ? r->counters : nullptr;
+  q.maint_flags = e->maint_flags;
+  q.gen = r ? (unsigned)r->gen : 0u;
+  q.force = force ? 1 : 0;
+  q.cnt = cnt;
+  return q;
+}
+
+// the swapping paths call this after they have changed types themselves: the rebuild alone, forced -- it also takes the
+// "marked again" bit off entries that had not fitted into the last pass' list and are listed now
+static int rebuild_visible_list(dslam_engine *e, dslam_render_state *r) {
+  int grid;
+  const TileChain vis_ch = next_chain(e, bit_tiles(r->n_entries) * (kBitTileWords / kCompactTileWords), &grid, true);
+  TileChain push_ch = vis_ch;   // (no push job in this launch)
+  push_ch.n_tiles = 0;
+  hipLaunchKernelGGL(k_push_freed_and_rebuild, dim3(grid), dim3(256), 0, e->stream, (unsigned char *)nullptr, 0, (int *)nullptr,
+                     (SceneCounters *)nullptr, 0, push_ch, 0, rebuild_params(e, r, true, nullptr), vis_ch);
   dbg_sync(e, "rebuild_visible_list");
   DSLAM_HIP(hipGetLastError());
   return DSLAM_OK;
 }
 
 // the tail of a removal pass: m.rem_list[0 .. remove_count) (ascending entry index, flags set in m.rem_flags) ->
-// release + leaders, unlink, free-list pushes + counters, visible-list rebuild if a visible entry went
+// release + leaders, unlink, then ONE launch for the free-list pushes + counters and the visible-list rebuild (if a
+// visible entry went)
 static int release_listed(dslam_engine *e, dslam_scene *s, dslam_render_state *r, const MaintScratch &m, int count_as_slid) {
   hipLaunchKernelGGL(k_release_and_leaders, dim3(kReleaseWgs + kLeaderWgs), dim3(256), 0, e->stream, m.rem_list, s->counters,
                      s->hash, reinterpret_cast<uint4 *>(s->voxels), s->alloc_list, s->masks, s->last_seen, s->history_words,
@@ -373,23 +431,18 @@ static int release_listed(dslam_engine *e, dslam_scene *s, dslam_render_state *r
                      m.rem_flags, m.freed_flags, r ? r->visible_type : (unsigned char *)nullptr,
                      r ? r->vis_bits : (unsigned *)nullptr, s->alloc_bits, e->maint_flags, (r && !r->types_follow_list) ? 1 : 0);
   dbg_sync(e, "k_unlink");
-  if (getenv("DSLAM_DEBUG_SYNC")) {
-    unsigned tk = 0;
-    SceneCounters sc;
-    (void)hipMemcpy(&tk, e->ticket, 4, hipMemcpyDeviceToHost);
-    (void)hipMemcpy(&sc, s->counters, sizeof(sc), hipMemcpyDeviceToHost);
-    fprintf(stderr, "[dslam] ticket dev %u host %u  remove_count %d last_free %d last_free_ex %d err %d epoch %u\n", tk, e->ticket_base,
-            sc.remove_count, sc.last_free, sc.last_free_ex, sc.error_flags, e->epoch);
-  }
   {
-    int grid;
-    const TileChain ch = next_chain(e, (s->p.num_excess + kSweepTile - 1) / kSweepTile, &grid);
-    hipLaunchKernelGGL(k_push_freed_finalize, dim3(grid), dim3(256), 0, e->stream, m.freed_flags, s->p.num_excess,
-                       s->excess_list, s->counters, count_as_slid, ch);
+    int push_grid, vis_grid = 0;
+    const TileChain push_ch = next_chain(e, (s->p.num_excess + kSweepTile - 1) / kSweepTile, &push_grid);
+    TileChain vis_ch = push_ch;
+    vis_ch.n_tiles = 0;
+    if (r) vis_ch = next_chain(e, bit_tiles(r->n_entries) * (kBitTileWords / kCompactTileWords), &vis_grid, true);
+    hipLaunchKernelGGL(k_push_freed_and_rebuild, dim3(push_grid + vis_grid), dim3(256), 0, e->stream, m.freed_flags,
+                       s->p.num_excess, s->excess_list, s->counters, count_as_slid, push_ch, push_grid,
+                       rebuild_params(e, r, false, s->counters), vis_ch);
   }
-  dbg_sync(e, "k_push_freed_finalize");
+  dbg_sync(e, "k_push_freed_and_rebuild");
   DSLAM_HIP(hipGetLastError());
-  if (r) return rebuild_visible_list(e, r, false);
   return DSLAM_OK;
 }
 
