@@ -324,6 +324,18 @@ class CApi:
         self._call("deprocess_frame_stored", self._engine, scene.ptr, view.ptr, fs.ptr, C.c_int(slot), _fptr(m), _fptr(k),
                    _fptr(mr), _fptr(kr))
 
+    def reintegrate_batch(self, scene, view, rs, fs, slots, old_Ms, new_Ms, intr, affine_a=1.0 / 1000.0, affine_b=0.0):
+        """DenseSlam::OnlineCorrection's loop (DenseSlam.cpp:389-403) over keyframes of a store as ONE call: equal to
+        view_update_from_store + deprocess_frame_stored(old pose) + process_frame(new pose, is_defusion) +
+        frame_store_put_visible_list per keyframe; the HIP engine runs it block-major (each touched block loaded once)."""
+        n = len(slots)
+        sl = np.ascontiguousarray(slots, dtype=np.int32)
+        om = np.ascontiguousarray(np.stack([mat_to_abi(m) for m in old_Ms]) if n else np.zeros((0, 16)), dtype=np.float32)
+        nm = np.ascontiguousarray(np.stack([mat_to_abi(m) for m in new_Ms]) if n else np.zeros((0, 16)), dtype=np.float32)
+        k = np.ascontiguousarray(intr, dtype=np.float32)
+        self._call("reintegrate_batch", self._engine, scene.ptr, view.ptr, rs.ptr, fs.ptr, C.c_int(n), _vptr(sl), _fptr(om), _fptr(nm),
+                   _fptr(k), C.c_float(affine_a), C.c_float(affine_b))
+
     def view_update_from_store(self, view, fs, slot, affine_a=1.0 / 1000.0, affine_b=0.0, timestamp=0.0, bilateral=False):
         self._call("view_update_from_store", self._engine, view.ptr, fs.ptr, C.c_int(slot), C.c_float(affine_a),
                    C.c_float(affine_b), C.c_double(timestamp), C.c_int(int(bilateral)))

@@ -366,6 +366,8 @@ struct SweepParams {
   const unsigned *q1, *q2, *mark, *retest;   // this pass
   unsigned *oq1, *oq2, *omark;               // the other set: zeroed here for the next pass
   unsigned *vis_bits, *alloc_bits;
+  int *born;        // (re-integration batch) per voxel-block slot: which pass allocated it; null otherwise
+  int born_stamp;
   unsigned long long *agg_req, *agg_vis;
   unsigned epoch;
   unsigned *ticket;
@@ -555,8 +557,10 @@ __global__ __launch_bounds__(256) void k_alloc_sweep(SweepParams p) {
           if (!is2) {
             const bool ok = p.do_commit && vr < avail_vba;
             if (ok) {
-              store_entry(p.hash, t, bc.x, bc.y, bc.z, 0, p.alloc_list[base_free - vr]);
+              const int slot = p.alloc_list[base_free - vr];
+              store_entry(p.hash, t, bc.x, bc.y, bc.z, 0, slot);
               bit_set(p.alloc_bits, t);
+              if (p.born) p.born[slot] = p.born_stamp;
             }
             // without the commit (onlyUpdateVisibleList) the request alone makes the entry "visible" this pass, like
             // upstream; with it, only if it got a block
@@ -570,9 +574,11 @@ __global__ __launch_bounds__(256) void k_alloc_sweep(SweepParams p) {
           } else {
             if (p.do_commit && k2 < avail_ex && vr < avail_vba) {
               const int ex_off = p.excess_list[base_free_ex - k2];
+              const int slot = p.alloc_list[base_free - vr];
               p.hash[t].offset = ex_off + 1;
-              store_entry(p.hash, p.num_buckets + ex_off, bc.x, bc.y, bc.z, 0, p.alloc_list[base_free - vr]);
+              store_entry(p.hash, p.num_buckets + ex_off, bc.x, bc.y, bc.z, 0, slot);
               bit_set(p.alloc_bits, p.num_buckets + ex_off);
+              if (p.born) p.born[slot] = p.born_stamp;
               // (its type byte and its place in the visible list are the business of the tile that owns the new entry)
             }
             k2++;
@@ -836,6 +842,7 @@ int launch_allocate(dslam_engine *e, dslam_scene *s, const dslam_view *v, dslam_
   sp.q1 = mp.q1; sp.q2 = mp.q2; sp.mark = mp.mark; sp.retest = e->bits_retest;
   sp.oq1 = e->bits_q1[oth]; sp.oq2 = e->bits_q2[oth]; sp.omark = e->bits_mark[oth];
   sp.vis_bits = r->vis_bits; sp.alloc_bits = s->alloc_bits;
+  sp.born = s->alloc_born; sp.born_stamp = s->alloc_born_stamp;
   sp.agg_req = e->agg; sp.agg_vis = e->agg + e->agg_tiles;
   if (++e->epoch == 0) e->epoch = 1;
   sp.epoch = e->epoch;

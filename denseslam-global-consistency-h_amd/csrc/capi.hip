@@ -387,6 +387,9 @@ int dslam_scene_destroy(dslam_scene *s) {
   free_dev(s->alloc_list); free_dev(s->excess_list); free_dev(s->last_seen); free_dev(s->masks); free_dev(s->counters);
   free_dev(s->swap_state); free_dev(s->slab_ptrs_dev); free_dev(s->alloc_bits); free_dev(s->swap1_bits);
   free_dev(s->dirty); free_dev(s->dirty_list); free_dev(s->dirty_counts);
+  free_dev(s->batch_born); free_dev(s->batch_opmask); free_dev(s->batch_slot_entry); free_dev(s->batch_list); free_dev(s->batch_counters);
+  if (s->batch_ops_dev) (void)hipFree(s->batch_ops_dev);
+  if (s->batch_lists_dev) (void)hipFree(s->batch_lists_dev);
   for (uint4 *slab : s->slabs) (void)hipHostFree(slab);
   if (s->next_slot_host) (void)hipHostFree(s->next_slot_host);
   free_dev(s->slot_dev);
@@ -788,7 +791,7 @@ int dslam_frame_store_create(dslam_engine *e, int w_rgb, int h_rgb, int w_d, int
 int dslam_frame_store_destroy(dslam_frame_store *fs) {
   if (!fs) return DSLAM_OK;
   (void)hipStreamSynchronize(fs->engine->stream);
-  free_dev(fs->rgba); free_dev(fs->depth); free_dev(fs->lists);
+  free_dev(fs->rgba); free_dev(fs->depth); free_dev(fs->lists); free_dev(fs->batch_lists);
   delete fs;
   return DSLAM_OK;
 }
@@ -870,10 +873,14 @@ int dslam_frame_store_enable_lists(dslam_engine *e, dslam_frame_store *fs, const
   fs->list_bytes = (kListHeader + (size_t)fs->list_cap * (sizeof(int) + sizeof(short4)) + 255) & ~(size_t)255;
   DSLAM_HIP(hipMalloc(&fs->lists, fs->list_bytes * fs->capacity));
   fs->has_list.assign(fs->capacity, 0);
+  fs->list_ptr.resize(fs->capacity);
+  for (int i = 0; i < fs->capacity; i++) fs->list_ptr[i] = fs->lists + fs->list_bytes * i;
+  free_dev(fs->batch_lists);   // (sized for the old lists)
+  fs->batch_list_ptr.clear();
   return DSLAM_OK;
 }
 
-static unsigned char *list_slot(const dslam_frame_store *fs, int slot) { return fs->lists + fs->list_bytes * slot; }
+static unsigned char *list_slot(const dslam_frame_store *fs, int slot) { return fs->list_ptr[slot]; }
 
 int dslam_frame_store_put_visible_list(dslam_engine *e, dslam_frame_store *fs, int slot, const dslam_scene *s,
                                        const dslam_render_state *r) {
@@ -902,6 +909,113 @@ int dslam_deprocess_frame_stored(dslam_engine *e, dslam_scene *s, const dslam_vi
                              reinterpret_cast<const short4 *>(base + kListHeader + (size_t)fs->list_cap * sizeof(int)), M_d, intr_d,
                              M_rgb, intr_rgb, true);
   if (rc) return rc;
+  return finish_call(e);
+}
+
+// ---- the re-integration batch, block-major (integrate.hip) ---------------------------------------------------------------
+namespace {
+constexpr int kBatchMax = 32;   // keyframes per launch of the block kernel: two operation bits each in a 64-bit mask
+struct HostBatchOp {            // = BatchOp (integrate.hip)
+  float M[16];
+  const void *raw, *rgba;
+  int push_bit, push_frame, pad[2];
+};
+struct HostBatchList {          // = BatchListRef
+  const void *count, *ids, *pos;
+};
+}  // namespace
+
+static int batch_scratch(dslam_engine *e, dslam_scene *s, dslam_frame_store *fs) {
+  const size_t L = (size_t)s->p.num_local_blocks;
+  if (!s->batch_born) {
+    DSLAM_HIP(hipMalloc(&s->batch_born, L * sizeof(int)));
+    DSLAM_HIP(hipMalloc(&s->batch_opmask, L * sizeof(unsigned long long)));
+    DSLAM_HIP(hipMalloc(&s->batch_slot_entry, L * sizeof(int)));
+    DSLAM_HIP(hipMalloc(&s->batch_list, L * sizeof(int)));
+    DSLAM_HIP(hipMalloc(&s->batch_counters, 4 * sizeof(int)));
+    DSLAM_HIP(hipMalloc(&s->batch_ops_dev, 2 * kBatchMax * sizeof(HostBatchOp)));
+    DSLAM_HIP(hipMalloc(&s->batch_lists_dev, 2 * kBatchMax * sizeof(HostBatchList)));
+  }
+  if (!fs->batch_lists) {
+    DSLAM_HIP(hipMalloc(&fs->batch_lists, fs->list_bytes * kBatchMax));
+    fs->batch_list_ptr.resize(kBatchMax);
+    for (int i = 0; i < kBatchMax; i++) fs->batch_list_ptr[i] = fs->batch_lists + fs->list_bytes * i;
+  }
+  (void)e;
+  return DSLAM_OK;
+}
+
+int dslam_reintegrate_batch(dslam_engine *e, dslam_scene *s, dslam_view *v, dslam_render_state *r, dslam_frame_store *fs,
+                            int n, const int32_t *slots, const float *old_M, const float *new_M, const float intr[4],
+                            float affine_a, float affine_b) {
+  DSLAM_REQUIRE(e && s && v && r && fs && slots && old_M && new_M && intr && n >= 0, "null argument");
+  DSLAM_REQUIRE(s->engine == e && v->engine == e && r->engine == e && fs->engine == e, "objects belong to a different engine");
+  DSLAM_REQUIRE(fs->lists, "dslam_frame_store_enable_lists has not been called");
+  DSLAM_REQUIRE(v->w_rgb == fs->w_rgb && v->h_rgb == fs->h_rgb && v->w_d == fs->w_d && v->h_d == fs->h_d, "view and frame store sizes differ");
+  if (s->p.use_swapping || s->p.stop_integrating_at_max_w || v->w_rgb != v->w_d || v->h_rgb != v->h_d) {
+    set_last_error("dslam_reintegrate_batch: scenes with host swapping or stopIntegratingAtMaxW and views with a separate colour "
+                   "camera take the per-keyframe calls (dslam_deprocess_frame_stored + dslam_process_frame)");
+    return DSLAM_ERR_UNSUPPORTED;
+  }
+  for (int k = 0; k < n; k++) {
+    DSLAM_REQUIRE(slots[k] >= 0 && slots[k] < fs->capacity, "frame store slot out of range");
+    DSLAM_REQUIRE(fs->has_list[slots[k]], "no visible list was stored for a keyframe of the batch");
+    for (int j = 0; j < k; j++) DSLAM_REQUIRE(slots[j] != slots[k], "a keyframe appears twice in the batch");
+  }
+  if (n == 0) return DSLAM_OK;
+  int rc = batch_scratch(e, s, fs);
+  if (rc) return rc;
+  e->view_reads++;  // (see dslam_engine::last_fence)
+  s->version = next_map_version();  // the map changes: GetImage memos of this scene are stale
+  r->memo_valid = false;
+  const size_t L = (size_t)s->p.num_local_blocks;
+  const size_t ids_off = kListHeader, pos_off = kListHeader + (size_t)fs->list_cap * sizeof(int);
+  for (int first = 0; first < n; first += kBatchMax) {
+    const int K = (n - first) < kBatchMax ? (n - first) : kBatchMax;
+    DSLAM_HIP(hipMemsetAsync(s->batch_born, 0, L * sizeof(int), e->stream));
+    DSLAM_HIP(hipMemsetAsync(s->batch_opmask, 0, L * sizeof(unsigned long long), e->stream));
+    DSLAM_HIP(hipMemsetAsync(s->batch_counters, 0, 4 * sizeof(int), e->stream));
+    std::vector<HostBatchOp> ops(2 * K);
+    std::vector<HostBatchList> lists(2 * K);
+    // phase 1: the allocation passes of the K re-fusions, in keyframe order (they read the table and the keyframes' depth
+    // images, not the voxels); every pass' list goes to a scratch buffer, the blocks it allocates are stamped
+    s->alloc_born = s->batch_born;
+    for (int k = 0; k < K; k++) {
+      const int slot = slots[first + k];
+      const void *rgba = fs->rgba + fs->rgba_bytes * slot, *raw = fs->depth + fs->depth_bytes * slot;
+      if ((rc = launch_view_convert(e, v, rgba, raw, affine_a, affine_b))) break;
+      s->alloc_born_stamp = k + 1;
+      if ((rc = launch_allocate(e, s, v, r, new_M + 16 * (size_t)(first + k), intr, 0))) break;
+      int bit = 0, frame = 0;
+      if ((rc = prepare_push_visible_list(e, s, 1, &bit, &frame))) break;   // (ProcessFrame(isDefusion) queues on ring 1)
+      unsigned char *nb = fs->batch_list_ptr[k];
+      if ((rc = launch_store_visible_list(e, s, r, nb, reinterpret_cast<int *>(nb + ids_off), reinterpret_cast<short4 *>(nb + pos_off),
+                                          fs->list_cap)))
+        break;
+      const unsigned char *ob = list_slot(fs, slot);
+      HostBatchOp &d = ops[2 * k], &f = ops[2 * k + 1];
+      memcpy(d.M, old_M + 16 * (size_t)(first + k), 64);
+      memcpy(f.M, new_M + 16 * (size_t)(first + k), 64);
+      d.raw = f.raw = raw; d.rgba = f.rgba = rgba;
+      d.push_bit = d.push_frame = 0; f.push_bit = bit; f.push_frame = frame;
+      lists[2 * k] = {ob, ob + ids_off, ob + pos_off};
+      lists[2 * k + 1] = {nb, nb + ids_off, nullptr};
+    }
+    s->alloc_born = nullptr;
+    if (rc) return rc;
+    // phase 2: which operations touch which block, then every touched block once
+    DSLAM_HIP(hipMemcpyAsync(s->batch_ops_dev, ops.data(), ops.size() * sizeof(HostBatchOp), hipMemcpyHostToDevice, e->stream));
+    DSLAM_HIP(hipMemcpyAsync(s->batch_lists_dev, lists.data(), lists.size() * sizeof(HostBatchList), hipMemcpyHostToDevice, e->stream));
+    DSLAM_HIP(hipStreamSynchronize(e->stream));   // (the sources are vectors of this scope)
+    if ((rc = launch_batch_ops(e, s->batch_lists_dev, 2 * K, s, s->batch_born, s->batch_opmask, s->batch_slot_entry, s->batch_list,
+                               s->batch_counters)))
+      return rc;
+    if ((rc = launch_reintegrate_blocks(e, s, v->w_d, v->h_d, v->w_rgb, v->h_rgb, intr, affine_a, affine_b, s->batch_ops_dev,
+                                        s->batch_opmask, s->batch_slot_entry, s->batch_list, s->batch_counters, s->batch_counters + 1, 1)))
+      return rc;
+    // the lists of the re-fusions become the keyframes' stored lists: the buffers trade places
+    for (int k = 0; k < K; k++) std::swap(fs->list_ptr[slots[first + k]], fs->batch_list_ptr[k]);
+  }
   return finish_call(e);
 }
 

@@ -157,6 +157,16 @@ struct dslam_scene {
   bool dirty_tracking = false;
   int *dirty_list = nullptr;            // device [num_local_blocks]: the dirty slots in virtual (shard-major) order
   int *dirty_counts = nullptr;          // device [128]: per shard its number of dirty slots (+ scratch)
+  // block-major re-integration batch (dslam_reintegrate_batch): per voxel-block slot the re-fusion pass of the batch that
+  // allocated it (0: it existed before), which operations of the batch touch it, an entry that holds it; the list of
+  // touched slots; [0] its length, [1] the work cursor.  alloc_born / alloc_born_stamp: the allocation sweep stamps the
+  // blocks it commits while a batch is being planned
+  int *batch_born = nullptr;
+  unsigned long long *batch_opmask = nullptr;
+  int *batch_slot_entry = nullptr, *batch_list = nullptr, *batch_counters = nullptr;
+  void *batch_ops_dev = nullptr, *batch_lists_dev = nullptr;
+  int *alloc_born = nullptr;
+  int alloc_born_stamp = 0;
   int dirty_shards = 0, dirty_chunk = 0;  // the layout of the last dslam_shard_dirty_plan
 };
 
@@ -243,6 +253,11 @@ struct dslam_frame_store {
   int list_cap = 0;
   size_t list_bytes = 0;  // per slot
   std::vector<unsigned char> has_list;
+  // where each slot's list lives: a buffer of `lists`, or -- after a re-integration batch, which writes the lists of its
+  // re-fusions to scratch buffers and then trades buffers instead of copying -- one of `batch_lists`
+  std::vector<unsigned char *> list_ptr;
+  unsigned char *batch_lists = nullptr;          // 32 more list buffers (allocated by the first batch)
+  std::vector<unsigned char *> batch_list_ptr;
 };
 
 namespace dslam {
@@ -279,6 +294,11 @@ int launch_integrate_list(dslam_engine *e, dslam_scene *s, const dslam_view *v, 
                           const float *intr_rgb, bool deintegrate);
 int launch_store_visible_list(dslam_engine *e, const dslam_scene *s, const dslam_render_state *r, void *header, int *ids,
                               short4 *pos, int capacity);
+int launch_batch_ops(dslam_engine *e, const void *lists_dev, int n_ops, const dslam_scene *s, const int *born,
+                     unsigned long long *opmask, int *slot_entry, int *dirty_list, int *dirty_count);
+int launch_reintegrate_blocks(dslam_engine *e, dslam_scene *s, int w_d, int h_d, int w_rgb, int h_rgb, const float *intr,
+                              float a, float b, const void *ops_dev, const unsigned long long *opmask, const int *slot_entry,
+                              const int *dirty_list, const int *dirty_count, int *cursor, int push_ring);
 int ensure_view_depth(dslam_engine *e, const dslam_view *v);
 int launch_selftest_division(dslam_engine *e, long long samples, unsigned long long *mismatches_dev);
 int prepare_push_visible_list(dslam_engine *e, dslam_scene *s, int q, int *bit_out, int *frame_out);

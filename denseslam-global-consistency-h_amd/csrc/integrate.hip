@@ -946,6 +946,284 @@ int launch_integrate_list(dslam_engine *e, dslam_scene *s, const dslam_view *v, 
   return launch_integrate_params(e, ip, deintegrate);
 }
 
+// =========================================================================================================================
+// Block-major re-integration batch (dslam_reintegrate_batch)
+// =========================================================================================================================
+// Reference: DenseSlam::OnlineCorrection's loop (DenseSlam.cpp:389-403): for every corrected keyframe k, DeProcessFrame at
+// its old pose, then ProcessFrame at the new one.  Run as written that is 2 K launches of k_integrate which each stream
+// every visible block through HBM again: 32 keyframes visit ~512 k blocks (4.2 GB) of which 34 k are distinct (0.28 GB).
+// A voxel's value depends only on its own history, so the batch is re-ordered BLOCK-major: the allocation passes of all K
+// re-fusions run first, in keyframe order (they do not read voxels); then ONE launch takes every block the batch touches,
+// loads its 4 KiB once, applies -- in keyframe order -- the de- and re-updates of every keyframe whose list names it, and
+// stores it once.  Per voxel the sequence of operations is the one of the loop above: the result is bit-identical.
+//   opmask[slot]   bit 2k: de-integration of keyframe k applies to the block in this slot (its stored fusion-time list
+//                  names an entry that still holds the block, and the block existed before re-fusion k allocated);
+//                  bit 2k + 1: the re-fusion of keyframe k lists it
+//   ops[2k], ops[2k + 1]   pose and images of the two operations
+// A wave fetches its next block from a device counter (blocks differ in how many operations they take).
+struct BatchOp {
+  Mat4 M;                // world -> camera of this operation (old pose: de-integration, new pose: re-fusion)
+  const short *raw;      // the keyframe's int16 depth image (the float value is derived per read, like UpdateView does)
+  const uchar4 *rgba;
+  int push_bit, push_frame;  // re-fusions: the ring bit and frame stamp ProcessFrame(isDefusion) queues the block with
+  int pad[2];
+};
+
+struct BatchParams {
+  IntegrateParams ip;    // what does not change over the batch (intrinsics, mu, sizes, weights, shard, rings ...)
+  const BatchOp *ops;
+  const unsigned long long *opmask;
+  const int *slot_entry;  // per slot: a hash entry that holds it (its block position)
+  const int *dirty_list;  // slots with a non-zero opmask (any order)
+  const int *dirty_count;
+  int *cursor;
+  float a, b;             // depth = raw * a + b
+  int raw_bytes;
+};
+
+// pair_project with the depth pixel derived from the int16 image: (r <= 0 || r > 32000) ? -1 : r * a + b, the conversion of
+// k_mark / k_convert_depth (same operations, same bits).  The halfword comes out of the dword that holds it.
+__device__ __forceinline__ float raw_depth_at(__amdgpu_buffer_rsrc_t raw_rs, int x, int y, int W, float a, float b) {
+  const unsigned off = ((unsigned)__mul24(y, W) + (unsigned)x) << 1;
+  const unsigned w32 = __builtin_amdgcn_raw_buffer_load_b32(raw_rs, off & ~3u, 0, 0);
+  const int r = (int)(short)((off & 2u) ? (w32 >> 16) : (w32 & 0xffffu));
+  return (r <= 0 || r > 32000) ? -1.0f : (float)r * a + b;
+}
+
+__device__ __forceinline__ void pair_project_raw(PairProj &q, f2 pcx, f2 pcy, f2 pcz, const IntegrateParams &p,
+                                                 __amdgpu_buffer_rsrc_t raw_rs, float a, float b) {
+  const f2 fx2 = {p.fx_d, p.fx_d}, fy2 = {p.fy_d, p.fy_d}, cx2 = {p.cx_d, p.cx_d}, cy2 = {p.cy_d, p.cy_d};
+  q.pcz = pcz;
+  q.u = div_ieee2(fx2 * pcx, pcz) + cx2;
+  q.w = div_ieee2(fy2 * pcy, pcz) + cy2;
+  const float wmax = (float)(p.Wd - 2), hmax = (float)(p.Hd - 2);
+  q.act0 = (pcz.x >= kMinCamZ) & in_image(q.u.x, q.w.x, wmax, hmax);
+  q.act1 = (pcz.y >= kMinCamZ) & in_image(q.u.y, q.w.y, wmax, hmax);
+  const f2 half = {0.5f, 0.5f};
+  const f2 ur = q.u + half, wr = q.w + half;
+  // (a voxel that failed a test may produce any pixel index: its read stays inside the buffer resource or returns 0)
+  q.dm.x = q.act0 ? raw_depth_at(raw_rs, (int)ur.x, (int)wr.x, p.Wd, a, b) : 0.0f;
+  q.dm.y = q.act1 ? raw_depth_at(raw_rs, (int)ur.y, (int)wr.y, p.Wd, a, b) : 0.0f;
+}
+
+struct BatchColQueue {   // (the colour queue of k_integrate: one per wave)
+  float u[kColQueue], w[kColQueue];
+  unsigned c[kColQueue], r[kColQueue];
+  unsigned char list[kColQueue];
+};
+
+// one operation on one half block (two 16-byte chunks per lane): k_integrate's packed path -- projection, depth update on
+// 2-vectors, narrow-band colour updates queued in LDS and run densely -- with the operation's own pose and images
+template <bool DEINT>
+__device__ __forceinline__ void batch_half(uint4 (&v)[2], bool (&chs)[2], int half, int gz, int vz0, const float (&pxy)[2][3],
+                                           const Mat4 &M, const IntegrateParams &p, __amdgpu_buffer_rsrc_t raw_rs, float a, float b,
+                                           const float *inv_tab, BatchColQueue &Q, int lane) {
+  int q_n = 0;
+  unsigned cms[2] = {0u, 0u};
+#pragma unroll
+  for (int jj = 0; jj < 2; jj++) {
+    const float fz = (float)(gz + (half * 2 + jj) * 2 + vz0) * p.voxel_size;
+    const float az0 = M.m[8] * fz, az1 = M.m[9] * fz, az2 = M.m[10] * fz;
+    const f2 a0 = {az0, az0}, a1 = {az1, az1}, a2 = {az2, az2};
+    const f2 t0 = {M.m[12], M.m[12]}, t1 = {M.m[13], M.m[13]}, t2 = {M.m[14], M.m[14]};
+    const f2 px = {pxy[0][0], pxy[1][0]}, py = {pxy[0][1], pxy[1][1]}, pz = {pxy[0][2], pxy[1][2]};
+    PairProj q;
+    pair_project_raw(q, (px + a0) + t0, (py + a1) + t1, (pz + a2) + t2, p, raw_rs, a, b);
+    unsigned cm;
+    chs[jj] |= pair_update<DEINT, false>(v[jj], q, p, inv_tab, cm);
+    cms[jj] = cm;
+    if (__ballot(cm != 0u)) {
+#pragma unroll
+      for (int h = 0; h < 2; h++) {
+        const bool c = (cm >> h) & 1u;
+        const unsigned long long bm = __ballot(c);
+        if (c) {
+          const unsigned lo = h ? v[jj].z : v[jj].x, hi = h ? v[jj].w : v[jj].y;
+          const int own = (jj * 2 + h) * 64 + lane;
+          const int slot = q_n + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(bm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bm, 0u));
+          Q.u[own] = h ? q.u.y : q.u.x;
+          Q.w[own] = h ? q.w.y : q.w.x;
+          Q.c[own] = __builtin_amdgcn_perm(hi, lo, 0x06050403u);
+          Q.list[slot] = (unsigned char)own;
+        }
+        q_n += __popcll(bm);
+      }
+    }
+  }
+  if (q_n > 0) {
+    __builtin_amdgcn_wave_barrier();
+    for (int i = lane; i < q_n; i += 64) {
+      const int o = Q.list[i];
+      if constexpr (DEINT) Q.r[o] = defuse_colour_word<false>(Q.c[o], Q.u[o], Q.w[o], p, inv_tab);
+      else Q.r[o] = fuse_colour_word<false>(Q.c[o], Q.u[o], Q.w[o], p, inv_tab);
+    }
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int jj = 0; jj < 2; jj++)
+#pragma unroll
+      for (int h = 0; h < 2; h++)
+        if ((cms[jj] >> h) & 1u) {
+          const unsigned word = Q.r[(jj * 2 + h) * 64 + lane];
+          unsigned &lo = h ? v[jj].z : v[jj].x;
+          unsigned &hi = h ? v[jj].w : v[jj].y;
+          lo = __builtin_amdgcn_perm(word, lo, 0x04020100u);
+          hi = __builtin_amdgcn_perm(hi, word, 0x07030201u);
+        }
+    __builtin_amdgcn_wave_barrier();   // (the queue is refilled by the next half)
+  }
+}
+
+constexpr int kBatchWgWaves = 8;
+constexpr int kBatchGrid = 1024;   // 8192 waves: one full residency wave; blocks are fetched from a counter
+
+__global__ __launch_bounds__(kBatchWgWaves * 64) void k_reintegrate_blocks(BatchParams bp) {
+  __shared__ float inv_tab[kInvTab];
+  __shared__ BatchColQueue col_q[kBatchWgWaves];
+  for (int i = threadIdx.x; i < kInvTab; i += kBatchWgWaves * 64) inv_tab[i] = recip_table_entry(i);
+  __syncthreads();
+  const IntegrateParams &p0 = bp.ip;
+  const int lane = threadIdx.x & 63;
+  BatchColQueue &Q = col_q[threadIdx.x >> 6];
+  const int n = bp.dirty_count[0];
+  const int vx0 = (lane & 3) * 2, vy = (lane >> 2) & 7, vz0 = lane >> 5;
+  while (true) {
+    int i = 0;
+    if (lane == 0) i = atomicAdd(bp.cursor, 1);
+    i = __builtin_amdgcn_readfirstlane(i);
+    if (i >= n) break;
+    const int ptr = __builtin_amdgcn_readfirstlane(bp.dirty_list[i]);
+    const unsigned long long mask = bp.opmask[ptr];
+    // (before the shard test, as in k_integrate: every rank of a sharded batch ends up with the same marks and the same
+    // rings) the block joins the list of every re-fusion that names it on the defusion ring
+    if (lane == 0) {
+      if (p0.dirty) p0.dirty[ptr] = 1;
+      if (p0.push_words) {
+        unsigned long long *ring = p0.masks + ((size_t)ptr * 2 + p0.push_ring) * p0.push_words;
+        int frame = -1;
+        for (unsigned long long m = mask & 0xAAAAAAAAAAAAAAAAull; m; m &= m - 1) {
+          const BatchOp &op = bp.ops[__ffsll((long long)m) - 1];
+          ring[op.push_bit >> 6] |= 1ull << (op.push_bit & 63);
+          frame = op.push_frame;   // (ascending: the last re-fusion that lists the block)
+        }
+        if (frame >= 0) p0.last_seen[ptr] = frame;
+      }
+    }
+    if (p0.num_shards > 1 && ((ptr / p0.chunk_blocks) % p0.num_shards) != p0.shard) continue;
+    if (p0.shard_count >= 0 && (ptr < p0.shard_first || ptr >= p0.shard_first + p0.shard_count)) continue;
+    const HashEntry e = load_entry(p0.hash, bp.slot_entry[ptr]);
+    const int gx = __builtin_amdgcn_readfirstlane((int)e.pos[0]) * kBlock, gy = __builtin_amdgcn_readfirstlane((int)e.pos[1]) * kBlock,
+              gz = __builtin_amdgcn_readfirstlane((int)e.pos[2]) * kBlock;
+    uint4 *blk = p0.voxels16 + (size_t)ptr * (kBlock3 / 2);
+    uint4 va[2], vb[2];   // the two halves of the block
+    va[0] = blk[lane]; va[1] = blk[64 + lane]; vb[0] = blk[128 + lane]; vb[1] = blk[192 + lane];
+    bool cha[2] = {false, false}, chb[2] = {false, false};
+    const float fyv = (float)(gy + vy) * p0.voxel_size;
+    float fxv[2];
+    fxv[0] = (float)(gx + vx0) * p0.voxel_size;
+    fxv[1] = (float)(gx + vx0 + 1) * p0.voxel_size;
+    unsigned mlo = (unsigned)mask, mhi = (unsigned)(mask >> 32);
+    for (int part = 0; part < 2; part++) {
+      for (unsigned m = part ? mhi : mlo; m; m &= m - 1) {
+        const int bit = __builtin_amdgcn_readfirstlane(part * 32 + __ffs((int)m) - 1);
+        const BatchOp &op = bp.ops[bit];
+        IntegrateParams p = p0;
+        p.rgba = op.rgba;
+        const Mat4 &M = op.M;
+        float pxy[2][3];
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+          pxy[h][0] = M.m[0] * fxv[h] + M.m[4] * fyv;
+          pxy[h][1] = M.m[1] * fxv[h] + M.m[5] * fyv;
+          pxy[h][2] = M.m[2] * fxv[h] + M.m[6] * fyv;
+        }
+        const __amdgpu_buffer_rsrc_t raw_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<short *>(op.raw), 0, bp.raw_bytes, 0x00020000);
+        if (bit & 1) {   // re-fusion at the new pose; the block joins the keyframe's list on the defusion ring
+          batch_half<false>(va, cha, 0, gz, vz0, pxy, M, p, raw_rs, bp.a, bp.b, inv_tab, Q, lane);
+          batch_half<false>(vb, chb, 1, gz, vz0, pxy, M, p, raw_rs, bp.a, bp.b, inv_tab, Q, lane);
+        } else {         // de-integration at the old pose
+          batch_half<true>(va, cha, 0, gz, vz0, pxy, M, p, raw_rs, bp.a, bp.b, inv_tab, Q, lane);
+          batch_half<true>(vb, chb, 1, gz, vz0, pxy, M, p, raw_rs, bp.a, bp.b, inv_tab, Q, lane);
+        }
+      }
+    }
+    if (cha[0]) blk[lane] = va[0];
+    if (cha[1]) blk[64 + lane] = va[1];
+    if (chb[0]) blk[128 + lane] = vb[0];
+    if (chb[1]) blk[192 + lane] = vb[1];
+  }
+}
+
+// Which operations touch which block.  One workgroup row per operation (blockIdx.y = 2k / 2k + 1), lanes over that
+// operation's list: the keyframe's stored fusion-time list (de-integration; entries that no longer hold that block, or
+// whose block the batch itself allocated at or after re-fusion k, are skipped -- what dslam_deprocess_frame_stored would
+// have found at that point of the sequence) or the list the re-fusion's allocation pass left (kept in the batch's scratch).
+struct BatchListRef {
+  const RenderCounters *count;   // header of the list (no_visible = its length)
+  const int *ids;
+  const short4 *pos;             // stored lists: the block each entry held at fusion time; null: a fresh list
+};
+__global__ __launch_bounds__(256) void k_batch_ops(const BatchListRef *__restrict__ lists, const HashEntry *__restrict__ hash,
+                                                   const int *__restrict__ born, unsigned long long *opmask, int *slot_entry,
+                                                   int *dirty_list, int *dirty_count) {
+  const int op = blockIdx.y, k = op >> 1;
+  const BatchListRef L = lists[op];
+  const int n = L.count->no_visible;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+    const int t = L.ids[i];
+    const HashEntry e = load_entry(hash, t);
+    if (e.ptr < 0) continue;
+    if (L.pos) {
+      const short4 ep = L.pos[i];
+      if (ep.x != e.pos[0] || ep.y != e.pos[1] || ep.z != e.pos[2]) continue;
+      if (born[e.ptr] > k) continue;   // allocated by re-fusion k or a later one: did not exist when keyframe k was de-integrated
+    }
+    const unsigned long long old = atomicOr(&opmask[e.ptr], 1ull << op);
+    if (old == 0) {   // first operation on this block: it joins the batch's block list
+      slot_entry[e.ptr] = t;
+      dirty_list[atomicAdd(dirty_count, 1)] = e.ptr;
+    }
+  }
+}
+
+int launch_batch_ops(dslam_engine *e, const void *lists_dev, int n_ops, const dslam_scene *s, const int *born,
+                     unsigned long long *opmask, int *slot_entry, int *dirty_list, int *dirty_count) {
+  hipLaunchKernelGGL(k_batch_ops, dim3(32, n_ops), dim3(256), 0, e->stream, reinterpret_cast<const BatchListRef *>(lists_dev), s->hash,
+                     born, opmask, slot_entry, dirty_list, dirty_count);
+  DSLAM_HIP(hipGetLastError());
+  return DSLAM_OK;
+}
+
+int launch_reintegrate_blocks(dslam_engine *e, dslam_scene *s, int w_d, int h_d, int w_rgb, int h_rgb, const float *intr,
+                              float a, float b, const void *ops_dev, const unsigned long long *opmask, const int *slot_entry,
+                              const int *dirty_list, const int *dirty_count, int *cursor, int push_ring) {
+  BatchParams bp;
+  IntegrateParams &ip = bp.ip;
+  memset(&ip, 0, sizeof(ip));
+  ip.hash = s->hash;
+  ip.voxels16 = reinterpret_cast<uint4 *>(s->voxels);
+  ip.Wd = w_d; ip.Hd = h_d; ip.Wr = w_rgb; ip.Hr = h_rgb;
+  ip.fx_d = intr[0]; ip.fy_d = intr[1]; ip.cx_d = intr[2]; ip.cy_d = intr[3];
+  ip.fx_r = intr[0]; ip.fy_r = intr[1]; ip.cx_r = intr[2]; ip.cy_r = intr[3];
+  ip.voxel_size = s->p.voxel_size; ip.mu = s->p.mu; ip.max_w = s->p.max_w;
+  ip.inv_32767 = 1.0f / 32767.0f; ip.inv_255 = 1.0f / 255.0f;
+  ip.same_cam = 1;
+  ip.stop_max = 0;
+  ip.depth_weighting = e->wp.depth_weighting; ip.max_new_w = e->wp.max_new_w; ip.max_distance = e->wp.max_distance;
+  ip.shard = s->shard; ip.num_shards = s->num_shards; ip.chunk_blocks = s->chunk_blocks;
+  ip.shard_first = s->shard_first; ip.shard_count = s->shard_count;
+  ip.dirty = s->dirty_tracking ? s->dirty : nullptr;
+  ip.masks = s->masks; ip.last_seen = s->last_seen;
+  ip.push_words = push_ring >= 0 ? s->history_words : 0;
+  ip.push_ring = push_ring >= 0 ? push_ring : 0;
+  bp.ops = reinterpret_cast<const BatchOp *>(ops_dev);
+  bp.opmask = opmask; bp.slot_entry = slot_entry; bp.dirty_list = dirty_list; bp.dirty_count = dirty_count; bp.cursor = cursor;
+  bp.a = a; bp.b = b;
+  bp.raw_bytes = (w_d * h_d * 2 + 3) & ~3;
+  hipLaunchKernelGGL(k_reintegrate_blocks, dim3(kBatchGrid), dim3(kBatchWgWaves * 64), 0, e->stream, bp);
+  DSLAM_HIP(hipGetLastError());
+  return DSLAM_OK;
+}
+
 // the render state's visible list, with the block position of every entry, into a keyframe's list slot
 __global__ __launch_bounds__(256) void k_store_visible_list(const int *__restrict__ ids, const RenderCounters *rc,
                                                             const HashEntry *__restrict__ hash, RenderCounters *header,

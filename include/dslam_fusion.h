@@ -269,6 +269,21 @@ int dslam_deprocess_frame_stored(dslam_engine *e, dslam_scene *s, const dslam_vi
                                  const float M_d[16], const float intrinsics_d[4], const float M_rgb[16],
                                  const float intrinsics_rgb[4]);
 
+/* The re-integration batch of DenseSlam::OnlineCorrection (DenseSlam.cpp:389-403: for every corrected keyframe
+ * DeProcessFrame at its old pose, ProcessFrame at the new one), as ONE call.  Equal -- map, rings, free lists, render state,
+ * stored lists: bit for bit -- to
+ *   for k in 0 .. n-1:  dslam_view_update_from_store(v, fs, slots[k]);  dslam_deprocess_frame_stored(s, v, fs, slots[k], old_M[k]);
+ *                       dslam_process_frame(s, v, r, new_M[k], is_defusion = 1);  dslam_frame_store_put_visible_list(fs, slots[k], s, r)
+ * but run block-major: the n allocation passes first, then every voxel block the batch touches is loaded once, takes the
+ * de- and re-updates of every keyframe that names it in keyframe order, and is stored once (csrc/integrate.hip).  The
+ * keyframes' images and fusion-time visible lists must be in the store; poses are n x 16 floats (column-major world ->
+ * camera), one camera (depth = colour).  Scenes with host swapping or stopIntegratingAtMaxW return DSLAM_ERR_UNSUPPORTED:
+ * use the per-keyframe calls.  On a sharded scene (dslam_scene_set_shard) every rank runs the allocation passes and
+ * updates its own blocks; the exchange is dslam_shard_dirty_plan / _pack / _unpack as for the per-keyframe calls. */
+int dslam_reintegrate_batch(dslam_engine *e, dslam_scene *s, dslam_view *v, dslam_render_state *r, dslam_frame_store *fs,
+                            int n, const int32_t *slots, const float *old_M, const float *new_M, const float intr[4],
+                            float affine_a, float affine_b);
+
 /* DenseSlam::depthPostProcessing's pixel loop (DenseSlam.cpp:488-529): blanks (sets to 0) every pixel of the
  * current keyframe's depth whose reprojection into the previous keyframe disagrees with that keyframe's depth by
  * more than `filter_threshold` (relative) and which lies below row `filter_area * rows`

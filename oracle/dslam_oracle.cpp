@@ -1240,6 +1240,22 @@ extern "C" int oracle_deprocess_frame_stored(oracle_engine *e, oracle_scene *s, 
   return 0;
 }
 
+// The re-integration batch of DenseSlam::OnlineCorrection (reference DenseSlam.cpp:389-403) as the reference runs it: keyframe
+// by keyframe, DeProcessFrame at the old pose (here from the stored list), ProcessFrame(isDefusion) at the new one.  This
+// sequence DEFINES dslam_reintegrate_batch; the HIP engine runs it block-major and must end in the same bytes.
+extern "C" int oracle_reintegrate_batch(oracle_engine *e, oracle_scene *s, oracle_view *v, oracle_render_state *r, oracle_frame_store *fs,
+                                        int n, const int32_t *slots, const float *old_M, const float *new_M, const float *intr,
+                                        float affine_a, float affine_b) {
+  for (int k = 0; k < n; k++) {
+    int rc = oracle_view_update_from_store(e, v, fs, slots[k], affine_a, affine_b, 0.0, 0);
+    if (rc) return rc;
+    if ((rc = oracle_deprocess_frame_stored(e, s, v, fs, slots[k], old_M + 16 * (size_t)k, intr, nullptr, nullptr))) return rc;
+    if ((rc = oracle_process_frame(e, s, v, r, new_M + 16 * (size_t)k, intr, nullptr, nullptr, 0, 1))) return rc;
+    if ((rc = oracle_frame_store_put_visible_list(e, fs, slots[k], s, r))) return rc;
+  }
+  return 0;
+}
+
 // -------------------------------------------------------------------------------------------------
 // Decay / SlideWindow (InfiniTamDriver.h:274-331).  The fork's bodies are not knowable;
 // the semantics below are this build's documented design (DESIGN.md "Decay and sliding window").

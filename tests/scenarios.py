@@ -146,3 +146,55 @@ def stored_list_scenario(api, pkg, synth, wl, params, maintenance):
     except pkg.DslamError:
         out["missing_list_refused"] = True
     return out
+
+
+def batch_scenario(api, pkg, synth, wl, params, maintenance, call, n_frames=12, picks=(7, 9, 8, 2, 11, 5), second=(3, 9, 7)):
+    """DenseSlam::OnlineCorrection's loop (reference DenseSlam.cpp:389-403) over keyframes kept in a store with their
+    fusion-time visible lists, twice (the second batch de-integrates from the lists the first one left), with a fusion in
+    between.  call = "batch": dslam_reintegrate_batch; "loop": the per-keyframe calls that define it."""
+    scene = api.create_scene(params)
+    rs, view = api.create_render_state(scene, wl.W, wl.H), api.create_view(wl.W, wl.H)
+    store = api.create_frame_store(wl.W, wl.H, n_frames + 1)
+    api.frame_store_enable_lists(store, scene)
+    poses = {}
+    out = {}
+    for i in range(n_frames):
+        rgba, mm, M = wl.frame(i)
+        api.view_update(view, rgba, mm, timestamp=float(i))
+        api.frame_store_put_view(store, i, view)
+        api.process_frame(scene, view, rs, M, wl.intr)
+        api.frame_store_put_visible_list(store, i, scene, rs)
+        poses[i] = M
+        if maintenance:
+            if api.stats(scene, rs)["fusion_fifo_len"] > 5:
+                api.slide_window(scene, rs, 5)
+            api.decay(scene, rs, 1, 3, True)
+
+    def correct(ids, seed):
+        new = []
+        for n, i in enumerate(ids):
+            new.append(synth.world_to_camera(wl.pose(i) @ synth.pose_matrix(
+                synth.look_rotation(0.003 * (n + 1 + seed), -0.002 * (1 + seed)), [0.004 + 0.002 * seed, 0.001 * n, -0.003])))
+        if call == "batch":
+            api.reintegrate_batch(scene, view, rs, store, list(ids), [poses[i] for i in ids], new, wl.intr)
+        else:
+            for i, new_M in zip(ids, new):
+                api.view_update_from_store(view, store, i, timestamp=float(i))
+                api.deprocess_frame_stored(scene, view, store, i, poses[i], wl.intr)
+                api.process_frame(scene, view, rs, new_M, wl.intr, is_defusion=True)
+                api.frame_store_put_visible_list(store, i, scene, rs)
+        for i, new_M in zip(ids, new):
+            poses[i] = new_M
+
+    correct([i for i in picks if i < n_frames], 0)
+    out["first"] = full_state(api, scene, rs)
+    rgba, mm, M = wl.frame(n_frames)     # the map is used on: one more keyframe
+    api.view_update(view, rgba, mm, timestamp=float(n_frames))
+    api.frame_store_put_view(store, n_frames, view)
+    api.process_frame(scene, view, rs, M, wl.intr)
+    api.frame_store_put_visible_list(store, n_frames, scene, rs)
+    poses[n_frames] = M
+    correct([i for i in second if i < n_frames] + [n_frames], 1)
+    out["second"] = full_state(api, scene, rs)
+    out["alloc_scratch"] = api.download_alloc_scratch(scene)
+    return out
