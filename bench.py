@@ -67,49 +67,113 @@ def cpu_model():
     return "unknown"
 
 
-def cpu_baseline(pkg, wl, params, frames, warm=20, budget_s=12.0, budget_1t_s=8.0):
+CPU_FRAMES = 96  # the CPU baseline runs on its own stretch of the sequence, whatever --steps says
+
+
+def cpu_baseline(pkg, wl, params, frames, warm=20, budget_s=6.0):
     """CPU oracle (kind "port": the reference's CPU engine cannot be built here) on the same frames with the
     same call sequence, built as the reference builds its CPU code (-O3 -march=native, CMakeLists.txt:32,45) on THIS
     machine.  Parallelisation = upstream's CPU engine: OpenMP over visible blocks (integration) and pixels (raycast),
     the allocation pass sequential.  The first `warm` frames (cold map, cold caches) are not timed, like the GPU
-    side's warm-up; then ~budget_s seconds on all the threads this process may use, then ~budget_1t_s on one."""
+    side's warm-up; then ~budget_s seconds each on 16 threads (the per-GPU share of the box), on every CPU this process
+    may use, and on one thread -- of the same CPU_FRAMES-frame stretch, independent of --steps."""
     orc_pkg = ge.load_oracle()
     orc, flags = orc_pkg.open_native_oracle(pkg.CApi)
     avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    # the GPU box gives one GPU a 16-CPU share of the host (gpurun); use that share, all of it, unless told otherwise
+    # the GPU box gives one GPU a 16-CPU share of the host (gpurun); `value` uses that share, all of it
     threads = max(1, min(orc.max_threads(), avail, int(os.environ.get("DSLAM_CPU_THREADS", "16"))))
+    threads_all = max(1, min(orc.max_threads(), avail))
     rgba, depth, Ms = frames
     s = orc.create_scene(params)
     rs = orc.create_render_state(s, wl.W, wl.H)
     rs_free = orc.create_render_state(s, wl.W, wl.H)  # renderState_freeview, as in the GPU step
     v = orc.create_view(wl.W, wl.H)
+    phases = {"update_view": 0.0, "allocate": 0.0, "integrate": 0.0, "raycast": 0.0}
 
-    def run(first, budget, max_frames):
+    def run(first, budget, max_frames, split=None):
         n, t0 = 0, time.perf_counter()
         while n < max_frames and first + n < len(Ms):
             i = first + n
+            ta = time.perf_counter()
             orc.view_update(v, rgba[i], depth[i], timestamp=float(i))
-            orc.process_frame(s, v, rs, Ms[i], wl.intr)
+            tb = time.perf_counter()
+            orc.allocate_scene_from_depth(s, v, rs, Ms[i], wl.intr)   # (ProcessFrame = these two calls + the ring push)
+            tc = time.perf_counter()
+            orc.integrate_into_scene(s, v, rs, Ms[i], wl.intr)
+            td = time.perf_counter()
             orc.get_image(s, rs_free, Ms[i], wl.intr, pkg.IMAGE_DEPTH, download=True)
+            te = time.perf_counter()
+            if split is not None:
+                for key, dt in zip(("update_view", "allocate", "integrate", "raycast"), (tb - ta, tc - tb, td - tc, te - td)):
+                    split[key] += dt
             n += 1
             if budget is not None and time.perf_counter() - t0 > budget:
                 break
         return n, time.perf_counter() - t0
 
     orc.set_threads(threads)
-    warm = min(warm, max(0, len(Ms) - 8))
+    warm = min(warm, max(0, len(Ms) - 12))
     run(0, None, warm)
-    n_all, dt_all = run(warm, budget_s, len(Ms) - warm - 4)
+    left = len(Ms) - warm
+    n_16, dt_16 = run(warm, budget_s, max(1, left // 2), phases)
+    out = {"value": n_16 / dt_16, "unit": "frames/s", "cores": threads, "kind": "port",
+           "sample": (f"frames {warm}..{warm + n_16 - 1} of a {len(Ms)}-frame {wl.name} {wl.W}x{wl.H} sequence of its own "
+                      f"(independent of --steps) after {warm} untimed warm-up frames, same call sequence (host images in, "
+                      f"depth image out), {dt_16:.1f} s")}
+    done = warm + n_16
+    if threads_all != threads:
+        orc.set_threads(threads_all)
+        n_all, dt_all = run(done, budget_s, max(1, (len(Ms) - done) // 2))
+        out["all_cpus_fps"] = n_all / dt_all
+        out["all_cpus_threads"] = threads_all
+        done += n_all
     orc.set_threads(1)
-    n_1t, dt_1t = run(warm + n_all, budget_1t_s, max(1, len(Ms) - warm - n_all))
-    return {"value": n_all / dt_all, "unit": "frames/s", "cores": threads, "kind": "port",
-            "sample": (f"frames {warm}..{warm + n_all - 1} of the same {wl.name} {wl.W}x{wl.H} sequence after {warm} untimed "
-                       f"warm-up frames, same call sequence (host images in, depth image out), {dt_all:.1f} s"),
-            "one_thread_fps": n_1t / dt_1t,
-            "one_thread_sample": f"frames {warm + n_all}..{warm + n_all + n_1t - 1}, {dt_1t:.1f} s",
-            "cores_available_to_process": avail, "cores_on_box": os.cpu_count(), "cpu_model": cpu_model(),
-            "build": "g++ " + flags,
-            "parallelisation": "OpenMP over visible blocks (integrate) and pixels (raycast); allocation sequential, as upstream's CPU engine"}
+    n_1t, dt_1t = run(done, budget_s, max(1, len(Ms) - done))
+    per = {k_: 1e3 * t / max(1, n_16) for k_, t in phases.items()}
+    tot = sum(per.values())
+    out.update({
+        "one_thread_fps": n_1t / dt_1t,
+        "one_thread_sample": f"frames {done}..{done + n_1t - 1}, {dt_1t:.1f} s",
+        "ms_per_frame_by_call": {k_: round(x, 2) for k_, x in per.items()},
+        "bounded_by": (f"{max(per, key=per.get)}: {max(per.values()):.1f} ms of {tot:.1f} ms per frame on {threads} threads "
+                       f"(allocation, sequential in upstream's CPU engine: {per['allocate']:.1f} ms; integration "
+                       f"{per['integrate']:.1f} ms and raycast {per['raycast']:.1f} ms are the OpenMP loops; compare the 1-thread "
+                       f"and all-CPU figures: more cores move the rate little).  The GPU / CPU ratio says nothing about kernel "
+                       f"quality, roofline.frac does"),
+        "cores_available_to_process": avail, "cores_on_box": os.cpu_count(), "cpu_model": cpu_model(),
+        "build": "g++ " + flags,
+        "parallelisation": "OpenMP over visible blocks (integrate) and pixels (raycast); allocation sequential, as upstream's CPU engine"})
+    return out
+
+
+def spawn_ranks(args):
+    """`python bench.py --gpus N` without a launcher: start N ranks of this script, one per GPU, BEFORE this process
+    makes any GPU call (it never does), hand rank 0's JSON line through, fail if a rank fails."""
+    import socket
+    import subprocess
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ)
+        env.update({"RANK": str(r), "LOCAL_RANK": str(r), "WORLD_SIZE": str(args.gpus), "MASTER_ADDR": "127.0.0.1",
+                    "MASTER_PORT": str(port), "HSA_ENABLE_IPC_MODE_LEGACY": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0")})
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE, text=True))
+    outs = [p.communicate()[0] for p in procs]
+    bad = [r for r, p in enumerate(procs) if p.returncode != 0]
+    if args.spawn_dry_run:
+        ranks = sorted((json.loads(line) for o in outs for line in o.splitlines() if line.startswith("{")),
+                       key=lambda d: d["rank"])
+        print(json.dumps({"spawn_dry_run": True, "n_gpus": args.gpus, "ranks": ranks, "failed_ranks": bad}), flush=True)
+    else:
+        for line in outs[0].splitlines():
+            if line.startswith("{"):
+                print(line, flush=True)
+    if bad:
+        raise SystemExit(f"bench.py: rank(s) {bad} failed")
 
 
 def main():
@@ -129,11 +193,18 @@ def main():
                          "device = inputs resident in HBM, outputs left there; sync = PCIe-inclusive, every call synchronous")
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise torch.distributed (RCCL) and run the all-gather path even with one rank (plumbing check)")
+    ap.add_argument("--spawn-dry-run", action="store_true",
+                    help="with --gpus N: start the N ranks, let each report its rank / world size and exit before it touches a GPU")
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        return spawn_ranks(args)   # (this process stays off the GPU; the ranks are children with RANK / LOCAL_RANK / WORLD_SIZE set)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.spawn_dry_run:
+        print(json.dumps({"rank": rank, "local_rank": local_rank, "world_size": world}), flush=True)
+        return
 
     pkg = ge.load_package()
     from dslam_amd.harness import synth
@@ -145,7 +216,9 @@ def main():
     # (rocprofv3 --pmc preloads its tool library) there is no such moment, so no pool is used there.
     preloaded = os.environ.get("LD_PRELOAD", "") + os.environ.get("ROCP_TOOL_LIBRARIES", "")
     workers = 1 if "rocprof" in preloaded.lower() else max(1, min(16, (os.cpu_count() or 2) // max(1, world)))
-    frames = generate_frames(args.workload, args.width, args.height, nframes, workers)
+    want_cpu = rank == 0 and world == 1 and not args.no_cpu_baseline
+    frames_all = generate_frames(args.workload, args.width, args.height, max(nframes, CPU_FRAMES) if want_cpu else nframes, workers)
+    frames = tuple(x[:nframes] for x in frames_all)
     rgba_h, depth_h, Ms = frames
 
     import torch
@@ -254,10 +327,15 @@ def main():
     eng.set_async(args.mode != "sync")
 
     # ---- sharded global re-integration (BASELINE configs[4]): de-integrate + re-integrate the last
-    # `--reint` keyframes at corrected poses, blocks sharded over the ranks, one RCCL all-gather at the end.
+    # `--reint` keyframes at corrected poses, blocks sharded over the ranks, one RCCL all-gather at the end.  Three forms of
+    # the same batch, each undoing the one before it (old -> new, new -> old, old -> new):
+    #   reference_calls   DeProcessFrame + ProcessFrame per keyframe, as DenseSlam::OnlineCorrection calls them
+    #   stored_lists      the same loop, de-integrating from each keyframe's stored visible list (no allocation pass at the old pose)
+    #   block_major       dslam_reintegrate_batch: allocation passes first, then every touched block loaded once (the headline)
     reint_out = None
     if args.reint > 0:
         try:
+            import zlib
             from dslam_amd.harness import reintegrate as reint
             Kre = min(args.reint, K)
             ids = list(range(Wm + K - Kre, Wm + K))
@@ -265,51 +343,105 @@ def main():
             for n_, i in enumerate(ids):  # a smooth loop-closure correction: small rotation + translation drift
                 T_new = wl.pose(i) @ synth.pose_matrix(synth.look_rotation(0.002 * (n_ + 1), 0.0), [0.01 * (n_ + 1), 0.0, 0.02])
                 new_poses.append(synth.world_to_camera(T_new))
-            batch = reint.Batch([("dev", rgba_d.data_ptr() + i * rgba_stride, depth_d.data_ptr() + i * depth_stride) for i in ids],
-                                [Ms[i] for i in ids], new_poses, wl.intr)
+            old_poses = [Ms[i] for i in ids]
             chunk = 64
-            ag = reint.make_torch_all_gather(eng, scene, dist, eng.synchronize) if use_dist else None
-            timers = {}
-            barrier()
-            reint.reintegrate(eng, scene, view, rs, batch, rank=rank, world=world, chunk_blocks=chunk, all_gather=ag,
-                              timers=timers, force_collective=use_dist)
-            barrier()
-            tt = torch.tensor([timers["total_s"], timers["reintegrate_s"], timers["all_gather_s"]], device=dev,
-                              dtype=torch.float64)
+
+            def max_over_ranks(vals):
+                t = torch.tensor(vals, device=dev, dtype=torch.float64)
+                if use_dist:
+                    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                return [float(x) for x in t.tolist()]
+
+            def checksum(sc, vox):
+                """(voxel pool, hash table) as two integers; the pool is summed on the device."""
+                eng.synchronize()
+                torch.cuda.synchronize()
+                pool = int(vox.view(torch.int64).sum().item())
+                table = zlib.crc32(eng.download_hash_table(sc).tobytes())
+                return pool, table
+
+            def run_legs(sc, vw, rstate, vox, rank_, world_, collective):
+                """The three forms on one map; returns their timings and the map checksum after each."""
+                res, sums = {}, []
+                ag = reint.make_torch_all_gather(eng, sc, dist, eng.synchronize) if collective else None
+                kw = dict(rank=rank_, world=world_, chunk_blocks=chunk, all_gather=ag, force_collective=collective)
+                frames_dev = [("dev", rgba_d.data_ptr() + i * rgba_stride, depth_d.data_ptr() + i * depth_stride) for i in ids]
+                tm = {}
+                barrier()
+                reint.reintegrate(eng, sc, vw, rstate, reint.Batch(frames_dev, old_poses, new_poses, wl.intr), timers=tm, **kw)
+                barrier()
+                res["reference_calls"] = tm
+                sums.append(checksum(sc, vox))
+                # keyframe images into a store; lists as a re-fusion at the corrected pose leaves them
+                store = eng.create_frame_store(wl.W, wl.H, Kre)
+                eng.frame_store_enable_lists(store, sc)
+                eng.set_async(False)
+                for n_, i in enumerate(ids):
+                    eng.view_update_device(vw, rgba_d.data_ptr() + i * rgba_stride, depth_d.data_ptr() + i * depth_stride, timestamp=float(i))
+                    eng.frame_store_put_view(store, n_, vw)
+                    eng.allocate_scene_from_depth(sc, vw, rstate, new_poses[n_], wl.intr, only_update_visible_list=True)
+                    eng.frame_store_put_visible_list(store, n_, sc, rstate)
+                eng.set_async(args.mode != "sync")
+                frames_st = [("store", store, n_) for n_ in range(Kre)]
+                tm = {}
+                barrier()
+                reint.reintegrate(eng, sc, vw, rstate, reint.Batch(frames_st, new_poses, old_poses, wl.intr), timers=tm, stored_lists=True, **kw)
+                barrier()
+                res["stored_lists"] = tm
+                sums.append(checksum(sc, vox))
+                tm = {}
+                barrier()
+                reint.reintegrate(eng, sc, vw, rstate, reint.Batch(frames_st, old_poses, new_poses, wl.intr), timers=tm, batched=True, **kw)
+                barrier()
+                res["block_major"] = tm
+                sums.append(checksum(sc, vox))
+                store.close()
+                return res, sums
+
+            res, sums = run_legs(scene, view, rs, vox_t, rank, world, use_dist)
+            reint_out = {"keyframes": Kre, "ranks_seen_by_rccl": dist.get_world_size() if use_dist else 1,
+                         "scaling": "strong (fixed batch; allocation replicated on every rank, voxel blocks sharded, one all-gather "
+                                    "of the blocks the batch touched)"}
+            for form, tm in res.items():
+                tot, rei, agt = max_over_ranks([tm["total_s"], tm["reintegrate_s"], tm["all_gather_s"]])
+                reint_out[form] = {"keyframes_per_s": Kre / tot, "total_ms": tot * 1e3, "compute_ms": rei * 1e3, "all_gather_ms": agt * 1e3,
+                                   "gathered_bytes": tm["gathered_bytes"], "dirty_blocks": tm["dirty_blocks"],
+                                   "all_gather_GBps": (tm["gathered_bytes"] / agt / 1e9) if (use_dist and agt > 0) else None}
+            reint_out["keyframes_per_s"] = reint_out["block_major"]["keyframes_per_s"]
+            reint_out["all_gather_ms"] = reint_out["block_major"]["all_gather_ms"]
+            reint_out["gathered_bytes"] = reint_out["block_major"]["gathered_bytes"]
+            # (forms 1 and 3 need not leave the same bytes: DeProcessFrame as the reference calls it visits what an allocation
+            # pass at the old pose finds today, the stored-list forms visit the keyframe's own blocks; parity of each form is
+            # the test-suite's business, the checks below are about the ranks)
             if use_dist:
-                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            tot, rei, agt = [float(x) for x in tt.tolist()]
-            reint_out = {"keyframes": Kre, "keyframes_per_s": Kre / tot, "total_ms": tot * 1e3, "compute_ms": rei * 1e3,
-                         "all_gather_ms": agt * 1e3, "gathered_bytes": timers["gathered_bytes"],
-                         "dirty_blocks": timers["dirty_blocks"],
-                         "all_gather_GBps": (timers["gathered_bytes"] / agt / 1e9) if (use_dist and agt > 0) else None,
-                         "scaling": "strong (fixed batch; allocation replicated on every rank, voxel blocks sharded, "
-                                    "one all-gather of the blocks the batch touched)"}
-            # the same batch undone again (poses back to the originals), this time de-integrating from each keyframe's
-            # stored visible list instead of an allocation pass at the old pose (dslam_deprocess_frame_stored)
-            store = eng.create_frame_store(wl.W, wl.H, Kre)
-            eng.frame_store_enable_lists(store, scene)
-            eng.set_async(False)
-            for n_, i in enumerate(ids):  # keyframe images into the store; lists as a re-fusion at the corrected pose leaves them
-                eng.view_update_device(view, rgba_d.data_ptr() + i * rgba_stride, depth_d.data_ptr() + i * depth_stride, timestamp=float(i))
-                eng.frame_store_put_view(store, n_, view)
-                eng.allocate_scene_from_depth(scene, view, rs, new_poses[n_], wl.intr, only_update_visible_list=True)
-                eng.frame_store_put_visible_list(store, n_, scene, rs)
-            batch2 = reint.Batch([("store", store, n_) for n_ in range(Kre)], new_poses, [Ms[i] for i in ids], wl.intr)
-            eng.set_async(args.mode != "sync")
-            timers2 = {}
-            barrier()
-            reint.reintegrate(eng, scene, view, rs, batch2, rank=rank, world=world, chunk_blocks=chunk, all_gather=ag,
-                              timers=timers2, force_collective=use_dist, stored_lists=True)
-            barrier()
-            t2 = torch.tensor([timers2["total_s"]], device=dev, dtype=torch.float64)
-            if use_dist:
-                dist.all_reduce(t2, op=dist.ReduceOp.MAX)
-            reint_out["stored_lists_keyframes_per_s"] = Kre / float(t2.item())
-            reint_out["stored_lists_total_ms"] = float(t2.item()) * 1e3
-            store.close()
+                # every rank must hold the same map after each exchange ...
+                flat = [float(x % (1 << 52)) for pair in sums for x in pair]
+                t_min = torch.tensor(flat, device=dev, dtype=torch.float64)
+                t_max = t_min.clone()
+                dist.all_reduce(t_min, op=dist.ReduceOp.MIN)
+                dist.all_reduce(t_max, op=dist.ReduceOp.MAX)
+                reint_out["map_checksum_equal"] = bool(torch.equal(t_min, t_max))
+                # ... and rank 0 repeats everything UNSHARDED on a second map built from the same frames
+                if rank == 0:
+                    vox_ref = torch.empty(nlb * 512 * 8, dtype=torch.uint8, device=dev)
+                    scene_ref = eng.create_scene(params, ext_voxel_blocks_dev=vox_ref.data_ptr())
+                    view_ref = eng.create_view(wl.W, wl.H)
+                    rs_ref = eng.create_render_state(scene_ref, wl.W, wl.H)
+                    eng.set_async(False)
+                    for i in range(Wm + K):
+                        eng.view_update_device(view_ref, rgba_d.data_ptr() + i * rgba_stride, depth_d.data_ptr() + i * depth_stride, timestamp=float(i))
+                        eng.process_frame(scene_ref, view_ref, rs_ref, Ms[i], wl.intr)
+                    eng.set_async(args.mode != "sync")
+                    saved = barrier
+                    barrier = lambda: (eng.synchronize(), torch.cuda.synchronize())  # noqa: E731  (rank-local leg: no collective)
+                    _, sums_ref = run_legs(scene_ref, view_ref, rs_ref, vox_ref, 0, 1, False)
+                    barrier = saved
+                    reint_out["equals_unsharded_run_on_rank0"] = bool(sums_ref == sums)
+                    for o in (rs_ref, view_ref, scene_ref):
+                        o.close()
         except Exception as ex:  # never lose the main line over the auxiliary measurement
-            reint_out = {"error": repr(ex)}
+            import traceback
+            reint_out = {"error": repr(ex), "trace": traceback.format_exc()[-600:]}
 
     # ---- the same frames at the two other call disciplines (rank-local; not `value`)
     extra = {}
@@ -345,11 +477,14 @@ def main():
         alg_bytes = 8212.0 * blocks + 8.0 * wl.W * wl.H * launches
         avg_ms = int_ms / max(1, launches)
         achieved = (alg_bytes / max(1, launches)) / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
-        traffic = None
-        for tag in ("r02", "r01"):  # PMC passes are separate rocprofv3 runs of this same command (profiles/)
+        traffic, traffic_source = None, None
+        for tag in ("r03", "r02", "r01"):  # PMC passes are separate rocprofv3 runs of this same command (profiles/)
             pmc_path = os.path.join(ROOT, "profiles", f"{tag}_integrate_pmc.json")
             if os.path.exists(pmc_path):
                 traffic = json.load(open(pmc_path))["traffic_bytes_per_visible_block"] * blocks / max(1, launches)
+                traffic_source = (f"profiles/{tag}_integrate_pmc.json: bytes per visible block from the builder's separate rocprofv3 "
+                                  f"--pmc passes (FETCH_SIZE, WRITE_SIZE) of this command, scaled by this run's block count -- NOT "
+                                  f"measured in this run")
                 break
         calls = {"pipelined": "PCIe-inclusive, pipelined: page-locked host frames in (copy stream, overlapped with the previous "
                               "frame's kernels), raycast depth image stored into page-locked host memory every frame, one fence per frame",
@@ -379,7 +514,7 @@ def main():
                        "allocated_blocks_end": nlb - 1 - st["last_free_block_id"],
                        "raycast_hits_last_frame": hits},
             "roofline": {"bound": "hbm", "kernel": "k_integrate<false>", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
                          "avg_launch_us": avg_ms * 1e3, "launches": launches,
                          "algorithmic_bytes_per_launch": alg_bytes / max(1, launches)},
         }
@@ -389,7 +524,7 @@ def main():
         if reint_out is not None:
             out["reintegration"] = reint_out
         if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(pkg, wl, params, frames)
+            out["cpu_baseline"] = cpu_baseline(pkg, wl, params, frames_all)
             out["cpu_baseline"]["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
         print(json.dumps(out), flush=True)
     if use_dist:

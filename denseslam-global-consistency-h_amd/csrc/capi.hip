@@ -387,7 +387,7 @@ int dslam_scene_destroy(dslam_scene *s) {
   free_dev(s->alloc_list); free_dev(s->excess_list); free_dev(s->last_seen); free_dev(s->masks); free_dev(s->counters);
   free_dev(s->swap_state); free_dev(s->slab_ptrs_dev); free_dev(s->alloc_bits); free_dev(s->swap1_bits);
   free_dev(s->dirty); free_dev(s->dirty_list); free_dev(s->dirty_counts);
-  free_dev(s->batch_born); free_dev(s->batch_opmask); free_dev(s->batch_slot_entry); free_dev(s->batch_list); free_dev(s->batch_counters);
+  free_dev(s->batch_born); free_dev(s->batch_opmask); free_dev(s->batch_slot_entry); free_dev(s->batch_list); free_dev(s->batch_order); free_dev(s->batch_counters);
   if (s->batch_ops_dev) (void)hipFree(s->batch_ops_dev);
   if (s->batch_lists_dev) (void)hipFree(s->batch_lists_dev);
   for (uint4 *slab : s->slabs) (void)hipHostFree(slab);
@@ -932,6 +932,7 @@ static int batch_scratch(dslam_engine *e, dslam_scene *s, dslam_frame_store *fs)
     DSLAM_HIP(hipMalloc(&s->batch_opmask, L * sizeof(unsigned long long)));
     DSLAM_HIP(hipMalloc(&s->batch_slot_entry, L * sizeof(int)));
     DSLAM_HIP(hipMalloc(&s->batch_list, L * sizeof(int)));
+    DSLAM_HIP(hipMalloc(&s->batch_order, L * sizeof(int)));
     DSLAM_HIP(hipMalloc(&s->batch_counters, 4 * sizeof(int)));
     DSLAM_HIP(hipMalloc(&s->batch_ops_dev, 2 * kBatchMax * sizeof(HostBatchOp)));
     DSLAM_HIP(hipMalloc(&s->batch_lists_dev, 2 * kBatchMax * sizeof(HostBatchList)));
@@ -1008,10 +1009,10 @@ int dslam_reintegrate_batch(dslam_engine *e, dslam_scene *s, dslam_view *v, dsla
     DSLAM_HIP(hipMemcpyAsync(s->batch_lists_dev, lists.data(), lists.size() * sizeof(HostBatchList), hipMemcpyHostToDevice, e->stream));
     DSLAM_HIP(hipStreamSynchronize(e->stream));   // (the sources are vectors of this scope)
     if ((rc = launch_batch_ops(e, s->batch_lists_dev, 2 * K, s, s->batch_born, s->batch_opmask, s->batch_slot_entry, s->batch_list,
-                               s->batch_counters)))
+                               s->batch_counters, s->batch_order)))
       return rc;
     if ((rc = launch_reintegrate_blocks(e, s, v->w_d, v->h_d, v->w_rgb, v->h_rgb, intr, affine_a, affine_b, s->batch_ops_dev,
-                                        s->batch_opmask, s->batch_slot_entry, s->batch_list, s->batch_counters, s->batch_counters + 1, 1)))
+                                        s->batch_opmask, s->batch_slot_entry, s->batch_order, s->batch_counters, s->batch_counters + 1, 1, 2 * K)))
       return rc;
     // the lists of the re-fusions become the keyframes' stored lists: the buffers trade places
     for (int k = 0; k < K; k++) std::swap(fs->list_ptr[slots[first + k]], fs->batch_list_ptr[k]);

@@ -163,7 +163,7 @@ struct dslam_scene {
   // blocks it commits while a batch is being planned
   int *batch_born = nullptr;
   unsigned long long *batch_opmask = nullptr;
-  int *batch_slot_entry = nullptr, *batch_list = nullptr, *batch_counters = nullptr;
+  int *batch_slot_entry = nullptr, *batch_list = nullptr, *batch_order = nullptr, *batch_counters = nullptr;
   void *batch_ops_dev = nullptr, *batch_lists_dev = nullptr;
   int *alloc_born = nullptr;
   int alloc_born_stamp = 0;
@@ -295,10 +295,10 @@ int launch_integrate_list(dslam_engine *e, dslam_scene *s, const dslam_view *v, 
 int launch_store_visible_list(dslam_engine *e, const dslam_scene *s, const dslam_render_state *r, void *header, int *ids,
                               short4 *pos, int capacity);
 int launch_batch_ops(dslam_engine *e, const void *lists_dev, int n_ops, const dslam_scene *s, const int *born,
-                     unsigned long long *opmask, int *slot_entry, int *dirty_list, int *dirty_count);
+                     unsigned long long *opmask, int *slot_entry, int *dirty_list, int *dirty_count, int *ordered_list);
 int launch_reintegrate_blocks(dslam_engine *e, dslam_scene *s, int w_d, int h_d, int w_rgb, int h_rgb, const float *intr,
                               float a, float b, const void *ops_dev, const unsigned long long *opmask, const int *slot_entry,
-                              const int *dirty_list, const int *dirty_count, int *cursor, int push_ring);
+                              const int *dirty_list, const int *dirty_count, int *cursor, int push_ring, int n_ops);
 int ensure_view_depth(dslam_engine *e, const dslam_view *v);
 int launch_selftest_division(dslam_engine *e, long long samples, unsigned long long *mismatches_dev);
 int prepare_push_visible_list(dslam_engine *e, dslam_scene *s, int q, int *bit_out, int *frame_out);

@@ -979,19 +979,21 @@ struct BatchParams {
   int *cursor;
   float a, b;             // depth = raw * a + b
   int raw_bytes;
+  int n_ops;
 };
 
-// pair_project with the depth pixel derived from the int16 image: (r <= 0 || r > 32000) ? -1 : r * a + b, the conversion of
-// k_mark / k_convert_depth (same operations, same bits).  The halfword comes out of the dword that holds it.
-__device__ __forceinline__ float raw_depth_at(__amdgpu_buffer_rsrc_t raw_rs, int x, int y, int W, float a, float b) {
-  const unsigned off = ((unsigned)__mul24(y, W) + (unsigned)x) << 1;
-  const unsigned w32 = __builtin_amdgcn_raw_buffer_load_b32(raw_rs, off & ~3u, 0, 0);
-  const int r = (int)(short)((off & 2u) ? (w32 >> 16) : (w32 & 0xffffu));
-  return (r <= 0 || r > 32000) ? -1.0f : (float)r * a + b;
-}
+// pair_project with the depth pixels taken from the int16 image: the float value is derived as UpdateView derives it,
+// (r <= 0 || r > 32000) ? -1 : r * a + b (the conversion of k_mark / k_convert_depth: same operations, same bits).  The
+// projection only REQUESTS the dword that holds the halfword; raw_depth_finish turns it into metres when the update needs
+// it, so that the requests of several chunks are in flight together.
+struct RawProj {
+  PairProj q;        // (q.dm holds the two raw dwords until raw_depth_finish)
+  unsigned hi_half;  // bit h: voxel h's pixel is the upper halfword of its dword
+};
 
-__device__ __forceinline__ void pair_project_raw(PairProj &q, f2 pcx, f2 pcy, f2 pcz, const IntegrateParams &p,
-                                                 __amdgpu_buffer_rsrc_t raw_rs, float a, float b) {
+__device__ __forceinline__ void pair_project_raw(RawProj &o, f2 pcx, f2 pcy, f2 pcz, const IntegrateParams &p,
+                                                 __amdgpu_buffer_rsrc_t raw_rs) {
+  PairProj &q = o.q;
   const f2 fx2 = {p.fx_d, p.fx_d}, fy2 = {p.fy_d, p.fy_d}, cx2 = {p.cx_d, p.cx_d}, cy2 = {p.cy_d, p.cy_d};
   q.pcz = pcz;
   q.u = div_ieee2(fx2 * pcx, pcz) + cx2;
@@ -1002,44 +1004,65 @@ __device__ __forceinline__ void pair_project_raw(PairProj &q, f2 pcx, f2 pcy, f2
   const f2 half = {0.5f, 0.5f};
   const f2 ur = q.u + half, wr = q.w + half;
   // (a voxel that failed a test may produce any pixel index: its read stays inside the buffer resource or returns 0)
-  q.dm.x = q.act0 ? raw_depth_at(raw_rs, (int)ur.x, (int)wr.x, p.Wd, a, b) : 0.0f;
-  q.dm.y = q.act1 ? raw_depth_at(raw_rs, (int)ur.y, (int)wr.y, p.Wd, a, b) : 0.0f;
+  const unsigned off0 = ((unsigned)__mul24((int)wr.x, p.Wd) + (unsigned)(int)ur.x) << 1;
+  const unsigned off1 = ((unsigned)__mul24((int)wr.y, p.Wd) + (unsigned)(int)ur.y) << 1;
+  q.dm.x = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(raw_rs, off0 & ~3u, 0, 0));
+  q.dm.y = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(raw_rs, off1 & ~3u, 0, 0));
+  o.hi_half = ((off0 >> 1) & 1u) | (off1 & 2u);
 }
 
+__device__ __forceinline__ void raw_depth_finish(RawProj &o, float a, float b) {
+  const unsigned w0 = __float_as_uint(o.q.dm.x), w1 = __float_as_uint(o.q.dm.y);
+  const int r0 = (int)(short)((o.hi_half & 1u) ? (w0 >> 16) : (w0 & 0xffffu));
+  const int r1 = (int)(short)((o.hi_half & 2u) ? (w1 >> 16) : (w1 & 0xffffu));
+  o.q.dm.x = (r0 <= 0 || r0 > 32000) ? -1.0f : (float)r0 * a + b;
+  o.q.dm.y = (r1 <= 0 || r1 > 32000) ? -1.0f : (float)r1 * a + b;
+}
+
+constexpr int kBatchColQueue = 256;   // one slot per voxel of a half block
 struct BatchColQueue {   // (the colour queue of k_integrate: one per wave)
-  float u[kColQueue], w[kColQueue];
-  unsigned c[kColQueue], r[kColQueue];
-  unsigned char list[kColQueue];
+  float u[kBatchColQueue], w[kBatchColQueue];
+  unsigned c[kBatchColQueue], r[kBatchColQueue];
+  unsigned char list[kBatchColQueue];
 };
 
-// one operation on one half block (two 16-byte chunks per lane): k_integrate's packed path -- projection, depth update on
-// 2-vectors, narrow-band colour updates queued in LDS and run densely -- with the operation's own pose and images
+// One operation on one HALF block (the unit of work: two 16-byte chunks per lane).  Both chunks are projected and their
+// four depth pixels requested before the first update waits; the narrow-band colour updates of the half are queued in
+// LDS and run densely in one pass, as in k_integrate.  Half blocks, not blocks: the wave then needs ~90 registers instead
+// of ~140 (5 waves per SIMD instead of 3 to hide the two round trips of an operation behind each other's arithmetic)
+// and the batch has twice as many independent units to deal out.
 template <bool DEINT>
-__device__ __forceinline__ void batch_half(uint4 (&v)[2], bool (&chs)[2], int half, int gz, int vz0, const float (&pxy)[2][3],
-                                           const Mat4 &M, const IntegrateParams &p, __amdgpu_buffer_rsrc_t raw_rs, float a, float b,
-                                           const float *inv_tab, BatchColQueue &Q, int lane) {
-  int q_n = 0;
-  unsigned cms[2] = {0u, 0u};
+__device__ __forceinline__ void batch_op(uint4 (&v)[2], bool (&chs)[2], int gz0, const float (&pxy)[2][3], const float *Mm,
+                                         const IntegrateParams &p, __amdgpu_buffer_rsrc_t raw_rs, float a, float b, const float *inv_tab,
+                                         BatchColQueue &Q, int lane) {
+  RawProj rq[2];
 #pragma unroll
-  for (int jj = 0; jj < 2; jj++) {
-    const float fz = (float)(gz + (half * 2 + jj) * 2 + vz0) * p.voxel_size;
-    const float az0 = M.m[8] * fz, az1 = M.m[9] * fz, az2 = M.m[10] * fz;
+  for (int j = 0; j < 2; j++) {
+    const float fz = (float)(gz0 + j * 2) * p.voxel_size;   // (gz0: the z of this lane's voxels in the half's first chunk)
+    // (the pose is read from LDS where it is used: six registers less across the operation)
+    const float az0 = Mm[8] * fz, az1 = Mm[9] * fz, az2 = Mm[10] * fz;
     const f2 a0 = {az0, az0}, a1 = {az1, az1}, a2 = {az2, az2};
-    const f2 t0 = {M.m[12], M.m[12]}, t1 = {M.m[13], M.m[13]}, t2 = {M.m[14], M.m[14]};
+    const f2 t0 = {Mm[12], Mm[12]}, t1 = {Mm[13], Mm[13]}, t2 = {Mm[14], Mm[14]};
     const f2 px = {pxy[0][0], pxy[1][0]}, py = {pxy[0][1], pxy[1][1]}, pz = {pxy[0][2], pxy[1][2]};
-    PairProj q;
-    pair_project_raw(q, (px + a0) + t0, (py + a1) + t1, (pz + a2) + t2, p, raw_rs, a, b);
+    pair_project_raw(rq[j], (px + a0) + t0, (py + a1) + t1, (pz + a2) + t2, p, raw_rs);
+  }
+  int q_n = 0;
+  unsigned cms = 0;   // bit 2j + h: voxel h of chunk j is queued
+#pragma unroll
+  for (int j = 0; j < 2; j++) {
+    raw_depth_finish(rq[j], a, b);
+    const PairProj &q = rq[j].q;
     unsigned cm;
-    chs[jj] |= pair_update<DEINT, false>(v[jj], q, p, inv_tab, cm);
-    cms[jj] = cm;
+    chs[j] |= pair_update<DEINT, false>(v[j], q, p, inv_tab, cm);
+    cms |= cm << (2 * j);
     if (__ballot(cm != 0u)) {
 #pragma unroll
       for (int h = 0; h < 2; h++) {
         const bool c = (cm >> h) & 1u;
         const unsigned long long bm = __ballot(c);
         if (c) {
-          const unsigned lo = h ? v[jj].z : v[jj].x, hi = h ? v[jj].w : v[jj].y;
-          const int own = (jj * 2 + h) * 64 + lane;
+          const unsigned lo = h ? v[j].z : v[j].x, hi = h ? v[j].w : v[j].y;
+          const int own = (j * 2 + h) * 64 + lane;
           const int slot = q_n + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(bm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bm, 0u));
           Q.u[own] = h ? q.u.y : q.u.x;
           Q.w[own] = h ? q.w.y : q.w.x;
@@ -1059,17 +1082,17 @@ __device__ __forceinline__ void batch_half(uint4 (&v)[2], bool (&chs)[2], int ha
     }
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
-    for (int jj = 0; jj < 2; jj++)
+    for (int j = 0; j < 2; j++)
 #pragma unroll
       for (int h = 0; h < 2; h++)
-        if ((cms[jj] >> h) & 1u) {
-          const unsigned word = Q.r[(jj * 2 + h) * 64 + lane];
-          unsigned &lo = h ? v[jj].z : v[jj].x;
-          unsigned &hi = h ? v[jj].w : v[jj].y;
+        if ((cms >> (2 * j + h)) & 1u) {
+          const unsigned word = Q.r[(j * 2 + h) * 64 + lane];
+          unsigned &lo = h ? v[j].z : v[j].x;
+          unsigned &hi = h ? v[j].w : v[j].y;
           lo = __builtin_amdgcn_perm(word, lo, 0x04020100u);
           hi = __builtin_amdgcn_perm(hi, word, 0x07030201u);
         }
-    __builtin_amdgcn_wave_barrier();   // (the queue is refilled by the next half)
+    __builtin_amdgcn_wave_barrier();   // (the queue is refilled by the next operation)
   }
 }
 
@@ -1079,29 +1102,33 @@ constexpr int kBatchGrid = 1024;   // 8192 waves: one full residency wave; block
 __global__ __launch_bounds__(kBatchWgWaves * 64) void k_reintegrate_blocks(BatchParams bp) {
   __shared__ float inv_tab[kInvTab];
   __shared__ BatchColQueue col_q[kBatchWgWaves];
+  __shared__ BatchOp s_ops[64];   // the batch's operations: read per operation from LDS, not with a ~1 us scalar load each
   for (int i = threadIdx.x; i < kInvTab; i += kBatchWgWaves * 64) inv_tab[i] = recip_table_entry(i);
+  for (int i = threadIdx.x; i < bp.n_ops * (int)(sizeof(BatchOp) / 4); i += kBatchWgWaves * 64)
+    reinterpret_cast<unsigned *>(s_ops)[i] = reinterpret_cast<const unsigned *>(bp.ops)[i];
   __syncthreads();
   const IntegrateParams &p0 = bp.ip;
   const int lane = threadIdx.x & 63;
   BatchColQueue &Q = col_q[threadIdx.x >> 6];
-  const int n = bp.dirty_count[0];
+  const int n = bp.dirty_count[0] * 2;   // units of work: half blocks
   const int vx0 = (lane & 3) * 2, vy = (lane >> 2) & 7, vz0 = lane >> 5;
   while (true) {
     int i = 0;
     if (lane == 0) i = atomicAdd(bp.cursor, 1);
     i = __builtin_amdgcn_readfirstlane(i);
     if (i >= n) break;
-    const int ptr = __builtin_amdgcn_readfirstlane(bp.dirty_list[i]);
+    const int ptr = __builtin_amdgcn_readfirstlane(bp.dirty_list[i >> 1]);
+    const int half = i & 1;
     const unsigned long long mask = bp.opmask[ptr];
     // (before the shard test, as in k_integrate: every rank of a sharded batch ends up with the same marks and the same
     // rings) the block joins the list of every re-fusion that names it on the defusion ring
-    if (lane == 0) {
+    if (lane == 0 && half == 0) {
       if (p0.dirty) p0.dirty[ptr] = 1;
       if (p0.push_words) {
         unsigned long long *ring = p0.masks + ((size_t)ptr * 2 + p0.push_ring) * p0.push_words;
         int frame = -1;
         for (unsigned long long m = mask & 0xAAAAAAAAAAAAAAAAull; m; m &= m - 1) {
-          const BatchOp &op = bp.ops[__ffsll((long long)m) - 1];
+          const BatchOp &op = s_ops[__ffsll((long long)m) - 1];
           ring[op.push_bit >> 6] |= 1ull << (op.push_bit & 63);
           frame = op.push_frame;   // (ascending: the last re-fusion that lists the block)
         }
@@ -1113,43 +1140,38 @@ __global__ __launch_bounds__(kBatchWgWaves * 64) void k_reintegrate_blocks(Batch
     const HashEntry e = load_entry(p0.hash, bp.slot_entry[ptr]);
     const int gx = __builtin_amdgcn_readfirstlane((int)e.pos[0]) * kBlock, gy = __builtin_amdgcn_readfirstlane((int)e.pos[1]) * kBlock,
               gz = __builtin_amdgcn_readfirstlane((int)e.pos[2]) * kBlock;
-    uint4 *blk = p0.voxels16 + (size_t)ptr * (kBlock3 / 2);
-    uint4 va[2], vb[2];   // the two halves of the block
-    va[0] = blk[lane]; va[1] = blk[64 + lane]; vb[0] = blk[128 + lane]; vb[1] = blk[192 + lane];
-    bool cha[2] = {false, false}, chb[2] = {false, false};
+    uint4 *blk = p0.voxels16 + (size_t)ptr * (kBlock3 / 2) + half * 128;
+    uint4 v[2];
+    v[0] = blk[lane];
+    v[1] = blk[64 + lane];
+    bool chs[2] = {false, false};
+    const int gz0 = gz + half * 4 + vz0;
     const float fyv = (float)(gy + vy) * p0.voxel_size;
     float fxv[2];
     fxv[0] = (float)(gx + vx0) * p0.voxel_size;
     fxv[1] = (float)(gx + vx0 + 1) * p0.voxel_size;
-    unsigned mlo = (unsigned)mask, mhi = (unsigned)(mask >> 32);
+    const unsigned mlo = (unsigned)mask, mhi = (unsigned)(mask >> 32);
     for (int part = 0; part < 2; part++) {
       for (unsigned m = part ? mhi : mlo; m; m &= m - 1) {
         const int bit = __builtin_amdgcn_readfirstlane(part * 32 + __ffs((int)m) - 1);
-        const BatchOp &op = bp.ops[bit];
+        const BatchOp &op = s_ops[bit];
         IntegrateParams p = p0;
         p.rgba = op.rgba;
-        const Mat4 &M = op.M;
         float pxy[2][3];
 #pragma unroll
         for (int h = 0; h < 2; h++) {
-          pxy[h][0] = M.m[0] * fxv[h] + M.m[4] * fyv;
-          pxy[h][1] = M.m[1] * fxv[h] + M.m[5] * fyv;
-          pxy[h][2] = M.m[2] * fxv[h] + M.m[6] * fyv;
+          pxy[h][0] = op.M.m[0] * fxv[h] + op.M.m[4] * fyv;
+          pxy[h][1] = op.M.m[1] * fxv[h] + op.M.m[5] * fyv;
+          pxy[h][2] = op.M.m[2] * fxv[h] + op.M.m[6] * fyv;
         }
+        const float *Mz = op.M.m;
         const __amdgpu_buffer_rsrc_t raw_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<short *>(op.raw), 0, bp.raw_bytes, 0x00020000);
-        if (bit & 1) {   // re-fusion at the new pose; the block joins the keyframe's list on the defusion ring
-          batch_half<false>(va, cha, 0, gz, vz0, pxy, M, p, raw_rs, bp.a, bp.b, inv_tab, Q, lane);
-          batch_half<false>(vb, chb, 1, gz, vz0, pxy, M, p, raw_rs, bp.a, bp.b, inv_tab, Q, lane);
-        } else {         // de-integration at the old pose
-          batch_half<true>(va, cha, 0, gz, vz0, pxy, M, p, raw_rs, bp.a, bp.b, inv_tab, Q, lane);
-          batch_half<true>(vb, chb, 1, gz, vz0, pxy, M, p, raw_rs, bp.a, bp.b, inv_tab, Q, lane);
-        }
+        if (bit & 1) batch_op<false>(v, chs, gz0, pxy, Mz, p, raw_rs, bp.a, bp.b, inv_tab, Q, lane);   // re-fusion at the new pose
+        else batch_op<true>(v, chs, gz0, pxy, Mz, p, raw_rs, bp.a, bp.b, inv_tab, Q, lane);              // de-integration at the old one
       }
     }
-    if (cha[0]) blk[lane] = va[0];
-    if (cha[1]) blk[64 + lane] = va[1];
-    if (chb[0]) blk[128 + lane] = vb[0];
-    if (chb[1]) blk[192 + lane] = vb[1];
+    if (chs[0]) blk[lane] = v[0];
+    if (chs[1]) blk[64 + lane] = v[1];
   }
 }
 
@@ -1185,17 +1207,39 @@ __global__ __launch_bounds__(256) void k_batch_ops(const BatchListRef *__restric
   }
 }
 
+// The blocks with the most operations first: a wave fetches its next block from a counter, so the launch ends with whatever
+// was fetched last -- a block with 60 operations must not be that one.  Counting sort by popcount (65 bins), one workgroup.
+__global__ __launch_bounds__(1024) void k_batch_order(const int *__restrict__ list, const int *__restrict__ count,
+                                                      const unsigned long long *__restrict__ opmask, int *__restrict__ out) {
+  __shared__ int s_bin[65];
+  const int n = count[0];
+  if (threadIdx.x < 65) s_bin[threadIdx.x] = 0;
+  __syncthreads();
+  for (int i = threadIdx.x; i < n; i += 1024) atomicAdd(&s_bin[64 - __popcll(opmask[list[i]])], 1);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int run = 0;
+    for (int k = 0; k < 65; k++) { const int c = s_bin[k]; s_bin[k] = run; run += c; }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < n; i += 1024) {
+    const int slot = list[i];
+    out[atomicAdd(&s_bin[64 - __popcll(opmask[slot])], 1)] = slot;
+  }
+}
+
 int launch_batch_ops(dslam_engine *e, const void *lists_dev, int n_ops, const dslam_scene *s, const int *born,
-                     unsigned long long *opmask, int *slot_entry, int *dirty_list, int *dirty_count) {
+                     unsigned long long *opmask, int *slot_entry, int *dirty_list, int *dirty_count, int *ordered_list) {
   hipLaunchKernelGGL(k_batch_ops, dim3(32, n_ops), dim3(256), 0, e->stream, reinterpret_cast<const BatchListRef *>(lists_dev), s->hash,
                      born, opmask, slot_entry, dirty_list, dirty_count);
+  hipLaunchKernelGGL(k_batch_order, dim3(1), dim3(1024), 0, e->stream, dirty_list, dirty_count, opmask, ordered_list);
   DSLAM_HIP(hipGetLastError());
   return DSLAM_OK;
 }
 
 int launch_reintegrate_blocks(dslam_engine *e, dslam_scene *s, int w_d, int h_d, int w_rgb, int h_rgb, const float *intr,
                               float a, float b, const void *ops_dev, const unsigned long long *opmask, const int *slot_entry,
-                              const int *dirty_list, const int *dirty_count, int *cursor, int push_ring) {
+                              const int *dirty_list, const int *dirty_count, int *cursor, int push_ring, int n_ops) {
   BatchParams bp;
   IntegrateParams &ip = bp.ip;
   memset(&ip, 0, sizeof(ip));
@@ -1219,6 +1263,7 @@ int launch_reintegrate_blocks(dslam_engine *e, dslam_scene *s, int w_d, int h_d,
   bp.opmask = opmask; bp.slot_entry = slot_entry; bp.dirty_list = dirty_list; bp.dirty_count = dirty_count; bp.cursor = cursor;
   bp.a = a; bp.b = b;
   bp.raw_bytes = (w_d * h_d * 2 + 3) & ~3;
+  bp.n_ops = n_ops;
   hipLaunchKernelGGL(k_reintegrate_blocks, dim3(kBatchGrid), dim3(kBatchWgWaves * 64), 0, e->stream, bp);
   DSLAM_HIP(hipGetLastError());
   return DSLAM_OK;

@@ -49,19 +49,25 @@ def _update_view(api, view, frame, ts):
 
 
 def reintegrate(api, scene, view, rs, batch, rank=0, world=1, chunk_blocks=64, all_gather=None, timers=None,
-                force_collective=False, stored_lists=False):
+                force_collective=False, stored_lists=False, batched=False):
     """Run the batch on this rank; `all_gather(counts)` performs pack -> collective -> unpack for the per-shard dirty
     block counts (None when world == 1; force_collective runs it even for a single rank, as a plumbing check).
     stored_lists: the frames are ("store", frame_store, slot) keyframes whose fusion-time visible lists sit in the
     store; de-integration then skips its allocation pass (dslam_deprocess_frame_stored) -- the part of the batch that
-    every rank would otherwise repeat -- and the list of the re-fusion replaces the stored one."""
+    every rank would otherwise repeat -- and the list of the re-fusion replaces the stored one.
+    batched (implies stored lists, all keyframes in ONE store): the whole loop as one dslam_reintegrate_batch call -- the HIP
+    engine then runs it block-major (allocation passes first, every touched voxel block loaded once); same bytes."""
     t0 = time.perf_counter()
     collective = (world > 1 or force_collective) and all_gather is not None
     if collective:
         api.track_dirty(scene, True)
     if world > 1:
         api.set_shard(scene, rank, world, chunk_blocks)
-    for k in range(len(batch)):
+    if batched:
+        store = batch.frames[0][1]
+        assert all(f[0] == "store" and f[1] is store for f in batch.frames), "a batched run needs all keyframes in one store"
+        api.reintegrate_batch(scene, view, rs, store, [f[2] for f in batch.frames], batch.old_poses, batch.new_poses, batch.intr)
+    for k in range(0 if batched else len(batch)):
         _update_view(api, view, batch.frames[k], float(k))
         if stored_lists:
             api.deprocess_frame_stored(scene, view, batch.frames[k][1], batch.frames[k][2], batch.old_poses[k], batch.intr)

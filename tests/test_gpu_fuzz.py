@@ -124,8 +124,18 @@ def _trial(pkg, synth, gpu, oracle, seed, use_store=None, extras=True, more_ops=
             # own visible list, types and generation bit; upstream's local maps each own one)
             fuse_free = bool(more_ops and ops_v >= 2 and op == "fuse" and rng_store.random() < 0.125)
             slot = -1
+            batch = []  # [(slot, new pose)]: the keyframes one "refuse_stored" corrects (own random stream: the trials of earlier hunts are unchanged)
             if op == "refuse_stored" and stored:
                 slot = int(rng_store.choice(sorted(stored)))
+                batch = [(slot, M)]
+                rng_batch = np.random.default_rng(seed * 1000003 + step)
+                if extras and ops_v >= 2 and rng_batch.random() < 0.5:   # OnlineCorrection corrects several keyframes in one go
+                    for extra_slot in rng_batch.permutation([q for q in sorted(stored) if q != slot])[:int(rng_batch.integers(0, 3))]:
+                        jit = synth.pose_matrix(synth.look_rotation(rng_batch.normal(0, 0.01), rng_batch.normal(0, 0.01)), rng_batch.normal(0, 0.01, 3))
+                        batch.append((int(extra_slot), (np.asarray(wl.frame(int(extra_slot))[2], np.float64) @ jit).astype(np.float32)))
+                # dslam_reintegrate_batch (block-major) on the HIP engine where it applies; the oracle always runs the loop that defines it
+                use_batch_call = bool(extras and ops_v >= 2 and is_hip and not two_cam and not kw["stop_integrating_at_max_w"] and
+                                      not p.use_swapping and rng_batch.random() < 0.6)
             log.append((op, i, args))
             sharded = shard_mode and ((op == "refuse" and bool(fused)) or (op == "refuse_stored" and slot >= 0))
             chunk = 8
@@ -146,10 +156,15 @@ def _trial(pkg, synth, gpu, oracle, seed, use_store=None, extras=True, more_ops=
                     if use_store and not args[0]:
                         api.frame_store_put_visible_list(stores[name], i, s, free if fuse_free else rs)
                 elif op == "refuse_stored" and slot >= 0:
-                    api.view_update_from_store(v, stores[name], slot, timestamp=float(step))
-                    api.deprocess_frame_stored(s, v, stores[name], slot, stored[slot], wl.intr, **cam(stored[slot]))
-                    api.process_frame(s, v, rs, M, wl.intr, is_defusion=True, **cam(M))
-                    api.frame_store_put_visible_list(stores[name], slot, s, rs)
+                    if use_batch_call and name != "oracle":
+                        api.reintegrate_batch(s, v, rs, stores[name], [q for q, _ in batch], [stored[q] for q, _ in batch],
+                                              [Mq for _, Mq in batch], wl.intr)
+                    else:
+                        for q, Mq in batch:
+                            api.view_update_from_store(v, stores[name], q, timestamp=float(step))
+                            api.deprocess_frame_stored(s, v, stores[name], q, stored[q], wl.intr, **cam(stored[q]))
+                            api.process_frame(s, v, rs, Mq, wl.intr, is_defusion=True, **cam(Mq))
+                            api.frame_store_put_visible_list(stores[name], q, s, rs)
                 elif op == "refuse" and fused:
                     rgba_o, mm_o, M_o = fused[-1]
                     api.view_update(v, rgba_o, mm_o, timestamp=float(step))
@@ -205,8 +220,8 @@ def _trial(pkg, synth, gpu, oracle, seed, use_store=None, extras=True, more_ops=
                 gpu.synchronize()
             if op == "fuse" and not args[0] and use_store:
                 stored[i] = M
-            if op == "refuse_stored" and slot >= 0:
-                stored[slot] = M
+            for q, Mq in batch:
+                stored[q] = Mq
             if op == "fuse" and not args[0]:
                 rgba_n = rgba.copy()
                 rgba_n[..., 3] = 255 if args[1] else rgba[..., 3]
