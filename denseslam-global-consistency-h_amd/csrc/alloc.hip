@@ -197,7 +197,7 @@ __device__ __forceinline__ int ray_segment(float d, int x, int y, const Mat4 &in
   return no_steps;
 }
 
-// The re-test job of k_mark: workgroup = 256 words of the render state's visible bits (8192 entries).  An entry whose
+// The re-test job of k_mark: workgroup = 64 words of the render state's visible bits (2048 entries).  An entry whose
 // type byte carries the OTHER generation bit was visible in the previous pass (upstream re-arms it as 3 and tests it
 // against the frustum); a byte with THIS pass' bit is visible whatever the test says (marked by a pixel of this launch, or
 // a 1 / 2 that did not fit into the previous list and counts as marked again, see k_alloc_sweep).  The job only reads
@@ -205,23 +205,26 @@ __device__ __forceinline__ int ray_segment(float d, int x, int y, const Mat4 &in
 // The set bits are expanded into an LDS list and tested one per lane and round: visible entries of the excess area sit
 // in a few full words (excess slots are handed out contiguously), and a lane walking its own word would test 32 of them
 // one after the other while its neighbours idle.
+constexpr int kRetestWords = 64;   // words of vis_bits per workgroup of the re-test job: 2048 entries, 8 per thread
 __device__ __forceinline__ void retest_job(const MarkParams &p) {
   __shared__ int red[4];
-  __shared__ unsigned short s_list[8192];
-  __shared__ unsigned s_res[256];
-  const int w = blockIdx.x * 256 + threadIdx.x;   // (the job's workgroups cover the whole tiles of the bitmap)
-  if (w == 0) {  // the pool tops as they are before this pass' commits (the sweep's last tile moves them)
+  __shared__ unsigned short s_list[kRetestWords * 32];
+  __shared__ unsigned s_res[kRetestWords];
+  const int w = blockIdx.x * kRetestWords + (threadIdx.x >> 2);   // (the job's workgroups cover the whole tiles of the bitmap)
+  const int byte = threadIdx.x & 3;                               // this thread's 8 entries of the word
+  if (blockIdx.x == 0 && threadIdx.x == 0) {  // the pool tops as they are before this pass' commits (the sweep's last tile moves them)
     p.cnt->base_free = p.cnt->last_free;
     p.cnt->base_free_ex = p.cnt->last_free_ex;
   }
-  for (unsigned m = p.old_q1[w] | p.old_q2[w]; m; m &= m - 1) p.alloc_type[w * 32 + __ffs((int)m) - 1] = 0;
-  const unsigned bits = p.vis_bits[w];
-  s_res[threadIdx.x] = 0;
+  for (unsigned m = ((p.old_q1[w] | p.old_q2[w]) >> (8 * byte)) & 0xffu; m; m &= m - 1)
+    p.alloc_type[w * 32 + 8 * byte + __ffs((int)m) - 1] = 0;
+  const unsigned bits = (p.vis_bits[w] >> (8 * byte)) & 0xffu;
+  if (threadIdx.x < kRetestWords) s_res[threadIdx.x] = 0;
   int tot;
   const int rank = block_excl_scan<4>(__popc(bits), red, tot);
-  expand_bits(bits, threadIdx.x * 32, rank, s_list);
+  expand_bits(bits, threadIdx.x * 8, rank, s_list);
   __syncthreads();
-  const int t0 = blockIdx.x * 8192;
+  const int t0 = blockIdx.x * (kRetestWords * 32);
   for (int j = threadIdx.x; j < tot; j += 256) {
     const int rel = s_list[j], t = t0 + rel;
     const unsigned char ty = p.vis_type[t];
@@ -240,7 +243,7 @@ __device__ __forceinline__ void retest_job(const MarkParams &p) {
     if (keep) atomicOr(&s_res[rel >> 5], 1u << (rel & 31));
   }
   __syncthreads();
-  p.retest[w] = s_res[threadIdx.x];
+  if (threadIdx.x < kRetestWords) p.retest[blockIdx.x * kRetestWords + threadIdx.x] = s_res[threadIdx.x];
 }
 
 __global__ __launch_bounds__(256) void k_mark(MarkParams p) {
@@ -427,12 +430,17 @@ __device__ void walk_requests(const SweepParams &p, int limit_word, int avail_vb
   f1s = v[2];
 }
 
+// Order of work in a tile (what a workgroup waits for is other tiles' counts and its own dependent loads, so everything
+// that needs neither goes first and the loads of independent chains are in flight together):
+//   words -> request counts out -> [replay of the winners' walks || type bytes of the entries visible before] ->
+//   visible counts out -> look-back (by now the words in front are there) -> commits -> visible list
 template <bool SWAPPING>
 __global__ __launch_bounds__(256) void k_alloc_sweep(SweepParams p) {
   __shared__ int red[16];
   __shared__ int s_ticket;
   __shared__ unsigned s_newx[kBitTileWords];   // entries other tiles' commits create in this tile (excess area)
   __shared__ unsigned s_mk[kBitTileWords], s_qx[kBitTileWords];   // the tile's mark bits / entries this pass made visible
+  __shared__ unsigned s_cur[kBitTileWords];    // entries visible before whose type byte carries this pass' generation bit
   constexpr int kEmitWindow = 8192;
   __shared__ unsigned short s_list[kEmitWindow];
   // (snapshot taken by k_mark)
@@ -440,237 +448,239 @@ __global__ __launch_bounds__(256) void k_alloc_sweep(SweepParams p) {
   const int avail_vba = base_free + 1, avail_ex = base_free_ex + 1;
   const int b = take_ticket(p.ticket, p.ticket_base, &s_ticket);   // (one tile per workgroup, in starting order)
   if (b >= p.n_tiles) return;
+  const int w0 = b * kBitTileWords + threadIdx.x * 4;   // this thread's four words
+  const uint4 q1 = *reinterpret_cast<const uint4 *>(p.q1 + w0), q2 = *reinterpret_cast<const uint4 *>(p.q2 + w0);
+  const uint4 mk = *reinterpret_cast<const uint4 *>(p.mark + w0), rt = *reinterpret_cast<const uint4 *>(p.retest + w0);
+  const uint4 pold = *reinterpret_cast<const uint4 *>(p.vis_bits + w0);
+  const int tile_first = b * kBitTileEntries;
+  const bool last = b == p.n_tiles - 1;
+  const bool has_excess = tile_first + kBitTileEntries > p.num_buckets || last;   // other tiles' commits may create entries here
+  *reinterpret_cast<uint4 *>(&s_cur[threadIdx.x * 4]) = make_uint4(0, 0, 0, 0);
+  *reinterpret_cast<uint4 *>(&s_newx[threadIdx.x * 4]) = make_uint4(0, 0, 0, 0);
+  // ---- request counts out first: nothing about them depends on anything else ---------------------------------------------
+  const int c1 = popc4(q1), c2 = popc4(q2);
+  int r1, r2, tot1, tot2;
+  block_excl_scan2<4>(c1, c2, red, r1, r2, tot1, tot2);
+  if (threadIdx.x == 0) publish(p.agg_req, b, p.epoch, tot1, tot2);
+  // the other set of bitmaps starts the next pass clean
   {
-    const int w0 = b * kBitTileWords + threadIdx.x * 4;   // this thread's four words
-    const uint4 q1 = *reinterpret_cast<const uint4 *>(p.q1 + w0), q2 = *reinterpret_cast<const uint4 *>(p.q2 + w0);
-    const uint4 mk = *reinterpret_cast<const uint4 *>(p.mark + w0), rt = *reinterpret_cast<const uint4 *>(p.retest + w0);
-    const uint4 pold = *reinterpret_cast<const uint4 *>(p.vis_bits + w0);
-    const int tile_first = b * kBitTileEntries;
-    // `mark` only holds found entries that were not visible before (see k_mark); one that was is known by its type byte,
-    // which carries this pass' generation bit.  The re-test job has accepted every such byte it saw -- but it ran while
-    // the pixels were still marking, and an entry that fails the block frustum test can be marked all the same (a block
-    // that cuts a corner of the image without one of its own corners inside).  So the bytes of the entries the job turned
-    // down are looked at once more, now that the marking is over; dense, through the LDS list, because those entries
-    // cluster like the visible ones do.  Usually there are none to a few dozen per tile.
-    uint4 late = make_uint4(0, 0, 0, 0);
-    {
-      const uint4 cand = andn4v(pold, rt);
-      *reinterpret_cast<uint4 *>(&s_qx[threadIdx.x * 4]) = make_uint4(0, 0, 0, 0);
-      int ctot;
-      const int crank = block_excl_scan<4>(popc4(cand), red, ctot);
-      if (ctot > 0) {
-        for (int win = 0; win < ctot; win += kEmitWindow) {
-          __syncthreads();
-          int r = crank - win;
+    const uint4 z = make_uint4(0, 0, 0, 0);
+    *reinterpret_cast<uint4 *>(p.oq1 + w0) = z;
+    *reinterpret_cast<uint4 *>(p.oq2 + w0) = z;
+    *reinterpret_cast<uint4 *>(p.omark + w0) = z;
+  }
+  // ---- replay: the block every request of this thread asks for (needs no rank; the commit further down does) -----------
+  // the final key of a slot names its winner (pixel, step); its walk is replayed to the block it asked for
+  short4 bc_first = make_short4(0, 0, 0, 0);   // (the first request's coordinates stay in registers; a thread rarely has two)
+  {
+    bool first = true;
 #pragma unroll 1
-          for (int i = 0; i < 4; i++)
-            for (unsigned m = sel4(cand, i); m; m &= m - 1) {
-              if (r >= 0 && r < kEmitWindow) s_list[r] = (unsigned short)((threadIdx.x * 4 + i) * 32 + __ffs((int)m) - 1);
-              r++;
-            }
-          __syncthreads();
-          const int n_win = (ctot - win) < kEmitWindow ? (ctot - win) : kEmitWindow;
-          for (int j = threadIdx.x; j < n_win; j += 256) {
-            const int rel = s_list[j];
-            const unsigned char ty = p.vis_type[tile_first + rel];
-            if (ty != 0 && (ty & 0x80u) == p.gen) atomicOr(&s_qx[rel >> 5], 1u << (rel & 31));
-          }
-        }
-        __syncthreads();
-        late = *reinterpret_cast<const uint4 *>(&s_qx[threadIdx.x * 4]);
-        __syncthreads();   // (s_qx is used again further down)
+    for (int i = 0; i < 4; i++) {
+      const unsigned a2 = sel4(q2, i);
+      for (unsigned m = sel4(q1, i) | a2; m; m &= m - 1) {
+        const int bit = __ffs((int)m) - 1;
+        const int t = (w0 + i) * 32 + bit;
+        const unsigned kz = p.keys[t] - 1u;
+        p.keys[t] = 0;   // leave the keys clean for the next pass
+        const int pix = (int)(kz >> p.cap_shift), step = (int)(kz & ((1u << p.cap_shift) - 1u));
+        const int py = pix / p.W, px = pix - py * p.W;
+        Vec3 pt, dir;
+        ray_segment(p.depth[pix], px, py, p.invM, p.inv_fx, p.inv_fy, p.cx, p.cy, p.mu, p.one_over_block, pt, dir);
+        for (int s = 0; s < step; s++) { pt.x += dir.x; pt.y += dir.y; pt.z += dir.z; }
+        const short4 bc = make_short4((short)(int)floorf(pt.x), (short)(int)floorf(pt.y), (short)(int)floorf(pt.z), 1);
+        p.alloc_type[t] = ((a2 >> bit) & 1u) ? 2 : 1;
+        p.coords[t] = bc;
+        if (first) { bc_first = bc; first = false; }
       }
     }
-    const uint4 seen = or4v(or4v(rt, mk), late);
-    // ---- counts out first: nothing a tile publishes depends on another tile -------------------------------------------
-    const int c1 = popc4(q1), c2 = popc4(q2);
-    int r1, r2, tot1, tot2;
-    block_excl_scan2<4>(c1, c2, red, r1, r2, tot1, tot2);
-    int tv[4] = {popc4(seen), popc4(andn4v(q1, seen)), 0, 0};
-    block_sum4(tv, red);
-    if (threadIdx.x == 0) {
-      publish(p.agg_req, b, p.epoch, tot1, tot2);
-      publish(p.agg_vis, b, p.epoch, tv[0], tv[1]);
-    }
-    // the other set of bitmaps starts the next pass clean
-    {
-      const uint4 z = make_uint4(0, 0, 0, 0);
-      *reinterpret_cast<uint4 *>(p.oq1 + w0) = z;
-      *reinterpret_cast<uint4 *>(p.oq2 + w0) = z;
-      *reinterpret_cast<uint4 *>(p.omark + w0) = z;
-    }
-    const bool last = b == p.n_tiles - 1;
-    const bool has_excess = tile_first + kBitTileEntries > p.num_buckets || last;   // other tiles' commits may create entries here
-    s_newx[threadIdx.x * 4] = 0; s_newx[threadIdx.x * 4 + 1] = 0; s_newx[threadIdx.x * 4 + 2] = 0; s_newx[threadIdx.x * 4 + 3] = 0;
-    // requests of the tiles behind this one: only the tiles of the excess area need them (for the totals), and there
-    // only excess requests exist -- counted straight from the bitmap
-    int later2 = 0;
-    if (has_excess)
-      for (int w = (b + 1) * kBitTileWords + threadIdx.x * 4; w < p.n_words; w += 1024) later2 += popc4(*reinterpret_cast<const uint4 *>(p.q2 + w));
-    int pre[4];  // requests (type 1, type 2) and visible entries (retest | mark; new type-1 requests) in front of this tile
-    if (!lookback2(p.agg_req, p.agg_vis, b, p.epoch, red, pre) && threadIdx.x == 0) atomicOr(&p.cnt->error_flags, 2);
-    int lv[4] = {later2, 0, 0, 0};
-    if (has_excess) block_sum4(lv, red);
-    const int all1 = pre[0] + tot1, all2 = pre[1] + tot2 + lv[0];   // (meaningful for has_excess tiles)
-    // ---- does a pool run out?  (wave-uniform decisions) --------------------------------------------------------------
-    const int vr_start = pre[0] + (pre[1] < avail_ex ? pre[1] : avail_ex);
-    int vq_before = pre[3];   // visible type-1 requests in front of this tile that are not in (retest | mark)
-    int seen_before = pre[2]; // entries in (retest | mark) in front of this tile that stay visible
-    int succ2_all = 0;        // successful type-2 requests of the whole pass (has_excess tiles)
-    if (p.do_commit) {
-      const bool dry_before = vr_start > avail_vba;
-      const bool dry_total = has_excess && all1 + (all2 < avail_ex ? all2 : avail_ex) > avail_vba;
-      if (dry_before || dry_total) {
-        int s1q, f1s, s2;
-        walk_requests(p, b * kBitTileWords, avail_vba, avail_ex, red, s1q, f1s, s2);
-        if (dry_before) { vq_before = s1q; seen_before -= f1s; }
-        succ2_all = s2;
-      } else {
-        succ2_all = all2 < avail_ex ? all2 : avail_ex;
-      }
-    }
-    // ---- this tile's requests: replay, rank, commit -------------------------------------------------------------------
-    uint4 qvis = make_uint4(0, 0, 0, 0);   // type-1 requests that make their entry visible in this pass
-    uint4 qfail = make_uint4(0, 0, 0, 0);  // type-1 requests that found no block: the entry is not visible, whatever it was
-    {
-      int k1 = pre[0] + r1, k2 = pre[1] + r2;
-#pragma unroll 1
-      for (int i = 0; i < 4; i++) {
-        const unsigned a1 = sel4(q1, i), a2 = sel4(q2, i);
-        for (unsigned m = a1 | a2; m; m &= m - 1) {
-          const int bit = __ffs((int)m) - 1;
-          const int t = (w0 + i) * 32 + bit;
-          const bool is2 = (a2 >> bit) & 1u;
-          // replay the winning pixel's walk up to the winning step: the block it asked for
-          const unsigned kz = p.keys[t] - 1u;
-          p.keys[t] = 0;   // leave the keys clean for the next pass
-          const int pix = (int)(kz >> p.cap_shift), step = (int)(kz & ((1u << p.cap_shift) - 1u));
-          const int py = pix / p.W, px = pix - py * p.W;
-          Vec3 pt, dir;
-          ray_segment(p.depth[pix], px, py, p.invM, p.inv_fx, p.inv_fy, p.cx, p.cy, p.mu, p.one_over_block, pt, dir);
-          for (int s = 0; s < step; s++) { pt.x += dir.x; pt.y += dir.y; pt.z += dir.z; }
-          const short4 bc = make_short4((short)(int)floorf(pt.x), (short)(int)floorf(pt.y), (short)(int)floorf(pt.z), 1);
-          p.alloc_type[t] = is2 ? 2 : 1;
-          p.coords[t] = bc;
-          // voxel-block slots consumed by all earlier requests in hash-index order (closed form)
-          const int vr = k1 + (k2 < avail_ex ? k2 : avail_ex);
-          if (!is2) {
-            const bool ok = p.do_commit && vr < avail_vba;
-            if (ok) {
-              const int slot = p.alloc_list[base_free - vr];
-              store_entry(p.hash, t, bc.x, bc.y, bc.z, 0, slot);
-              bit_set(p.alloc_bits, t);
-              if (p.born) p.born[slot] = p.born_stamp;
-            }
-            // without the commit (onlyUpdateVisibleList) the request alone makes the entry "visible" this pass, like
-            // upstream; with it, only if it got a block
-            if (ok || !p.do_commit) {
-              p.vis_type[t] = (unsigned char)(p.gen | 1u);
-              or4(qvis, i, 1u << bit);
-            } else {
-              or4(qfail, i, 1u << bit);
-            }
-            k1++;
-          } else {
-            if (p.do_commit && k2 < avail_ex && vr < avail_vba) {
-              const int ex_off = p.excess_list[base_free_ex - k2];
-              const int slot = p.alloc_list[base_free - vr];
-              p.hash[t].offset = ex_off + 1;
-              store_entry(p.hash, p.num_buckets + ex_off, bc.x, bc.y, bc.z, 0, slot);
-              bit_set(p.alloc_bits, p.num_buckets + ex_off);
-              if (p.born) p.born[slot] = p.born_stamp;
-              // (its type byte and its place in the visible list are the business of the tile that owns the new entry)
-            }
-            k2++;
-          }
-        }
-      }
-    }
-    // ---- entries other tiles create in the excess area: the first succ2_all slots off the excess free list ---------------
-    int newx_before = 0;   // ... of them in front of this tile and not counted as (retest | mark) there
-    __syncthreads();       // (s_newx zeroed)
-    if (has_excess) {
-      for (int j = threadIdx.x; j < succ2_all; j += 256) {
-        const int t = p.num_buckets + p.excess_list[base_free_ex - j];
-        const int rel = t - tile_first;
-        if (rel >= 0 && rel < kBitTileEntries) atomicOr(&s_newx[rel >> 5], 1u << (rel & 31));
-        else if (rel < 0 && !(((p.retest[t >> 5] | p.mark[t >> 5]) >> (t & 31)) & 1u)) newx_before++;
-      }
-      int nv[4] = {newx_before, 0, 0, 0};
-      block_sum4(nv, red);   // (has a barrier: s_newx is complete behind it)
-      newx_before = nv[0];
-    }
-    const uint4 newx = has_excess ? *reinterpret_cast<const uint4 *>(&s_newx[threadIdx.x * 4]) : make_uint4(0, 0, 0, 0);
-    // ---- the visible list -----------------------------------------------------------------------------------------------
-    const uint4 vis = or4v(or4v(andn4v(seen, qfail), qvis), newx);
-    int vis_tot;
-    const int vis_rank = block_excl_scan<4>(popc4(vis), red, vis_tot);   // (its barriers also order the request lanes' type bytes)
-    const int vis_first = seen_before + vq_before + newx_before;
-    // entries that are no longer visible (stores only: nothing to wait for)
-#pragma unroll 1
-    for (int i = 0; i < 4; i++)
-      for (unsigned m = sel4(pold, i) & ~sel4(vis, i); m; m &= m - 1) p.vis_type[(w0 + i) * 32 + __ffs((int)m) - 1] = 0;
-    // The visible entries are written densely: expanded into an LDS list (a window of kEmitWindow ranks at a time), then
-    // one entry per lane and round -- coalesced list stores, and the visible entries of the excess area, which fill a few
-    // words completely (excess slots are handed out contiguously), do not queue up behind a single lane.
-    *reinterpret_cast<uint4 *>(&s_mk[threadIdx.x * 4]) = mk;
-    *reinterpret_cast<uint4 *>(&s_qx[threadIdx.x * 4]) = or4v(qvis, newx);   // (the pass made these visible itself: type 1)
-    for (int win = 0; win < vis_tot; win += kEmitWindow) {
-      __syncthreads();   // (s_mk / s_qx written; the previous window read)
-      {
-        int r = vis_rank - win;
-#pragma unroll 1
-        for (int i = 0; i < 4; i++)
-          for (unsigned m = sel4(vis, i); m; m &= m - 1) {
-            if (r >= 0 && r < kEmitWindow) s_list[r] = (unsigned short)((threadIdx.x * 4 + i) * 32 + __ffs((int)m) - 1);
-            r++;
-          }
-      }
+  }
+  // ---- the type bytes of the entries that were visible before the pass ---------------------------------------------------
+  // A byte with this pass' generation bit: marked by a pixel of k_mark (`mark` only holds found entries that were NOT
+  // visible before), or a 1 / 2 that counts as marked again.  The re-test job has accepted every such byte it saw -- but
+  // it ran while the pixels were still marking, and an entry that fails the block frustum test can be marked all the same
+  // (a block that cuts a corner of the image without one of its own corners inside) -- so the bytes are read once more, now
+  // that the marking is over, densely through the LDS list (visible entries of the excess area fill whole words).  The same
+  // pass tells the list writer below which entries are upstream's 3s (visible before, not marked now): no byte is read there.
+  {
+    int ctot;
+    const int crank = block_excl_scan<4>(popc4(pold), red, ctot);
+    for (int win = 0; win < ctot; win += kEmitWindow) {
       __syncthreads();
-      const int n_win = (vis_tot - win) < kEmitWindow ? (vis_tot - win) : kEmitWindow;
-      for (int j = threadIdx.x; j < n_win; j += 256) {
-        const int rel = s_list[j], t = tile_first + rel, r = vis_first + win + j;
-        const bool in_mk = (s_mk[rel >> 5] >> (rel & 31)) & 1u, in_qx = (s_qx[rel >> 5] >> (rel & 31)) & 1u;
-        const bool in_x = has_excess && ((s_newx[rel >> 5] >> (rel & 31)) & 1u);
-        if (r < p.capacity) {
-          p.visible_ids[r] = t;
-          if (in_x) {
-            p.vis_type[t] = (unsigned char)(p.gen | 1u);   // (an entry another tile's commit created here)
-          } else if (!in_mk && !in_qx) {
-            // visible before, not marked now, inside the frustum: upstream's 3 (a byte with this pass' bit is a 1 / 2
-            // that counts as marked again: it stays)
-            const unsigned char ty = p.vis_type[t];
-            if ((ty & 0x80u) != p.gen) p.vis_type[t] = (unsigned char)(p.gen | 3u);
-          }
-        } else {
-          // no room in the list: upstream leaves the type in place without the entry being re-armed next pass, so
-          // a 1 / 2 counts as marked again then (next pass' bit), a 3 is re-tested (this pass' bit)
-          unsigned ty = 1;
-          if (!in_qx) {
-            const unsigned char old = p.vis_type[t];
-            ty = (in_mk || (old & 0x80u) == p.gen) ? (old & 0x7fu) : 3u;
-          }
-          p.vis_type[t] = (unsigned char)((ty == 3 ? p.gen : (p.gen ^ 0x80u)) | ty);
+      int r = crank - win;
+#pragma unroll 1
+      for (int i = 0; i < 4; i++)
+        for (unsigned m = sel4(pold, i); m; m &= m - 1) {
+          if (r >= 0 && r < kEmitWindow) s_list[r] = (unsigned short)((threadIdx.x * 4 + i) * 32 + __ffs((int)m) - 1);
+          r++;
         }
-        if (SWAPPING) {   // a visible entry's host copy (if it has one) is wanted back: IntegrateGlobalIntoLocal's state 1
-          const unsigned char st = p.swap_state[t];
-          if (st == 0) { p.swap_state[t] = 1; bit_set(p.swap1_bits, t); }
+      __syncthreads();
+      const int n_win = (ctot - win) < kEmitWindow ? (ctot - win) : kEmitWindow;
+      for (int j = threadIdx.x; j < n_win; j += 256) {
+        const int rel = s_list[j];
+        const unsigned char ty = p.vis_type[tile_first + rel];
+        if (ty != 0 && (ty & 0x80u) == p.gen) atomicOr(&s_cur[rel >> 5], 1u << (rel & 31));
+      }
+    }
+    __syncthreads();
+  }
+  const uint4 cur = *reinterpret_cast<const uint4 *>(&s_cur[threadIdx.x * 4]);
+  const uint4 seen = or4v(or4v(rt, mk), cur);   // (cur & ~rt: marked after the re-test job looked)
+  int tv[4] = {popc4(seen), popc4(andn4v(q1, seen)), 0, 0};
+  block_sum4(tv, red);
+  if (threadIdx.x == 0) publish(p.agg_vis, b, p.epoch, tv[0], tv[1]);
+  // requests of the tiles behind this one: only the tiles of the excess area need them (for the totals), and there
+  // only excess requests exist -- counted straight from the bitmap
+  int later2 = 0;
+  if (has_excess)
+    for (int w = (b + 1) * kBitTileWords + threadIdx.x * 4; w < p.n_words; w += 1024) later2 += popc4(*reinterpret_cast<const uint4 *>(p.q2 + w));
+  int pre[4];  // requests (type 1, type 2) and visible entries (seen; new type-1 requests) in front of this tile
+  if (!lookback2(p.agg_req, p.agg_vis, b, p.epoch, red, pre) && threadIdx.x == 0) atomicOr(&p.cnt->error_flags, 2);
+  int lv[4] = {later2, 0, 0, 0};
+  if (has_excess) block_sum4(lv, red);
+  const int all1 = pre[0] + tot1, all2 = pre[1] + tot2 + lv[0];   // (meaningful for has_excess tiles)
+  // ---- does a pool run out?  (wave-uniform decisions) ----------------------------------------------------------------
+  const int vr_start = pre[0] + (pre[1] < avail_ex ? pre[1] : avail_ex);
+  int vq_before = pre[3];   // visible type-1 requests in front of this tile that are not in `seen` there
+  int seen_before = pre[2]; // entries in `seen` in front of this tile that stay visible
+  int succ2_all = 0;        // successful type-2 requests of the whole pass (has_excess tiles)
+  if (p.do_commit) {
+    const bool dry_before = vr_start > avail_vba;
+    const bool dry_total = has_excess && all1 + (all2 < avail_ex ? all2 : avail_ex) > avail_vba;
+    if (dry_before || dry_total) {
+      int s1q, f1s, s2;
+      walk_requests(p, b * kBitTileWords, avail_vba, avail_ex, red, s1q, f1s, s2);
+      if (dry_before) { vq_before = s1q; seen_before -= f1s; }
+      succ2_all = s2;
+    } else {
+      succ2_all = all2 < avail_ex ? all2 : avail_ex;
+    }
+  }
+  // ---- this tile's requests: rank, commit ---------------------------------------------------------------------------------
+  uint4 qvis = make_uint4(0, 0, 0, 0);   // type-1 requests that make their entry visible in this pass
+  uint4 qfail = make_uint4(0, 0, 0, 0);  // type-1 requests that found no block: the entry is not visible, whatever it was
+  {
+    int k1 = pre[0] + r1, k2 = pre[1] + r2;
+    bool first = true;
+#pragma unroll 1
+    for (int i = 0; i < 4; i++) {
+      const unsigned a1 = sel4(q1, i), a2 = sel4(q2, i);
+      for (unsigned m = a1 | a2; m; m &= m - 1) {
+        const int bit = __ffs((int)m) - 1;
+        const int t = (w0 + i) * 32 + bit;
+        const bool is2 = (a2 >> bit) & 1u;
+        const short4 bc = first ? bc_first : p.coords[t];   // (this thread wrote it above)
+        first = false;
+        // voxel-block slots consumed by all earlier requests in hash-index order (closed form)
+        const int vr = k1 + (k2 < avail_ex ? k2 : avail_ex);
+        if (!is2) {
+          const bool ok = p.do_commit && vr < avail_vba;
+          if (ok) {
+            const int slot = p.alloc_list[base_free - vr];
+            store_entry(p.hash, t, bc.x, bc.y, bc.z, 0, slot);
+            bit_set(p.alloc_bits, t);
+            if (p.born) p.born[slot] = p.born_stamp;
+          }
+          // without the commit (onlyUpdateVisibleList) the request alone makes the entry "visible" this pass, like
+          // upstream; with it, only if it got a block
+          if (ok || !p.do_commit) {
+            p.vis_type[t] = (unsigned char)(p.gen | 1u);
+            or4(qvis, i, 1u << bit);
+          } else {
+            or4(qfail, i, 1u << bit);
+          }
+          k1++;
+        } else {
+          if (p.do_commit && k2 < avail_ex && vr < avail_vba) {
+            const int ex_off = p.excess_list[base_free_ex - k2];
+            const int slot = p.alloc_list[base_free - vr];
+            p.hash[t].offset = ex_off + 1;
+            store_entry(p.hash, p.num_buckets + ex_off, bc.x, bc.y, bc.z, 0, slot);
+            bit_set(p.alloc_bits, p.num_buckets + ex_off);
+            if (p.born) p.born[slot] = p.born_stamp;
+            // (its type byte and its place in the visible list are the business of the tile that owns the new entry)
+          }
+          k2++;
         }
       }
     }
-    *reinterpret_cast<uint4 *>(p.vis_bits + w0) = vis;
-    if (last && threadIdx.x == 0) {
-      const int n = vis_first + vis_tot;
-      p.rc->no_visible = n < p.capacity ? n : p.capacity;
-      if (p.do_commit) {
-        const int vr_all = all1 + (all2 < avail_ex ? all2 : avail_ex);
-        const int succ_vba = vr_all < avail_vba ? vr_all : avail_vba;   // every success takes exactly one voxel-block slot
-        p.cnt->last_free = base_free - succ_vba;
-        p.cnt->last_free_ex = base_free_ex - succ2_all;
-        p.cnt->alloc_failures = all1 + all2 - succ_vba;
+  }
+  // ---- entries other tiles create in the excess area: the first succ2_all slots off the excess free list -----------------
+  int newx_before = 0;   // ... of them in front of this tile and not counted as `seen` there
+  if (has_excess) {
+    for (int j = threadIdx.x; j < succ2_all; j += 256) {
+      const int t = p.num_buckets + p.excess_list[base_free_ex - j];
+      const int rel = t - tile_first;
+      if (rel >= 0 && rel < kBitTileEntries) atomicOr(&s_newx[rel >> 5], 1u << (rel & 31));
+      // (a free excess slot has no live entry: k_mark cannot have marked it, so `seen` there is retest | mark)
+      else if (rel < 0 && !(((p.retest[t >> 5] | p.mark[t >> 5]) >> (t & 31)) & 1u)) newx_before++;
+    }
+    int nv[4] = {newx_before, 0, 0, 0};
+    block_sum4(nv, red);   // (has a barrier: s_newx is complete behind it)
+    newx_before = nv[0];
+  }
+  const uint4 newx = has_excess ? *reinterpret_cast<const uint4 *>(&s_newx[threadIdx.x * 4]) : make_uint4(0, 0, 0, 0);
+  // ---- the visible list -------------------------------------------------------------------------------------------------
+  const uint4 vis = or4v(or4v(andn4v(seen, qfail), qvis), newx);
+  int vis_tot;
+  const int vis_rank = block_excl_scan<4>(popc4(vis), red, vis_tot);
+  const int vis_first = seen_before + vq_before + newx_before;
+  // entries that are no longer visible (stores only: nothing to wait for)
+#pragma unroll 1
+  for (int i = 0; i < 4; i++)
+    for (unsigned m = sel4(pold, i) & ~sel4(vis, i); m; m &= m - 1) p.vis_type[(w0 + i) * 32 + __ffs((int)m) - 1] = 0;
+  // The visible entries are written densely: expanded into an LDS list (a window of kEmitWindow ranks at a time), then
+  // one entry per lane and round -- coalesced list stores, and the visible entries of the excess area, which fill a few
+  // words completely (excess slots are handed out contiguously), do not queue up behind a single lane.
+  *reinterpret_cast<uint4 *>(&s_mk[threadIdx.x * 4]) = or4v(mk, cur);         // marked in this pass: the byte is right as it is
+  *reinterpret_cast<uint4 *>(&s_qx[threadIdx.x * 4]) = or4v(qvis, newx);      // made visible by this pass itself: type 1
+  for (int win = 0; win < vis_tot; win += kEmitWindow) {
+    __syncthreads();   // (s_mk / s_qx written; the previous window read)
+    {
+      int r = vis_rank - win;
+#pragma unroll 1
+      for (int i = 0; i < 4; i++)
+        for (unsigned m = sel4(vis, i); m; m &= m - 1) {
+          if (r >= 0 && r < kEmitWindow) s_list[r] = (unsigned short)((threadIdx.x * 4 + i) * 32 + __ffs((int)m) - 1);
+          r++;
+        }
+    }
+    __syncthreads();
+    const int n_win = (vis_tot - win) < kEmitWindow ? (vis_tot - win) : kEmitWindow;
+    for (int j = threadIdx.x; j < n_win; j += 256) {
+      const int rel = s_list[j], t = tile_first + rel, r = vis_first + win + j;
+      const bool in_mk = (s_mk[rel >> 5] >> (rel & 31)) & 1u, in_qx = (s_qx[rel >> 5] >> (rel & 31)) & 1u;
+      const bool in_x = has_excess && ((s_newx[rel >> 5] >> (rel & 31)) & 1u);
+      if (r < p.capacity) {
+        p.visible_ids[r] = t;
+        // an entry another tile's commit created here: type 1; visible before, not marked now, inside the frustum:
+        // upstream's 3; everything else carries its type already
+        if (in_x) p.vis_type[t] = (unsigned char)(p.gen | 1u);
+        else if (!in_mk && !in_qx) p.vis_type[t] = (unsigned char)(p.gen | 3u);
       } else {
-        p.cnt->alloc_failures = 0;
+        // no room in the list: upstream leaves the type in place without the entry being re-armed next pass, so
+        // a 1 / 2 counts as marked again then (next pass' bit), a 3 is re-tested (this pass' bit)
+        unsigned ty = 1;
+        if (!in_qx) ty = in_mk ? (p.vis_type[t] & 0x7fu) : 3u;
+        p.vis_type[t] = (unsigned char)((ty == 3 ? p.gen : (p.gen ^ 0x80u)) | ty);
       }
+      if (SWAPPING) {   // a visible entry's host copy (if it has one) is wanted back: IntegrateGlobalIntoLocal's state 1
+        const unsigned char st = p.swap_state[t];
+        if (st == 0) { p.swap_state[t] = 1; bit_set(p.swap1_bits, t); }
+      }
+    }
+  }
+  *reinterpret_cast<uint4 *>(p.vis_bits + w0) = vis;
+  if (last && threadIdx.x == 0) {
+    const int n = vis_first + vis_tot;
+    p.rc->no_visible = n < p.capacity ? n : p.capacity;
+    if (p.do_commit) {
+      const int vr_all = all1 + (all2 < avail_ex ? all2 : avail_ex);
+      const int succ_vba = vr_all < avail_vba ? vr_all : avail_vba;   // every success takes exactly one voxel-block slot
+      p.cnt->last_free = base_free - succ_vba;
+      p.cnt->last_free_ex = base_free_ex - succ2_all;
+      p.cnt->alloc_failures = all1 + all2 - succ_vba;
+    } else {
+      p.cnt->alloc_failures = 0;
     }
   }
 }
@@ -824,7 +834,7 @@ int launch_allocate(dslam_engine *e, dslam_scene *s, const dslam_view *v, dslam_
   mp.q1 = e->bits_q1[cur]; mp.q2 = e->bits_q2[cur]; mp.mark = e->bits_mark[cur];
   mp.old_q1 = e->bits_q1[oth]; mp.old_q2 = e->bits_q2[oth];
   mp.vis_bits = r->vis_bits; mp.retest = e->bits_retest;
-  mp.retest_wgs = n_words / 256; mp.n_words = n_words;
+  mp.retest_wgs = n_words / kRetestWords; mp.n_words = n_words;
   memcpy(mp.M.m, M_d, sizeof(float) * 16);
   mp.fx = intr[0]; mp.fy = intr[1]; mp.voxel_size = s->p.voxel_size;
   mp.swapping = s->p.use_swapping ? 1 : 0;

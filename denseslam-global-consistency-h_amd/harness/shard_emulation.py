@@ -6,7 +6,7 @@ bytes a rank receives and the xGMI link rate, and labelled as a model.
 
     python denseslam-global-consistency-h_amd/harness/shard_emulation.py [keyframes_in_map] [batch]
 
-prints one JSON object (profiles/r02_shard_emulation.json).
+prints one JSON object (profiles/r03_shard_emulation.json).
 """
 import json
 import sys
@@ -56,7 +56,8 @@ def main():
     out = {"workload": f"{wl.name} 640x480, map of {n_map} keyframes, batch = the last {K} de-/re-integrated at corrected poses",
            "chunk_blocks": chunk, "variants": {}}
     for variant, stored in (("allocation pass at the old pose (DeProcessFrame as the reference calls it)", False),
-                            ("keyframe's stored visible list (dslam_deprocess_frame_stored)", True)):
+                            ("keyframe's stored visible list (dslam_deprocess_frame_stored)", True),
+                            ("block-major batch (dslam_reintegrate_batch)", "batch")):
         rows = {}
         for world in (1, 2, 4, 8):
             per_rank, exch = [], []
@@ -69,7 +70,9 @@ def main():
                 if world > 1:
                     eng.set_shard(scene, rank, world, chunk)
                 eng.set_async(True)
-                for k in range(len(batch)):
+                if stored == "batch":
+                    eng.reintegrate_batch(scene, view, rs, store, ids, batch.old_poses, batch.new_poses, wl.intr)
+                for k in range(0 if stored == "batch" else len(batch)):
                     eng.view_update_from_store(view, store, ids[k], timestamp=float(k))
                     if stored:
                         eng.deprocess_frame_stored(scene, view, store, ids[k], batch.old_poses[k], wl.intr)

@@ -9,13 +9,27 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 
-def build_map(api, pkg, wl, params, n_frames, maintenance):
+def build_map(api, pkg, wl, params, n_frames, maintenance, store=None):
     """Fuse n_frames; with `maintenance` the map is also decayed and slid like BASELINE configs[2] (reference
-    DenseSlam.cpp:215-232), so that freed slots have gone back to the pool in arbitrary order and live blocks sit anywhere."""
+    DenseSlam.cpp:215-232), so that freed slots have gone back to the pool in arbitrary order and live blocks sit anywhere.
+    store: a list that receives a keyframe store holding every keyframe's images and fusion-time visible list."""
     import util
-    if not maintenance:
-        return util.run_sequence(api, pkg, wl, params, n_frames)
-    return util.run_sequence(api, pkg, wl, params, n_frames, decay=(1, 2, True), slide=2)
+    box = {}
+
+    def keep(i, scene, rs, view):
+        if "st" not in box:
+            box["st"] = api.create_frame_store(wl.W, wl.H, n_frames)
+            api.frame_store_enable_lists(box["st"], scene)
+        api.frame_store_put_view(box["st"], i, view)
+        api.frame_store_put_visible_list(box["st"], i, scene, rs)
+    kw = dict(after_frame=keep) if store is not None else {}
+    # (after_frame runs behind decay / slide of the same frame; the list is the one the fusion left in the render state --
+    # entries the maintenance took since are skipped by the stored-list de-integration, as the contract says)
+    out = util.run_sequence(api, pkg, wl, params, n_frames, **kw) if not maintenance else \
+        util.run_sequence(api, pkg, wl, params, n_frames, decay=(1, 2, True), slide=2, **kw)
+    if store is not None:
+        store.append(box["st"])
+    return out
 
 
 def make_batch(pkg, synth, reint, wl, first, n):
@@ -29,7 +43,7 @@ def make_batch(pkg, synth, reint, wl, first, n):
     return reint.Batch(frames, old, new, wl.intr)
 
 
-def main(rank, world, port, out_path, maintenance):
+def main(rank, world, port, out_path, maintenance, batched=False):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     import torch
@@ -45,20 +59,28 @@ def main(rank, world, port, out_path, maintenance):
     chunk = 16
     params = util.small_params(pkg, wl, num_local_blocks=0x800, num_buckets=0x1000, num_excess=0x400)
     n_frames = 12 if maintenance else 5
-    s, rs, v = build_map(api, pkg, wl, params, n_frames, maintenance)
+    stores = [] if batched else None
+    s, rs, v = build_map(api, pkg, wl, params, n_frames, maintenance, stores)
     # the keyframes still inside the window are the ones a correction re-fuses
-    batch = make_batch(pkg, synth, reint, wl, n_frames - 3 if maintenance else 0, 3 if maintenance else n_frames)
+    first, count = (n_frames - 3, 3) if maintenance else (0, n_frames)
+    batch = make_batch(pkg, synth, reint, wl, first, count)
+    if batched:   # the same keyframes out of the store, as ONE dslam_reintegrate_batch call per rank
+        batch = reint.Batch([("store", stores[0], j) for j in range(first, first + count)], batch.old_poses, batch.new_poses, batch.intr)
     timers = {}
     counts = reint.reintegrate(api, s, v, rs, batch, rank=rank, world=world, chunk_blocks=chunk,
-                               all_gather=reint.make_numpy_all_gather(api, s, dist), timers=timers)
+                               all_gather=reint.make_numpy_all_gather(api, s, dist), timers=timers, batched=batched)
     snap = util.snapshot(api, s, rs)
     ok = True
     msg = ""
     if rank == 0:
         # single-rank reference in the same process
-        s1, rs1, v1 = build_map(api, pkg, wl, params, n_frames, maintenance)
+        stores1 = [] if batched else None
+        s1, rs1, v1 = build_map(api, pkg, wl, params, n_frames, maintenance, stores1)
         before = util.snapshot(api, s1, rs1)
-        reint.reintegrate(api, s1, v1, rs1, batch, rank=0, world=1)
+        batch1 = batch if not batched else reint.Batch([("store", stores1[0], f[2]) for f in batch.frames], batch.old_poses,
+                                                       batch.new_poses, batch.intr)
+        # (the single-rank reference of the batched run is the per-keyframe loop with stored lists: the call's definition)
+        reint.reintegrate(api, s1, v1, rs1, batch1, rank=0, world=1, stored_lists=batched)
         ref = util.snapshot(api, s1, rs1)
         try:
             util.assert_same_state(snap, ref, "sharded vs single")
@@ -90,4 +112,5 @@ def main(rank, world, port, out_path, maintenance):
 
 
 if __name__ == "__main__":
-    main(int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]), sys.argv[4], int(sys.argv[5]) != 0)
+    main(int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]), sys.argv[4], int(sys.argv[5]) != 0,
+         len(sys.argv) > 6 and int(sys.argv[6]) != 0)

@@ -59,12 +59,14 @@ def test_dirty_plan_lists_exactly_the_visited_blocks(pkg, synth, oracle):
     oracle.track_dirty(s, False)
 
 
-@pytest.mark.parametrize("world,maintenance", [(2, 0), (2, 1), (4, 1)])
-def test_sharded_reintegration_equals_single_rank(tmp_path, world, maintenance):
+@pytest.mark.parametrize("world,maintenance,batched", [(2, 0, 0), (2, 1, 0), (4, 1, 0), (2, 1, 1)])
+def test_sharded_reintegration_equals_single_rank(tmp_path, world, maintenance, batched):
+    """batched: every rank runs the batch as ONE dslam_reintegrate_batch call (on the oracle: the loop that defines it) on its
+    shard; the reference is the unsharded per-keyframe loop with stored lists."""
     port = _free_port()
     out = tmp_path / "result.txt"
     procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "_gloo_worker.py"), str(r), str(world), str(port), str(out),
-                               str(maintenance)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+                               str(maintenance), str(batched)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
              for r in range(world)]
     logs = []
     for p in procs:
