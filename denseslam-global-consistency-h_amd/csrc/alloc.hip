@@ -383,6 +383,7 @@ struct SweepParams {
   Mat4 invM;
   float inv_fx, inv_fy, cx, cy, mu, one_over_block;
   int cap_shift;  // step_cap = 1 << cap_shift
+  unsigned long long *dbg;  // diagnostics (DSLAM_DBG_SWEEP=<file>): per tile 8 timestamps (s_memtime)
 };
 
 // Pools that run out during the pass (rare): which requests get a block is the sequential rule over ALL requests in
@@ -430,146 +431,161 @@ __device__ void walk_requests(const SweepParams &p, int limit_word, int avail_vb
   f1s = v[2];
 }
 
-// Order of work in a tile (what a workgroup waits for is other tiles' counts and its own dependent loads, so everything
-// that needs neither goes first and the loads of independent chains are in flight together):
-//   words -> request counts out -> [replay of the winners' walks || type bytes of the entries visible before] ->
-//   visible counts out -> look-back (by now the words in front are there) -> commits -> visible list
 template <bool SWAPPING>
 __global__ __launch_bounds__(256) void k_alloc_sweep(SweepParams p) {
   __shared__ int red[16];
   __shared__ int s_ticket;
   __shared__ unsigned s_newx[kBitTileWords];   // entries other tiles' commits create in this tile (excess area)
   __shared__ unsigned s_mk[kBitTileWords], s_qx[kBitTileWords];   // the tile's mark bits / entries this pass made visible
-  __shared__ unsigned s_cur[kBitTileWords];    // entries visible before whose type byte carries this pass' generation bit
   constexpr int kEmitWindow = 8192;
   __shared__ unsigned short s_list[kEmitWindow];
+  constexpr int kReqWindow = 2048;
+  __shared__ uint2 s_req[kReqWindow];                             // requests of the tile: entry | type, ranks inside the tile
+  __shared__ unsigned s_qv[kBitTileWords], s_qf[kBitTileWords];   // requests that made their entry visible / that found no block
   // (snapshot taken by k_mark)
   const int base_free = __builtin_amdgcn_readfirstlane(p.cnt->base_free), base_free_ex = __builtin_amdgcn_readfirstlane(p.cnt->base_free_ex);
   const int avail_vba = base_free + 1, avail_ex = base_free_ex + 1;
+  const unsigned long long t_start = p.dbg ? __builtin_amdgcn_s_memtime() : 0ull;
   const int b = take_ticket(p.ticket, p.ticket_base, &s_ticket);   // (one tile per workgroup, in starting order)
   if (b >= p.n_tiles) return;
-  const int w0 = b * kBitTileWords + threadIdx.x * 4;   // this thread's four words
-  const uint4 q1 = *reinterpret_cast<const uint4 *>(p.q1 + w0), q2 = *reinterpret_cast<const uint4 *>(p.q2 + w0);
-  const uint4 mk = *reinterpret_cast<const uint4 *>(p.mark + w0), rt = *reinterpret_cast<const uint4 *>(p.retest + w0);
-  const uint4 pold = *reinterpret_cast<const uint4 *>(p.vis_bits + w0);
-  const int tile_first = b * kBitTileEntries;
-  const bool last = b == p.n_tiles - 1;
-  const bool has_excess = tile_first + kBitTileEntries > p.num_buckets || last;   // other tiles' commits may create entries here
-  *reinterpret_cast<uint4 *>(&s_cur[threadIdx.x * 4]) = make_uint4(0, 0, 0, 0);
-  *reinterpret_cast<uint4 *>(&s_newx[threadIdx.x * 4]) = make_uint4(0, 0, 0, 0);
-  // ---- request counts out first: nothing about them depends on anything else ---------------------------------------------
-  const int c1 = popc4(q1), c2 = popc4(q2);
-  int r1, r2, tot1, tot2;
-  block_excl_scan2<4>(c1, c2, red, r1, r2, tot1, tot2);
-  if (threadIdx.x == 0) publish(p.agg_req, b, p.epoch, tot1, tot2);
-  // the other set of bitmaps starts the next pass clean
+#define STAMP(i) do { if (p.dbg && threadIdx.x == 0) p.dbg[(size_t)b * 8 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+  if (p.dbg && threadIdx.x == 0) p.dbg[(size_t)b * 8] = t_start;
+  STAMP(1);
   {
-    const uint4 z = make_uint4(0, 0, 0, 0);
-    *reinterpret_cast<uint4 *>(p.oq1 + w0) = z;
-    *reinterpret_cast<uint4 *>(p.oq2 + w0) = z;
-    *reinterpret_cast<uint4 *>(p.omark + w0) = z;
-  }
-  // ---- replay: the block every request of this thread asks for (needs no rank; the commit further down does) -----------
-  // the final key of a slot names its winner (pixel, step); its walk is replayed to the block it asked for
-  short4 bc_first = make_short4(0, 0, 0, 0);   // (the first request's coordinates stay in registers; a thread rarely has two)
-  {
-    bool first = true;
+    const int w0 = b * kBitTileWords + threadIdx.x * 4;   // this thread's four words
+    const uint4 q1 = *reinterpret_cast<const uint4 *>(p.q1 + w0), q2 = *reinterpret_cast<const uint4 *>(p.q2 + w0);
+    const uint4 mk = *reinterpret_cast<const uint4 *>(p.mark + w0), rt = *reinterpret_cast<const uint4 *>(p.retest + w0);
+    const uint4 pold = *reinterpret_cast<const uint4 *>(p.vis_bits + w0);
+    const int tile_first = b * kBitTileEntries;
+    // `mark` only holds found entries that were not visible before (see k_mark); one that was is known by its type byte,
+    // which carries this pass' generation bit.  The re-test job has accepted every such byte it saw -- but it ran while
+    // the pixels were still marking, and an entry that fails the block frustum test can be marked all the same (a block
+    // that cuts a corner of the image without one of its own corners inside).  So the bytes of the entries the job turned
+    // down are looked at once more, now that the marking is over; dense, through the LDS list, because those entries
+    // cluster like the visible ones do.  Usually there are none to a few dozen per tile.
+    uint4 late = make_uint4(0, 0, 0, 0);
+    {
+      const uint4 cand = andn4v(pold, rt);
+      *reinterpret_cast<uint4 *>(&s_qx[threadIdx.x * 4]) = make_uint4(0, 0, 0, 0);
+      int ctot;
+      const int crank = block_excl_scan<4>(popc4(cand), red, ctot);
+      if (ctot > 0) {
+        for (int win = 0; win < ctot; win += kEmitWindow) {
+          __syncthreads();
+          int r = crank - win;
 #pragma unroll 1
-    for (int i = 0; i < 4; i++) {
-      const unsigned a2 = sel4(q2, i);
-      for (unsigned m = sel4(q1, i) | a2; m; m &= m - 1) {
-        const int bit = __ffs((int)m) - 1;
-        const int t = (w0 + i) * 32 + bit;
+          for (int i = 0; i < 4; i++)
+            for (unsigned m = sel4(cand, i); m; m &= m - 1) {
+              if (r >= 0 && r < kEmitWindow) s_list[r] = (unsigned short)((threadIdx.x * 4 + i) * 32 + __ffs((int)m) - 1);
+              r++;
+            }
+          __syncthreads();
+          const int n_win = (ctot - win) < kEmitWindow ? (ctot - win) : kEmitWindow;
+          for (int j = threadIdx.x; j < n_win; j += 256) {
+            const int rel = s_list[j];
+            const unsigned char ty = p.vis_type[tile_first + rel];
+            if (ty != 0 && (ty & 0x80u) == p.gen) atomicOr(&s_qx[rel >> 5], 1u << (rel & 31));
+          }
+        }
+        __syncthreads();
+        late = *reinterpret_cast<const uint4 *>(&s_qx[threadIdx.x * 4]);
+        __syncthreads();   // (s_qx is used again further down)
+      }
+    }
+    const uint4 seen = or4v(or4v(rt, mk), late);
+    STAMP(2);
+    // ---- counts out first: nothing a tile publishes depends on another tile -------------------------------------------
+    const int c1 = popc4(q1), c2 = popc4(q2);
+    int r1, r2, tot1, tot2;
+    block_excl_scan2<4>(c1, c2, red, r1, r2, tot1, tot2);
+    int tv[4] = {popc4(seen), popc4(andn4v(q1, seen)), 0, 0};
+    block_sum4(tv, red);
+    if (threadIdx.x == 0) {
+      publish(p.agg_req, b, p.epoch, tot1, tot2);
+      publish(p.agg_vis, b, p.epoch, tv[0], tv[1]);
+    }
+    // the other set of bitmaps starts the next pass clean
+    {
+      const uint4 z = make_uint4(0, 0, 0, 0);
+      *reinterpret_cast<uint4 *>(p.oq1 + w0) = z;
+      *reinterpret_cast<uint4 *>(p.oq2 + w0) = z;
+      *reinterpret_cast<uint4 *>(p.omark + w0) = z;
+    }
+    const bool last = b == p.n_tiles - 1;
+    const bool has_excess = tile_first + kBitTileEntries > p.num_buckets || last;   // other tiles' commits may create entries here
+    s_newx[threadIdx.x * 4] = 0; s_newx[threadIdx.x * 4 + 1] = 0; s_newx[threadIdx.x * 4 + 2] = 0; s_newx[threadIdx.x * 4 + 3] = 0;
+    // requests of the tiles behind this one: only the tiles of the excess area need them (for the totals), and there
+    // only excess requests exist -- counted straight from the bitmap
+    int later2 = 0;
+    if (has_excess)
+      for (int w = (b + 1) * kBitTileWords + threadIdx.x * 4; w < p.n_words; w += 1024) later2 += popc4(*reinterpret_cast<const uint4 *>(p.q2 + w));
+    STAMP(3);
+    int pre[4];  // requests (type 1, type 2) and visible entries (retest | mark; new type-1 requests) in front of this tile
+    if (!lookback2(p.agg_req, p.agg_vis, b, p.epoch, red, pre) && threadIdx.x == 0) atomicOr(&p.cnt->error_flags, 2);
+    STAMP(4);
+    int lv[4] = {later2, 0, 0, 0};
+    if (has_excess) block_sum4(lv, red);
+    const int all1 = pre[0] + tot1, all2 = pre[1] + tot2 + lv[0];   // (meaningful for has_excess tiles)
+    // ---- does a pool run out?  (wave-uniform decisions) --------------------------------------------------------------
+    const int vr_start = pre[0] + (pre[1] < avail_ex ? pre[1] : avail_ex);
+    int vq_before = pre[3];   // visible type-1 requests in front of this tile that are not in (retest | mark)
+    int seen_before = pre[2]; // entries in (retest | mark) in front of this tile that stay visible
+    int succ2_all = 0;        // successful type-2 requests of the whole pass (has_excess tiles)
+    if (p.do_commit) {
+      const bool dry_before = vr_start > avail_vba;
+      const bool dry_total = has_excess && all1 + (all2 < avail_ex ? all2 : avail_ex) > avail_vba;
+      if (dry_before || dry_total) {
+        int s1q, f1s, s2;
+        walk_requests(p, b * kBitTileWords, avail_vba, avail_ex, red, s1q, f1s, s2);
+        if (dry_before) { vq_before = s1q; seen_before -= f1s; }
+        succ2_all = s2;
+      } else {
+        succ2_all = all2 < avail_ex ? all2 : avail_ex;
+      }
+    }
+    // ---- this tile's requests: replay, rank, commit -------------------------------------------------------------------
+    // Dense: the requests are expanded into an LDS list with their ranks (a window of kReqWindow at a time) and taken one per
+    // lane and round -- a request is a chain of dependent reads (key -> depth pixel -> free-list slot), and a lane that holds
+    // two of them in its own words would walk it twice while the rest of the workgroup waits at the next barrier (per-tile
+    // timeline: 4.6 + 1.8 us of a 16 us launch went there).
+    *reinterpret_cast<uint4 *>(&s_qv[threadIdx.x * 4]) = make_uint4(0, 0, 0, 0);
+    *reinterpret_cast<uint4 *>(&s_qf[threadIdx.x * 4]) = make_uint4(0, 0, 0, 0);
+    const int req_tot = tot1 + tot2;
+    for (int win = 0; win < req_tot; win += kReqWindow) {
+      __syncthreads();   // (s_qv / s_qf zeroed; the previous window read)
+      {
+        int k1 = r1, k2 = r2;   // ranks inside the tile
+#pragma unroll 1
+        for (int i = 0; i < 4; i++) {
+          const unsigned a1 = sel4(q1, i), a2 = sel4(q2, i);
+          for (unsigned m = a1 | a2; m; m &= m - 1) {
+            const int bit = __ffs((int)m) - 1;
+            const bool is2 = (a2 >> bit) & 1u;
+            const int idx = k1 + k2 - win;
+            if (idx >= 0 && idx < kReqWindow)
+              s_req[idx] = make_uint2((unsigned)((threadIdx.x * 4 + i) * 32 + bit) | (is2 ? 0x80000000u : 0u), (unsigned)k1 | ((unsigned)k2 << 16));
+            if (is2) k2++; else k1++;
+          }
+        }
+      }
+      __syncthreads();
+      const int n_win = (req_tot - win) < kReqWindow ? (req_tot - win) : kReqWindow;
+      for (int j = threadIdx.x; j < n_win; j += 256) {
+        const uint2 rq = s_req[j];
+        const int rel = (int)(rq.x & 0x7fffffffu), t = tile_first + rel;
+        const bool is2 = rq.x >> 31;
+        const int k1 = pre[0] + (int)(rq.y & 0xffffu), k2 = pre[1] + (int)(rq.y >> 16);
+        // replay the winning pixel's walk up to the winning step: the block it asked for
         const unsigned kz = p.keys[t] - 1u;
         p.keys[t] = 0;   // leave the keys clean for the next pass
         const int pix = (int)(kz >> p.cap_shift), step = (int)(kz & ((1u << p.cap_shift) - 1u));
         const int py = pix / p.W, px = pix - py * p.W;
         Vec3 pt, dir;
         ray_segment(p.depth[pix], px, py, p.invM, p.inv_fx, p.inv_fy, p.cx, p.cy, p.mu, p.one_over_block, pt, dir);
-        for (int s = 0; s < step; s++) { pt.x += dir.x; pt.y += dir.y; pt.z += dir.z; }
+        for (int st = 0; st < step; st++) { pt.x += dir.x; pt.y += dir.y; pt.z += dir.z; }
         const short4 bc = make_short4((short)(int)floorf(pt.x), (short)(int)floorf(pt.y), (short)(int)floorf(pt.z), 1);
-        p.alloc_type[t] = ((a2 >> bit) & 1u) ? 2 : 1;
+        p.alloc_type[t] = is2 ? 2 : 1;
         p.coords[t] = bc;
-        if (first) { bc_first = bc; first = false; }
-      }
-    }
-  }
-  // ---- the type bytes of the entries that were visible before the pass ---------------------------------------------------
-  // A byte with this pass' generation bit: marked by a pixel of k_mark (`mark` only holds found entries that were NOT
-  // visible before), or a 1 / 2 that counts as marked again.  The re-test job has accepted every such byte it saw -- but
-  // it ran while the pixels were still marking, and an entry that fails the block frustum test can be marked all the same
-  // (a block that cuts a corner of the image without one of its own corners inside) -- so the bytes are read once more, now
-  // that the marking is over, densely through the LDS list (visible entries of the excess area fill whole words).  The same
-  // pass tells the list writer below which entries are upstream's 3s (visible before, not marked now): no byte is read there.
-  {
-    int ctot;
-    const int crank = block_excl_scan<4>(popc4(pold), red, ctot);
-    for (int win = 0; win < ctot; win += kEmitWindow) {
-      __syncthreads();
-      int r = crank - win;
-#pragma unroll 1
-      for (int i = 0; i < 4; i++)
-        for (unsigned m = sel4(pold, i); m; m &= m - 1) {
-          if (r >= 0 && r < kEmitWindow) s_list[r] = (unsigned short)((threadIdx.x * 4 + i) * 32 + __ffs((int)m) - 1);
-          r++;
-        }
-      __syncthreads();
-      const int n_win = (ctot - win) < kEmitWindow ? (ctot - win) : kEmitWindow;
-      for (int j = threadIdx.x; j < n_win; j += 256) {
-        const int rel = s_list[j];
-        const unsigned char ty = p.vis_type[tile_first + rel];
-        if (ty != 0 && (ty & 0x80u) == p.gen) atomicOr(&s_cur[rel >> 5], 1u << (rel & 31));
-      }
-    }
-    __syncthreads();
-  }
-  const uint4 cur = *reinterpret_cast<const uint4 *>(&s_cur[threadIdx.x * 4]);
-  const uint4 seen = or4v(or4v(rt, mk), cur);   // (cur & ~rt: marked after the re-test job looked)
-  int tv[4] = {popc4(seen), popc4(andn4v(q1, seen)), 0, 0};
-  block_sum4(tv, red);
-  if (threadIdx.x == 0) publish(p.agg_vis, b, p.epoch, tv[0], tv[1]);
-  // requests of the tiles behind this one: only the tiles of the excess area need them (for the totals), and there
-  // only excess requests exist -- counted straight from the bitmap
-  int later2 = 0;
-  if (has_excess)
-    for (int w = (b + 1) * kBitTileWords + threadIdx.x * 4; w < p.n_words; w += 1024) later2 += popc4(*reinterpret_cast<const uint4 *>(p.q2 + w));
-  int pre[4];  // requests (type 1, type 2) and visible entries (seen; new type-1 requests) in front of this tile
-  if (!lookback2(p.agg_req, p.agg_vis, b, p.epoch, red, pre) && threadIdx.x == 0) atomicOr(&p.cnt->error_flags, 2);
-  int lv[4] = {later2, 0, 0, 0};
-  if (has_excess) block_sum4(lv, red);
-  const int all1 = pre[0] + tot1, all2 = pre[1] + tot2 + lv[0];   // (meaningful for has_excess tiles)
-  // ---- does a pool run out?  (wave-uniform decisions) ----------------------------------------------------------------
-  const int vr_start = pre[0] + (pre[1] < avail_ex ? pre[1] : avail_ex);
-  int vq_before = pre[3];   // visible type-1 requests in front of this tile that are not in `seen` there
-  int seen_before = pre[2]; // entries in `seen` in front of this tile that stay visible
-  int succ2_all = 0;        // successful type-2 requests of the whole pass (has_excess tiles)
-  if (p.do_commit) {
-    const bool dry_before = vr_start > avail_vba;
-    const bool dry_total = has_excess && all1 + (all2 < avail_ex ? all2 : avail_ex) > avail_vba;
-    if (dry_before || dry_total) {
-      int s1q, f1s, s2;
-      walk_requests(p, b * kBitTileWords, avail_vba, avail_ex, red, s1q, f1s, s2);
-      if (dry_before) { vq_before = s1q; seen_before -= f1s; }
-      succ2_all = s2;
-    } else {
-      succ2_all = all2 < avail_ex ? all2 : avail_ex;
-    }
-  }
-  // ---- this tile's requests: rank, commit ---------------------------------------------------------------------------------
-  uint4 qvis = make_uint4(0, 0, 0, 0);   // type-1 requests that make their entry visible in this pass
-  uint4 qfail = make_uint4(0, 0, 0, 0);  // type-1 requests that found no block: the entry is not visible, whatever it was
-  {
-    int k1 = pre[0] + r1, k2 = pre[1] + r2;
-    bool first = true;
-#pragma unroll 1
-    for (int i = 0; i < 4; i++) {
-      const unsigned a1 = sel4(q1, i), a2 = sel4(q2, i);
-      for (unsigned m = a1 | a2; m; m &= m - 1) {
-        const int bit = __ffs((int)m) - 1;
-        const int t = (w0 + i) * 32 + bit;
-        const bool is2 = (a2 >> bit) & 1u;
-        const short4 bc = first ? bc_first : p.coords[t];   // (this thread wrote it above)
-        first = false;
         // voxel-block slots consumed by all earlier requests in hash-index order (closed form)
         const int vr = k1 + (k2 < avail_ex ? k2 : avail_ex);
         if (!is2) {
@@ -584,106 +600,144 @@ __global__ __launch_bounds__(256) void k_alloc_sweep(SweepParams p) {
           // upstream; with it, only if it got a block
           if (ok || !p.do_commit) {
             p.vis_type[t] = (unsigned char)(p.gen | 1u);
-            or4(qvis, i, 1u << bit);
+            atomicOr(&s_qv[rel >> 5], 1u << (rel & 31));
           } else {
-            or4(qfail, i, 1u << bit);
+            atomicOr(&s_qf[rel >> 5], 1u << (rel & 31));
           }
-          k1++;
-        } else {
-          if (p.do_commit && k2 < avail_ex && vr < avail_vba) {
-            const int ex_off = p.excess_list[base_free_ex - k2];
-            const int slot = p.alloc_list[base_free - vr];
-            p.hash[t].offset = ex_off + 1;
-            store_entry(p.hash, p.num_buckets + ex_off, bc.x, bc.y, bc.z, 0, slot);
-            bit_set(p.alloc_bits, p.num_buckets + ex_off);
-            if (p.born) p.born[slot] = p.born_stamp;
-            // (its type byte and its place in the visible list are the business of the tile that owns the new entry)
-          }
-          k2++;
+        } else if (p.do_commit && k2 < avail_ex && vr < avail_vba) {
+          const int ex_off = p.excess_list[base_free_ex - k2];
+          const int slot = p.alloc_list[base_free - vr];
+          p.hash[t].offset = ex_off + 1;
+          store_entry(p.hash, p.num_buckets + ex_off, bc.x, bc.y, bc.z, 0, slot);
+          bit_set(p.alloc_bits, p.num_buckets + ex_off);
+          if (p.born) p.born[slot] = p.born_stamp;
+          // (its type byte and its place in the visible list are the business of the tile that owns the new entry)
         }
       }
-    }
-  }
-  // ---- entries other tiles create in the excess area: the first succ2_all slots off the excess free list -----------------
-  int newx_before = 0;   // ... of them in front of this tile and not counted as `seen` there
-  if (has_excess) {
-    for (int j = threadIdx.x; j < succ2_all; j += 256) {
-      const int t = p.num_buckets + p.excess_list[base_free_ex - j];
-      const int rel = t - tile_first;
-      if (rel >= 0 && rel < kBitTileEntries) atomicOr(&s_newx[rel >> 5], 1u << (rel & 31));
-      // (a free excess slot has no live entry: k_mark cannot have marked it, so `seen` there is retest | mark)
-      else if (rel < 0 && !(((p.retest[t >> 5] | p.mark[t >> 5]) >> (t & 31)) & 1u)) newx_before++;
-    }
-    int nv[4] = {newx_before, 0, 0, 0};
-    block_sum4(nv, red);   // (has a barrier: s_newx is complete behind it)
-    newx_before = nv[0];
-  }
-  const uint4 newx = has_excess ? *reinterpret_cast<const uint4 *>(&s_newx[threadIdx.x * 4]) : make_uint4(0, 0, 0, 0);
-  // ---- the visible list -------------------------------------------------------------------------------------------------
-  const uint4 vis = or4v(or4v(andn4v(seen, qfail), qvis), newx);
-  int vis_tot;
-  const int vis_rank = block_excl_scan<4>(popc4(vis), red, vis_tot);
-  const int vis_first = seen_before + vq_before + newx_before;
-  // entries that are no longer visible (stores only: nothing to wait for)
-#pragma unroll 1
-  for (int i = 0; i < 4; i++)
-    for (unsigned m = sel4(pold, i) & ~sel4(vis, i); m; m &= m - 1) p.vis_type[(w0 + i) * 32 + __ffs((int)m) - 1] = 0;
-  // The visible entries are written densely: expanded into an LDS list (a window of kEmitWindow ranks at a time), then
-  // one entry per lane and round -- coalesced list stores, and the visible entries of the excess area, which fill a few
-  // words completely (excess slots are handed out contiguously), do not queue up behind a single lane.
-  *reinterpret_cast<uint4 *>(&s_mk[threadIdx.x * 4]) = or4v(mk, cur);         // marked in this pass: the byte is right as it is
-  *reinterpret_cast<uint4 *>(&s_qx[threadIdx.x * 4]) = or4v(qvis, newx);      // made visible by this pass itself: type 1
-  for (int win = 0; win < vis_tot; win += kEmitWindow) {
-    __syncthreads();   // (s_mk / s_qx written; the previous window read)
-    {
-      int r = vis_rank - win;
-#pragma unroll 1
-      for (int i = 0; i < 4; i++)
-        for (unsigned m = sel4(vis, i); m; m &= m - 1) {
-          if (r >= 0 && r < kEmitWindow) s_list[r] = (unsigned short)((threadIdx.x * 4 + i) * 32 + __ffs((int)m) - 1);
-          r++;
-        }
     }
     __syncthreads();
-    const int n_win = (vis_tot - win) < kEmitWindow ? (vis_tot - win) : kEmitWindow;
-    for (int j = threadIdx.x; j < n_win; j += 256) {
-      const int rel = s_list[j], t = tile_first + rel, r = vis_first + win + j;
-      const bool in_mk = (s_mk[rel >> 5] >> (rel & 31)) & 1u, in_qx = (s_qx[rel >> 5] >> (rel & 31)) & 1u;
-      const bool in_x = has_excess && ((s_newx[rel >> 5] >> (rel & 31)) & 1u);
-      if (r < p.capacity) {
-        p.visible_ids[r] = t;
-        // an entry another tile's commit created here: type 1; visible before, not marked now, inside the frustum:
-        // upstream's 3; everything else carries its type already
-        if (in_x) p.vis_type[t] = (unsigned char)(p.gen | 1u);
-        else if (!in_mk && !in_qx) p.vis_type[t] = (unsigned char)(p.gen | 3u);
-      } else {
-        // no room in the list: upstream leaves the type in place without the entry being re-armed next pass, so
-        // a 1 / 2 counts as marked again then (next pass' bit), a 3 is re-tested (this pass' bit)
-        unsigned ty = 1;
-        if (!in_qx) ty = in_mk ? (p.vis_type[t] & 0x7fu) : 3u;
-        p.vis_type[t] = (unsigned char)((ty == 3 ? p.gen : (p.gen ^ 0x80u)) | ty);
+    const uint4 qvis = *reinterpret_cast<const uint4 *>(&s_qv[threadIdx.x * 4]);    // type-1 requests that make their entry visible in this pass
+    const uint4 qfail = *reinterpret_cast<const uint4 *>(&s_qf[threadIdx.x * 4]);   // type-1 requests that found no block: the entry is not visible, whatever it was
+    STAMP(5);
+    // ---- entries other tiles create in the excess area: the first succ2_all slots off the excess free list ---------------
+    int newx_before = 0;   // ... of them in front of this tile and not counted as (retest | mark) there
+    if (has_excess) {
+      for (int j = threadIdx.x; j < succ2_all; j += 256) {
+        const int t = p.num_buckets + p.excess_list[base_free_ex - j];
+        const int rel = t - tile_first;
+        if (rel >= 0 && rel < kBitTileEntries) atomicOr(&s_newx[rel >> 5], 1u << (rel & 31));
+        else if (rel < 0 && !(((p.retest[t >> 5] | p.mark[t >> 5]) >> (t & 31)) & 1u)) newx_before++;
       }
-      if (SWAPPING) {   // a visible entry's host copy (if it has one) is wanted back: IntegrateGlobalIntoLocal's state 1
-        const unsigned char st = p.swap_state[t];
-        if (st == 0) { p.swap_state[t] = 1; bit_set(p.swap1_bits, t); }
+      int nv[4] = {newx_before, 0, 0, 0};
+      block_sum4(nv, red);   // (has a barrier: s_newx is complete behind it)
+      newx_before = nv[0];
+    }
+    const uint4 newx = has_excess ? *reinterpret_cast<const uint4 *>(&s_newx[threadIdx.x * 4]) : make_uint4(0, 0, 0, 0);
+    STAMP(6);
+    // ---- the visible list -----------------------------------------------------------------------------------------------
+    const uint4 vis = or4v(or4v(andn4v(seen, qfail), qvis), newx);
+    int vis_tot;
+    const int vis_rank = block_excl_scan<4>(popc4(vis), red, vis_tot);   // (its barriers also order the request lanes' type bytes)
+    const int vis_first = seen_before + vq_before + newx_before;
+    // entries that are no longer visible (stores only: nothing to wait for)
+#pragma unroll 1
+    for (int i = 0; i < 4; i++)
+      for (unsigned m = sel4(pold, i) & ~sel4(vis, i); m; m &= m - 1) p.vis_type[(w0 + i) * 32 + __ffs((int)m) - 1] = 0;
+    // The visible entries are written densely: expanded into an LDS list (a window of kEmitWindow ranks at a time), then
+    // one entry per lane and round -- coalesced list stores, and the visible entries of the excess area, which fill a few
+    // words completely (excess slots are handed out contiguously), do not queue up behind a single lane.
+    *reinterpret_cast<uint4 *>(&s_mk[threadIdx.x * 4]) = mk;
+    *reinterpret_cast<uint4 *>(&s_qx[threadIdx.x * 4]) = or4v(qvis, newx);   // (the pass made these visible itself: type 1)
+    // The words are expanded by OTHER lanes than the ones that own them: word k by lane k % 256.  A lane owns four
+    // consecutive words, and the recently allocated -- mostly visible -- entries of the excess area are consecutive: the
+    // eight lanes that own them would each write 128 list entries one after the other while 248 lanes wait (the tile that ends
+    // the table took 8.5 us for its list where the others take 2.6).  (s_qv / s_qf are free again: the words and their ranks.)
+    {
+      const int c0 = __popc(vis.x), c1v = __popc(vis.y), c2v = __popc(vis.z);
+      *reinterpret_cast<uint4 *>(&s_qv[threadIdx.x * 4]) = vis;
+      *reinterpret_cast<uint4 *>(&s_qf[threadIdx.x * 4]) = make_uint4((unsigned)vis_rank, (unsigned)(vis_rank + c0), (unsigned)(vis_rank + c0 + c1v),
+                                                                     (unsigned)(vis_rank + c0 + c1v + c2v));
+    }
+    for (int win = 0; win < vis_tot; win += kEmitWindow) {
+      __syncthreads();   // (s_mk / s_qx / words / ranks written; the previous window read)
+#pragma unroll 1
+      for (int q = 0; q < 4; q++) {
+        const int k = threadIdx.x + 256 * q;
+        int r = (int)s_qf[k] - win;
+        for (unsigned m = s_qv[k]; m; m &= m - 1) {
+          if (r >= 0 && r < kEmitWindow) s_list[r] = (unsigned short)(k * 32 + __ffs((int)m) - 1);
+          r++;
+        }
+      }
+      __syncthreads();
+      const int n_win = (vis_tot - win) < kEmitWindow ? (vis_tot - win) : kEmitWindow;
+      // (four entries per lane at a time, their type bytes requested together: the tile that ends the table holds the
+      // visible entries of the whole excess area -- several rounds where the others need one -- and a round is a round trip)
+      constexpr int kEmitBatch = 4;
+      for (int j0 = threadIdx.x; j0 < n_win; j0 += 256 * kEmitBatch) {
+        int tt[kEmitBatch];
+        unsigned fl[kEmitBatch];          // bit 0 in_mk, 1 in_qx, 2 in_x, 3 valid
+        unsigned char old[kEmitBatch];
+#pragma unroll
+        for (int q = 0; q < kEmitBatch; q++) {
+          const int j = j0 + q * 256;
+          fl[q] = 0; tt[q] = 0; old[q] = 0;
+          if (j < n_win) {
+            const int rel = s_list[j];
+            tt[q] = tile_first + rel;
+            const bool in_mk = (s_mk[rel >> 5] >> (rel & 31)) & 1u, in_qx = (s_qx[rel >> 5] >> (rel & 31)) & 1u;
+            const bool in_x = has_excess && ((s_newx[rel >> 5] >> (rel & 31)) & 1u);
+            fl[q] = (in_mk ? 1u : 0u) | (in_qx ? 2u : 0u) | (in_x ? 4u : 0u) | 8u;
+            if (!in_qx) old[q] = p.vis_type[tt[q]];   // (entries this pass made visible itself are type 1 whatever the byte says)
+          }
+        }
+#pragma unroll
+        for (int q = 0; q < kEmitBatch; q++) {
+          if (!(fl[q] & 8u)) continue;
+          const int t = tt[q], r = vis_first + win + j0 + q * 256;
+          const bool in_mk = fl[q] & 1u, in_qx = fl[q] & 2u, in_x = fl[q] & 4u;
+          if (r < p.capacity) {
+            p.visible_ids[r] = t;
+            if (in_x) {
+              p.vis_type[t] = (unsigned char)(p.gen | 1u);   // (an entry another tile's commit created here)
+            } else if (!in_mk && !in_qx) {
+              // visible before, not marked now, inside the frustum: upstream's 3 (a byte with this pass' bit is a 1 / 2
+              // that counts as marked again: it stays)
+              if ((old[q] & 0x80u) != p.gen) p.vis_type[t] = (unsigned char)(p.gen | 3u);
+            }
+          } else {
+            // no room in the list: upstream leaves the type in place without the entry being re-armed next pass, so
+            // a 1 / 2 counts as marked again then (next pass' bit), a 3 is re-tested (this pass' bit)
+            unsigned ty = 1;
+            if (!in_qx) ty = (in_mk || (old[q] & 0x80u) == p.gen) ? (old[q] & 0x7fu) : 3u;
+            p.vis_type[t] = (unsigned char)((ty == 3 ? p.gen : (p.gen ^ 0x80u)) | ty);
+          }
+          if (SWAPPING) {   // a visible entry's host copy (if it has one) is wanted back: IntegrateGlobalIntoLocal's state 1
+            const unsigned char st = p.swap_state[t];
+            if (st == 0) { p.swap_state[t] = 1; bit_set(p.swap1_bits, t); }
+          }
+        }
       }
     }
-  }
-  *reinterpret_cast<uint4 *>(p.vis_bits + w0) = vis;
-  if (last && threadIdx.x == 0) {
-    const int n = vis_first + vis_tot;
-    p.rc->no_visible = n < p.capacity ? n : p.capacity;
-    if (p.do_commit) {
-      const int vr_all = all1 + (all2 < avail_ex ? all2 : avail_ex);
-      const int succ_vba = vr_all < avail_vba ? vr_all : avail_vba;   // every success takes exactly one voxel-block slot
-      p.cnt->last_free = base_free - succ_vba;
-      p.cnt->last_free_ex = base_free_ex - succ2_all;
-      p.cnt->alloc_failures = all1 + all2 - succ_vba;
-    } else {
-      p.cnt->alloc_failures = 0;
+    *reinterpret_cast<uint4 *>(p.vis_bits + w0) = vis;
+    STAMP(7);
+    if (last && threadIdx.x == 0) {
+      const int n = vis_first + vis_tot;
+      p.rc->no_visible = n < p.capacity ? n : p.capacity;
+      if (p.do_commit) {
+        const int vr_all = all1 + (all2 < avail_ex ? all2 : avail_ex);
+        const int succ_vba = vr_all < avail_vba ? vr_all : avail_vba;   // every success takes exactly one voxel-block slot
+        p.cnt->last_free = base_free - succ_vba;
+        p.cnt->last_free_ex = base_free_ex - succ2_all;
+        p.cnt->alloc_failures = all1 + all2 - succ_vba;
+      } else {
+        p.cnt->alloc_failures = 0;
+      }
     }
   }
 }
+
+#undef STAMP
 
 // The visible list of a render state was replaced behind its types' back (FindVisibleBlocks into this render state, an
 // uploaded list).  Upstream's next pass would leave every type as it is and set the LIST's entries to 3; in the
@@ -864,9 +918,23 @@ int launch_allocate(dslam_engine *e, dslam_scene *s, const dslam_view *v, dslam_
   sp.depth = v->depth; sp.W = W; sp.H = H;
   sp.invM = mp.invM; sp.inv_fx = mp.inv_fx; sp.inv_fy = mp.inv_fy; sp.cx = mp.cx; sp.cy = mp.cy;
   sp.mu = mp.mu; sp.one_over_block = mp.one_over_block; sp.cap_shift = cap_shift;
+  sp.dbg = nullptr;
+  static const char *dbg_file = getenv("DSLAM_DBG_SWEEP");
+  static int dbg_calls = 0;
+  unsigned long long *dbg_host = nullptr;
+  if (dbg_file && ++dbg_calls == 60) {
+    DSLAM_HIP(hipHostMalloc((void **)&dbg_host, (size_t)n_tiles * 64, hipHostMallocDefault));
+    memset(dbg_host, 0, (size_t)n_tiles * 64);
+    sp.dbg = dbg_host;
+  }
   if (s->p.use_swapping) hipLaunchKernelGGL(k_alloc_sweep<true>, dim3(grid), dim3(256), 0, e->stream, sp);
   else hipLaunchKernelGGL(k_alloc_sweep<false>, dim3(grid), dim3(256), 0, e->stream, sp);
   dbg_sync(e, "k_alloc_sweep");
+  if (dbg_host) {
+    DSLAM_HIP(hipStreamSynchronize(e->stream));
+    if (FILE *f = fopen(dbg_file, "wb")) { fwrite(dbg_host, 64, n_tiles, f); fclose(f); }
+    (void)hipHostFree(dbg_host);
+  }
   if (s->p.use_swapping) {
     hipLaunchKernelGGL(k_realloc_count, dim3(n_tiles), dim3(256), 0, e->stream, r->vis_bits, s->hash, e->tile_counts, s->counters);
     hipLaunchKernelGGL(k_realloc_apply, dim3(n_tiles), dim3(256), 0, e->stream, r->vis_bits, s->hash, e->tile_counts, s->alloc_list,

@@ -15,9 +15,14 @@
 // No look-back, no spin, no ticket: the only hand-off is the kernel boundary.
 // A selection is a functor with
 //   void prologue()                          an independent grid-stride job run by the compaction launch (optional work)
-//   bool test(int t)                         is entry t (its bit is set in the source bitmap) selected?  May have side
+//   Payload load(int t)                      what test / emit need to read about entry t (a hash entry, or nothing): the
+//                                            kernels request it for four entries per lane before they look at the first,
+//                                            so that the rounds of a crowded tile -- the one that ends the table holds the
+//                                            whole dense part of the excess area -- do not each pay their own round trip
+//   bool test(int t, const Payload &)        is entry t (its bit is set in the source bitmap) selected?  May have side
 //                                            effects on state that belongs to entry t alone.
-//   int  emit(int t, int rank, bool listed)  called for every selected entry (listed: rank < capacity; rank ascending with
+//   int  emit(int t, int rank, bool listed, const Payload &)
+//                                            called for every selected entry (listed: rank < capacity; rank ascending with
 //                                            t); the return values are summed per compaction tile (tile_sum_out)
 //   void finish(int total)                   called once (one thread of the tile that ends the table), behind every emit of
 //                                            that tile
@@ -28,6 +33,11 @@
 #include "dslam_internal.h"
 
 namespace dslam {
+
+struct NoPayload {};
+// for selections whose test / emit read what they need themselves
+#define DSLAM_SEL_NO_LOAD typedef NoPayload Payload; __device__ NoPayload load(int) const { return NoPayload(); }
+constexpr int kSelBatch = 4;            // entries per lane whose loads are in flight together
 
 constexpr int kTestTileWords = 32;      // k_bits_test: 1024 entries per workgroup
 constexpr int kCompactTileWords = 256;  // k_bits_compact: 8192 entries per workgroup
@@ -58,9 +68,18 @@ __global__ __launch_bounds__(256) void k_bits_test(const unsigned *__restrict__ 
   expand_bits(nib, threadIdx.x * 4, rank, s_list);
   __syncthreads();
   const int t0 = blockIdx.x * (kTestTileWords * 32);
-  for (int j = threadIdx.x; j < tot; j += 256) {
-    const int rel = s_list[j];
-    if (sel.test(t0 + rel)) atomicOr(&s_pick[rel >> 5], 1u << (rel & 31));
+  for (int j0 = threadIdx.x; j0 < tot; j0 += 256 * kSelBatch) {
+    typename Sel::Payload pl[kSelBatch];
+    int rel[kSelBatch];
+#pragma unroll
+    for (int q = 0; q < kSelBatch; q++) {
+      const int j = j0 + q * 256;
+      rel[q] = j < tot ? (int)s_list[j] : -1;
+      if (rel[q] >= 0) pl[q] = sel.load(t0 + rel[q]);
+    }
+#pragma unroll
+    for (int q = 0; q < kSelBatch; q++)
+      if (rel[q] >= 0 && sel.test(t0 + rel[q], pl[q])) atomicOr(&s_pick[rel[q] >> 5], 1u << (rel[q] & 31));
   }
   __syncthreads();
   if (threadIdx.x < kTestTileWords) {
@@ -94,10 +113,22 @@ __global__ __launch_bounds__(256) void k_bits_compact(const unsigned *__restrict
   __syncthreads();
   const int t0 = blockIdx.x * (kCompactTileWords * 32);
   int sum = 0;
-  for (int j = threadIdx.x; j < tot; j += 256) {
-    const int t = t0 + s_list[j], r = before + j;
-    if (r < capacity && out) out[r] = t;
-    sum += sel.emit(t, r, r < capacity);
+  for (int j0 = threadIdx.x; j0 < tot; j0 += 256 * kSelBatch) {
+    typename Sel::Payload pl[kSelBatch];
+    int tt[kSelBatch];
+#pragma unroll
+    for (int q = 0; q < kSelBatch; q++) {
+      const int j = j0 + q * 256;
+      tt[q] = j < tot ? t0 + (int)s_list[j] : -1;
+      if (tt[q] >= 0) pl[q] = sel.load(tt[q]);
+    }
+#pragma unroll
+    for (int q = 0; q < kSelBatch; q++) {
+      if (tt[q] < 0) continue;
+      const int r = before + j0 + q * 256;
+      if (r < capacity && out) out[r] = tt[q];
+      sum += sel.emit(tt[q], r, r < capacity, pl[q]);
+    }
   }
   if (tile_sum_out) {
     for (int d = 32; d > 0; d >>= 1) sum += __shfl_xor(sum, d, 64);

@@ -36,24 +36,26 @@ namespace dslam {
 //   SelSlidePop    same, and the bit is cleared; selected only if no queued list references the block any more
 //   SelDecaySweep  block not seen since `threshold` and not yet swept in this observation epoch (full-sweep decay)
 struct SelDecayAged {
+  DSLAM_SEL_NO_LOAD
   const HashEntry *hash;
   const unsigned long long *masks;
   int words, ring, bit;
-  __device__ bool test(int t) const {
+  __device__ bool test(int t, const NoPayload &) const {
     const int ptr = hash[t].ptr;
     if (ptr < 0) return false;
     return (masks[((size_t)ptr * 2 + ring) * words + (bit >> 6)] >> (bit & 63)) & 1ull;
   }
   __device__ void prologue() const {}
-  __device__ int emit(int, int, bool) const { return 0; }
+  __device__ int emit(int, int, bool, const NoPayload &) const { return 0; }
   __device__ void finish(int) const {}
 };
 struct SelSlidePop {
+  DSLAM_SEL_NO_LOAD
   const HashEntry *hash;
   unsigned long long *masks;
   int words, ring, bit;
   unsigned char *flags;   // (optional) byte flag per selected entry: the release pipeline's removal flags
-  __device__ bool test(int t) const {
+  __device__ bool test(int t, const NoPayload &) const {
     const int ptr = hash[t].ptr;
     if (ptr < 0) return false;
     unsigned long long *m = masks + ((size_t)ptr * 2) * words;
@@ -66,14 +68,15 @@ struct SelSlidePop {
     return any == 0;
   }
   __device__ void prologue() const {}
-  __device__ int emit(int t, int, bool) const { if (flags) flags[t] = 1; return 0; }
+  __device__ int emit(int t, int, bool, const NoPayload &) const { if (flags) flags[t] = 1; return 0; }
   __device__ void finish(int) const {}
 };
 struct SelDecaySweep {
+  DSLAM_SEL_NO_LOAD
   const HashEntry *hash;
   int *last_seen;
   int threshold;
-  __device__ bool test(int t) const {
+  __device__ bool test(int t, const NoPayload &) const {
     const int ptr = hash[t].ptr;
     if (ptr < 0) return false;
     const int ls = last_seen[ptr];
@@ -81,7 +84,7 @@ struct SelDecaySweep {
     return false;
   }
   __device__ void prologue() const {}
-  __device__ int emit(int, int, bool) const { return 0; }
+  __device__ int emit(int, int, bool, const NoPayload &) const { return 0; }
   __device__ void finish(int) const {}
 };
 
@@ -502,27 +505,30 @@ int launch_decay(dslam_engine *e, dslam_scene *s, dslam_render_state *r, int max
 // SelSwapFresh     resident with state 0 (never visible since allocation): over alloc_bits      -- flush promotion
 // SelSwapOut       state == 2, resident, not visible (or any visibility): over alloc_bits        -- SaveToGlobalMemory
 struct SelSwapPending {
+  DSLAM_SEL_NO_LOAD
   const unsigned char *swap_state;
-  __device__ bool test(int t) const { return swap_state[t] == 1; }
+  __device__ bool test(int t, const NoPayload &) const { return swap_state[t] == 1; }
   __device__ void prologue() const {}
-  __device__ int emit(int, int, bool) const { return 0; }
+  __device__ int emit(int, int, bool, const NoPayload &) const { return 0; }
   __device__ void finish(int) const {}
 };
 struct SelSwapFresh {
+  DSLAM_SEL_NO_LOAD
   const HashEntry *hash;
   const unsigned char *swap_state;
-  __device__ bool test(int t) const { return swap_state[t] == 0 && hash[t].ptr >= 0; }
+  __device__ bool test(int t, const NoPayload &) const { return swap_state[t] == 0 && hash[t].ptr >= 0; }
   __device__ void prologue() const {}
-  __device__ int emit(int, int, bool) const { return 0; }
+  __device__ int emit(int, int, bool, const NoPayload &) const { return 0; }
   __device__ void finish(int) const {}
 };
 struct SelSwapOut {
+  DSLAM_SEL_NO_LOAD
   const HashEntry *hash;
   const unsigned char *swap_state;
   const unsigned char *vis_type;   // null: whatever the visibility
-  __device__ bool test(int t) const { return swap_state[t] == 2 && hash[t].ptr >= 0 && (vis_type == nullptr || vis_type[t] == 0); }
+  __device__ bool test(int t, const NoPayload &) const { return swap_state[t] == 2 && hash[t].ptr >= 0 && (vis_type == nullptr || vis_type[t] == 0); }
   __device__ void prologue() const {}
-  __device__ int emit(int, int, bool) const { return 0; }
+  __device__ int emit(int, int, bool, const NoPayload &) const { return 0; }
   __device__ void finish(int) const {}
 };
 

@@ -42,10 +42,11 @@ struct MeshParams {
 
 // the live list: every entry with a resident block, ascending -- the scene's alloc_bits as a list (dslam_bits.h)
 struct SelLive {
+  DSLAM_SEL_NO_LOAD
   const HashEntry *hash;
-  __device__ bool test(int t) const { return hash[t].ptr >= 0; }
+  __device__ bool test(int t, const NoPayload &) const { return hash[t].ptr >= 0; }
   __device__ void prologue() const {}
-  __device__ int emit(int, int, bool) const { return 0; }
+  __device__ int emit(int, int, bool, const NoPayload &) const { return 0; }
   __device__ void finish(int) const {}
 };
 

@@ -120,18 +120,18 @@ struct SelFrustum {
     if (PROJECT)   // (independent job) reset the range image to (FAR_AWAY, VERY_CLOSE)
       for (int i = blockIdx.x * 256 + threadIdx.x; i < npix; i += gridDim.x * 256) range[i] = make_float2(kFarAway, kVeryClose);
   }
-  __device__ bool test(int t) const {
-    const HashEntry e = load_entry(hash, t);
+  typedef HashEntry Payload;
+  __device__ HashEntry load(int t) const { return load_entry(hash, t); }
+  __device__ bool test(int, const HashEntry &e) const {
     if (e.ptr < 0) return false;
     bool vis, vis_enl;
     check_block_vis<false>(vis, vis_enl, e.pos[0], e.pos[1], e.pos[2], fp.M, fp.fx, fp.fy, fp.cx, fp.cy, fp.voxel_size, fp.W, fp.H);
     return vis;
   }
-  __device__ int emit(int t, int r, bool listed) const {
+  __device__ int emit(int, int r, bool listed, const HashEntry &e) const {
     if (!PROJECT || !listed) return 0;
     ProjParams pp;
     pp.M = fp.M; pp.fx = fp.fx; pp.fy = fp.fy; pp.cx = fp.cx; pp.cy = fp.cy; pp.voxel_size = fp.voxel_size; pp.W = fp.W; pp.H = fp.H;
-    const HashEntry e = load_entry(hash, t);
     int4 box;
     float2 zr;
     const int req = project_single_block(e, pp, box, zr);
