@@ -728,6 +728,7 @@ __global__ __launch_bounds__(256) void k_alloc_sweep(SweepParams p) {
         const int vr_all = all1 + (all2 < avail_ex ? all2 : avail_ex);
         const int succ_vba = vr_all < avail_vba ? vr_all : avail_vba;   // every success takes exactly one voxel-block slot
         p.cnt->last_free = base_free - succ_vba;
+        p.cnt->base_free = base_free - succ_vba;   // (the pool top the re-allocation of a swapping scene counts from)
         p.cnt->last_free_ex = base_free_ex - succ2_all;
         p.cnt->alloc_failures = all1 + all2 - succ_vba;
       } else {
@@ -764,58 +765,30 @@ __global__ __launch_bounds__(256) void k_types_rearm(const int *__restrict__ ids
 }
 
 // reallocate swapped-out blocks that came back into view (useSwapping only): one pool, so the r-th request in
-// hash-index order succeeds iff r < available.  Requests = visible entries (a bit in vis_bits) whose block is on the host.
-// Two small launches over the bitmap tiles: count, then place (the tile's offset is the sum of the tile counts in front).
-__global__ __launch_bounds__(256) void k_realloc_count(const unsigned *__restrict__ vis_bits, const HashEntry *__restrict__ hash,
-                                                       int *__restrict__ tile_counts, SceneCounters *cnt) {
-  __shared__ int red[16];
-  const int w0 = blockIdx.x * kBitTileWords + threadIdx.x * 4;
-  if (blockIdx.x == 0 && threadIdx.x == 0) cnt->base_free = cnt->last_free;  // (nothing moves the top before the apply pass ends)
-  const uint4 v = *reinterpret_cast<const uint4 *>(vis_bits + w0);
-  int c = 0;
-#pragma unroll 1
-  for (int i = 0; i < 4; i++)
-    for (unsigned m = sel4(v, i); m; m &= m - 1) c += hash[(w0 + i) * 32 + __ffs((int)m) - 1].ptr == -1;
-  int cv[4] = {c, 0, 0, 0};
-  block_sum4(cv, red);
-  if (threadIdx.x == 0) tile_counts[blockIdx.x] = cv[0];
-}
-
-__global__ __launch_bounds__(256) void k_realloc_apply(const unsigned *__restrict__ vis_bits, HashEntry *hash,
-                                                       const int *__restrict__ tile_counts, const int *__restrict__ alloc_list,
-                                                       unsigned *alloc_bits, SceneCounters *cnt) {
-  __shared__ int red[4];
-  const int w0 = blockIdx.x * kBitTileWords + threadIdx.x * 4;
-  const uint4 v = *reinterpret_cast<const uint4 *>(vis_bits + w0);
-  uint4 need = make_uint4(0, 0, 0, 0);
-#pragma unroll 1
-  for (int i = 0; i < 4; i++)
-    for (unsigned m = sel4(v, i); m; m &= m - 1) {
-      const int bit = __ffs((int)m) - 1;
-      if (hash[(w0 + i) * 32 + bit].ptr == -1) or4(need, i, 1u << bit);
+// hash-index order succeeds iff r < available.  Requests = visible entries (a bit in vis_bits) whose block is on the host:
+// an ordered selection (dslam_bits.h) whose emit step hands the r-th of them voxelAllocationList[top - r].  The pool top
+// the ranks refer to is the sweep's result, left in base_free by its last tile (nothing else moves it before finish()).
+struct SelNeedsBlock {
+  DSLAM_SEL_NO_LOAD
+  HashEntry *hash;
+  const int *alloc_list;
+  unsigned *alloc_bits;
+  SceneCounters *cnt;
+  __device__ void prologue() const {}
+  __device__ bool test(int t, const NoPayload &) const { return hash[t].ptr == -1; }
+  __device__ int emit(int t, int rank, bool, const NoPayload &) const {
+    const int base = cnt->base_free;
+    if (rank <= base) {
+      hash[t].ptr = alloc_list[base - rank];
+      bit_set(alloc_bits, t);
     }
-  int tot;
-  int r = block_excl_scan<4>(popc4(need), red, tot);
-  const bool last = blockIdx.x == gridDim.x - 1;
-  if (tot == 0 && !last) return;
-  const int offset = block_sum_strided(tile_counts, blockIdx.x, 1, red);
-  const int base_free = cnt->base_free;
-  if (last && threadIdx.x == 0) {
-    const int total = offset + tot, avail = base_free + 1;
-    cnt->last_free = base_free - (total < avail ? total : avail);
+    return 0;
   }
-  r += offset;
-#pragma unroll 1
-  for (int i = 0; i < 4; i++)
-    for (unsigned m = sel4(need, i); m; m &= m - 1) {
-      const int t = (w0 + i) * 32 + __ffs((int)m) - 1;
-      if (r <= base_free) {
-        hash[t].ptr = alloc_list[base_free - r];
-        bit_set(alloc_bits, t);
-      }
-      r++;
-    }
-}
+  __device__ void finish(int total) const {
+    const int base = cnt->base_free, avail = base + 1;
+    cnt->last_free = base - (total < avail ? total : avail);
+  }
+};
 
 static inline int ceil_pow2(int v) {
   int p = 1;
@@ -936,9 +909,8 @@ int launch_allocate(dslam_engine *e, dslam_scene *s, const dslam_view *v, dslam_
     (void)hipHostFree(dbg_host);
   }
   if (s->p.use_swapping) {
-    hipLaunchKernelGGL(k_realloc_count, dim3(n_tiles), dim3(256), 0, e->stream, r->vis_bits, s->hash, e->tile_counts, s->counters);
-    hipLaunchKernelGGL(k_realloc_apply, dim3(n_tiles), dim3(256), 0, e->stream, r->vis_bits, s->hash, e->tile_counts, s->alloc_list,
-                       s->alloc_bits, s->counters);
+    SelNeedsBlock sel{s->hash, s->alloc_list, s->alloc_bits, s->counters};
+    launch_bits_select(e, r->vis_bits, N, sel, (int *)nullptr, N, (int *)nullptr);
   }
   DSLAM_HIP(hipGetLastError());
   return DSLAM_OK;
