@@ -960,7 +960,7 @@ int launch_integrate_list(dslam_engine *e, dslam_scene *s, const dslam_view *v, 
 //                  names an entry that still holds the block, and the block existed before re-fusion k allocated);
 //                  bit 2k + 1: the re-fusion of keyframe k lists it
 //   ops[2k], ops[2k + 1]   pose and images of the two operations
-// A wave fetches its next block from a device counter (blocks differ in how many operations they take).
+// Blocks differ in how many operations they take: they are ordered longest first and dealt round-robin over the waves.
 struct BatchOp {
   Mat4 M;                // world -> camera of this operation (old pose: de-integration, new pose: re-fusion)
   const short *raw;      // the keyframe's int16 depth image (the float value is derived per read, like UpdateView does)
@@ -1031,7 +1031,7 @@ struct BatchColQueue {   // (the colour queue of k_integrate: one per wave)
 // LDS and run densely in one pass, as in k_integrate.  Half blocks, not blocks: the wave then needs ~90 registers instead
 // of ~140 (5 waves per SIMD instead of 3 to hide the two round trips of an operation behind each other's arithmetic)
 // and the batch has twice as many independent units to deal out.
-template <bool DEINT>
+template <bool DEINT, bool UNIT_W>   // UNIT_W: no depth weighting -- every observation has weight 1 (the reference's configuration)
 __device__ __forceinline__ void batch_op(uint4 (&v)[2], bool (&chs)[2], int gz0, const float (&pxy)[2][3], const float *Mm,
                                          const IntegrateParams &p, __amdgpu_buffer_rsrc_t raw_rs, float a, float b, const float *inv_tab,
                                          BatchColQueue &Q, int lane) {
@@ -1053,7 +1053,7 @@ __device__ __forceinline__ void batch_op(uint4 (&v)[2], bool (&chs)[2], int gz0,
     raw_depth_finish(rq[j], a, b);
     const PairProj &q = rq[j].q;
     unsigned cm;
-    chs[j] |= pair_update<DEINT, false>(v[j], q, p, inv_tab, cm);
+    chs[j] |= pair_update<DEINT, UNIT_W>(v[j], q, p, inv_tab, cm);
     cms |= cm << (2 * j);
     if (__ballot(cm != 0u)) {
 #pragma unroll
@@ -1097,8 +1097,12 @@ __device__ __forceinline__ void batch_op(uint4 (&v)[2], bool (&chs)[2], int gz0,
 }
 
 constexpr int kBatchWgWaves = 8;
-constexpr int kBatchGrid = 1024;   // 8192 waves: one full residency wave; blocks are fetched from a counter
+// 4096 waves = what is resident at once (4 per SIMD at this register count).  Units are dealt round-robin over the list
+// ordered longest first -- NOT fetched from a device counter: ~77 k fetches from one address serialise at ~12 ns each,
+// which was 0.9 ms of a 1.2 ms launch and the whole launch of a rank that owns an eighth of the blocks.
+constexpr int kBatchGrid = 512;
 
+template <bool UNIT_W>
 __global__ __launch_bounds__(kBatchWgWaves * 64) void k_reintegrate_blocks(BatchParams bp) {
   __shared__ float inv_tab[kInvTab];
   __shared__ BatchColQueue col_q[kBatchWgWaves];
@@ -1112,11 +1116,8 @@ __global__ __launch_bounds__(kBatchWgWaves * 64) void k_reintegrate_blocks(Batch
   BatchColQueue &Q = col_q[threadIdx.x >> 6];
   const int n = bp.dirty_count[0] * 2;   // units of work: half blocks
   const int vx0 = (lane & 3) * 2, vy = (lane >> 2) & 7, vz0 = lane >> 5;
-  while (true) {
-    int i = 0;
-    if (lane == 0) i = atomicAdd(bp.cursor, 1);
-    i = __builtin_amdgcn_readfirstlane(i);
-    if (i >= n) break;
+  const int wave = __builtin_amdgcn_readfirstlane((int)((blockIdx.x * (kBatchWgWaves * 64) + threadIdx.x) >> 6));
+  for (int i = wave; i < n; i += kBatchGrid * kBatchWgWaves) {
     const int ptr = __builtin_amdgcn_readfirstlane(bp.dirty_list[i >> 1]);
     const int half = i & 1;
     const unsigned long long mask = bp.opmask[ptr];
@@ -1125,12 +1126,19 @@ __global__ __launch_bounds__(kBatchWgWaves * 64) void k_reintegrate_blocks(Batch
     if (lane == 0 && half == 0) {
       if (p0.dirty) p0.dirty[ptr] = 1;
       if (p0.push_words) {
+        // (one read-modify-write per ring word, not one per re-fusion: a chain of ~16 dependent round trips per block on
+        // one lane, for every block on every rank, was 0.3 ms of the launch)
         unsigned long long *ring = p0.masks + ((size_t)ptr * 2 + p0.push_ring) * p0.push_words;
+        const unsigned long long fmask = mask & 0xAAAAAAAAAAAAAAAAull;
         int frame = -1;
-        for (unsigned long long m = mask & 0xAAAAAAAAAAAAAAAAull; m; m &= m - 1) {
-          const BatchOp &op = s_ops[__ffsll((long long)m) - 1];
-          ring[op.push_bit >> 6] |= 1ull << (op.push_bit & 63);
-          frame = op.push_frame;   // (ascending: the last re-fusion that lists the block)
+        for (int w = 0; w < p0.push_words; w++) {
+          unsigned long long acc = 0;
+          for (unsigned long long m = fmask; m; m &= m - 1) {
+            const BatchOp &op = s_ops[__ffsll((long long)m) - 1];
+            if ((op.push_bit >> 6) == w) acc |= 1ull << (op.push_bit & 63);
+            frame = op.push_frame;   // (ascending: the last re-fusion that lists the block)
+          }
+          if (acc) ring[w] |= acc;
         }
         if (frame >= 0) p0.last_seen[ptr] = frame;
       }
@@ -1166,8 +1174,8 @@ __global__ __launch_bounds__(kBatchWgWaves * 64) void k_reintegrate_blocks(Batch
         }
         const float *Mz = op.M.m;
         const __amdgpu_buffer_rsrc_t raw_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<short *>(op.raw), 0, bp.raw_bytes, 0x00020000);
-        if (bit & 1) batch_op<false>(v, chs, gz0, pxy, Mz, p, raw_rs, bp.a, bp.b, inv_tab, Q, lane);   // re-fusion at the new pose
-        else batch_op<true>(v, chs, gz0, pxy, Mz, p, raw_rs, bp.a, bp.b, inv_tab, Q, lane);              // de-integration at the old one
+        if (bit & 1) batch_op<false, UNIT_W>(v, chs, gz0, pxy, Mz, p, raw_rs, bp.a, bp.b, inv_tab, Q, lane);   // re-fusion at the new pose
+        else batch_op<true, UNIT_W>(v, chs, gz0, pxy, Mz, p, raw_rs, bp.a, bp.b, inv_tab, Q, lane);              // de-integration at the old one
       }
     }
     if (chs[0]) blk[lane] = v[0];
@@ -1264,7 +1272,8 @@ int launch_reintegrate_blocks(dslam_engine *e, dslam_scene *s, int w_d, int h_d,
   bp.a = a; bp.b = b;
   bp.raw_bytes = (w_d * h_d * 2 + 3) & ~3;
   bp.n_ops = n_ops;
-  hipLaunchKernelGGL(k_reintegrate_blocks, dim3(kBatchGrid), dim3(kBatchWgWaves * 64), 0, e->stream, bp);
+  if (ip.depth_weighting) hipLaunchKernelGGL(k_reintegrate_blocks<false>, dim3(kBatchGrid), dim3(kBatchWgWaves * 64), 0, e->stream, bp);
+  else hipLaunchKernelGGL(k_reintegrate_blocks<true>, dim3(kBatchGrid), dim3(kBatchWgWaves * 64), 0, e->stream, bp);
   DSLAM_HIP(hipGetLastError());
   return DSLAM_OK;
 }
