@@ -24,7 +24,7 @@ MODES = {"memory": (0, 0), "memory_decay": (1, 0), "memory_slide_window": (0, 1)
 POOL_UNITS = 10.24  # a 0x40000-block pool in the log's unit (GiB * 10.24)
 
 
-def run_mode(api, pkg, wl, params, frames, voxel_decay, min_decay_age, max_decay_weight, slide_window, max_age):
+def run_mode(api, pkg, wl, params, frames, voxel_decay, min_decay_age, max_decay_weight, slide_window, max_age, force_all=True):
     """Used bytes after every keyframe (InfiniTamDriver::GetLocalMapUsedMemoryBytes, InfiniTamDriver.h:344-347) until the
     pool cannot serve an allocation any more (the reference's "Origin" and "Map regularization" logs end there)."""
     from dslam_amd.harness import evalio
@@ -39,7 +39,7 @@ def run_mode(api, pkg, wl, params, frames, voxel_decay, min_decay_age, max_decay
         if slide_window and st["fusion_fifo_len"] > max_age:                # :215-225 (database size > max_age)
             api.slide_window(scene, rs, max_age)
         if voxel_decay:                                                     # :227-232 (forceAllVoxels = true, InfiniTamDriver.h:280)
-            api.decay(scene, rs, max_decay_weight, min_decay_age, True)
+            api.decay(scene, rs, max_decay_weight, min_decay_age, force_all)
         st2 = api.stats(scene, rs)
         st2["num_allocated_blocks"] = scene.params.num_local_blocks
         used.append(evalio.used_memory_bytes(st2))

@@ -5,8 +5,10 @@ the decision does, the shape pin cannot discriminate between decisions, and the 
 
   noise    in {0.25, 0.5, 1.0} px disparity noise (0.3 % gross mismatches throughout)
   max_age  in {0.6, 0.81, 1.0} x the origin run's fill time e0 (the reference: 259 / 320 = 0.81)
-  decision Decay(forceAll) gated by `last_seen <= newest - minAge` (this build) against the same sweep WITHOUT the gate
-           (min_decay_age 0: every block is swept on every call) at noise 0.5 px, max_age 0.81 e0
+  decision Decay(forceAll = true) gated by `last_seen <= newest - minAge` (this build; what InfiniTamDriver::Decay passes)
+           against (a) the same sweep WITHOUT the gate (min_decay_age 0: every block is swept on every call) and (b) DynSLAM's
+           aged-list mode (forceAll = false: each visible list is decayed once, when it is minAge lists old), both at
+           noise 0.5 px, max_age 0.81 e0
 
     python denseslam-global-consistency-h_amd/harness/memory_sensitivity.py [keyframes] > profiles/r03_memory_shape_sensitivity.json
 """
@@ -39,21 +41,22 @@ def main():
 
     for noise in noises:
         base = {}
-        for min_age, label in ((30, "gated (this build)"),) + (((0, "no last_seen gate"),) if noise == 0.5 else ()):
+        for min_age, force_all, label in ((30, True, "gated full sweep (this build)"),) + (
+                ((0, True, "full sweep without the last_seen gate"), (30, False, "aged-list mode (forceAll = false)")) if noise == 0.5 else ()):
             params = pkg.SceneParams(history_words=8, **wl.scene_kwargs)
             un = {}
             for name in ("memory", "memory_decay"):   # the un-windowed runs do not depend on max_age
                 vd, sw = mc.MODES[name]
-                un[name] = mc.run_mode(eng, pkg, wl, params, frames[noise], vd, min_age, 3, sw, 0)
+                un[name] = mc.run_mode(eng, pkg, wl, params, frames[noise], vd, min_age, 3, sw, 0, force_all=force_all)
             e0 = un["memory"][1] or len(un["memory"][0])
-            for f in factors if min_age == 30 else (0.81,):
+            for f in factors if (min_age == 30 and force_all) else (0.81,):
                 max_age = max(1, int(round(f * e0)))
                 params = pkg.SceneParams(history_words=(max_age + 64) // 64 + 1, **wl.scene_kwargs)
                 curves = {k_: v[0] for k_, v in un.items()}
                 exhausted = {k_: v[1] for k_, v in un.items()}
                 for name in ("memory_slide_window", "memory_decay_slide_window"):
                     vd, sw = mc.MODES[name]
-                    curves[name], exhausted[name] = mc.run_mode(eng, pkg, wl, params, frames[noise], vd, min_age, 3, sw, max_age)
+                    curves[name], exhausted[name] = mc.run_mode(eng, pkg, wl, params, frames[noise], vd, min_age, 3, sw, max_age, force_all=force_all)
                 row = {"noise_px": noise, "max_age_over_e0": f, "max_age": max_age, "decay": label}
                 row.update(four_ratios(curves, exhausted))
                 rows.append(row)

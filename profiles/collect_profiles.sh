@@ -24,4 +24,9 @@ python profiles/experiments/pipeline_breakdown.py 100 > gpurun_out/final_pipelin
 python denseslam-global-consistency-h_amd/harness/side_bench.py 50 > gpurun_out/final_side_bench.json 2>gpurun_out/final_side_bench.err; tail -c 300 gpurun_out/final_side_bench.json
 python denseslam-global-consistency-h_amd/harness/quality.py 40 > gpurun_out/final_quality.json 2>gpurun_out/final_quality.err; tail -c 300 gpurun_out/final_quality.json
 python denseslam-global-consistency-h_amd/harness/maint_bench.py > gpurun_out/final_maintenance.json 2>gpurun_out/final_maintenance.err; tail -c 400 gpurun_out/final_maintenance.json
+# the same script under the kernel trace: per-kernel split of the maintenance path (S-stress calls + keyframe loops, BASELINE configs[2])
+(cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/final_maint_stats -- python3 $R/denseslam-global-consistency-h_amd/harness/maint_bench.py > /dev/null 2> $R/gpurun_out/final_maint_stats.err); echo maint_stats rc=$?
+# per-kernel times of the three forms of the re-integration batch
+(cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/final_reint_stats -- python3 $R/bench.py --steps 100 --warmup 10 --no-cpu-baseline --no-stress --no-extra-rates --mode device > $R/gpurun_out/final_reint_stats.log 2>&1); echo reint_stats rc=$?
+python denseslam-global-consistency-h_amd/harness/memory_sensitivity.py 1500 > gpurun_out/final_memory_sensitivity.json 2> gpurun_out/final_memory_sensitivity.err; echo sensitivity rc=$?
 python denseslam-global-consistency-h_amd/harness/shard_emulation.py 120 32 > gpurun_out/final_shard_emulation.json 2>/dev/null; tail -c 300 gpurun_out/final_shard_emulation.json

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Turn the raw outputs of profiles/collect_profiles.sh (run on the GPU box, merged back under gpurun_out/) into the
-per-round files of this directory.  Usage: python profiles/make_profiles.py r02
+per-round files of this directory.  Usage: python profiles/make_profiles.py r03
 
 gpurun_out/final_bench.json              <- python bench.py                      (the driver's command)
 gpurun_out/final_bench_sync.json         <- python bench.py --mode sync ...
@@ -57,7 +57,7 @@ def copy_json(src, dst):
 
 
 def main():
-    tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
+    tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
     bench = last_json_line(os.path.join(OUT, "final_bench.json"))
     json.dump(bench, open(os.path.join(HERE, f"{tag}_bench_default.json"), "w"), indent=1)
     copy_json("final_bench_sync.json", f"{tag}_bench_sync.json")
@@ -165,8 +165,45 @@ def main():
         }, open(os.path.join(HERE, f"{tag}_integrate_wave_timeline.json"), "w"), indent=1)
     sw = os.path.join(OUT, "final_sweep.bin")
     if os.path.exists(sw):
-        subprocess.run([sys.executable, os.path.join(HERE, "experiments", "sweep_timeline.py"), sw,
+        subprocess.run([sys.executable, os.path.join(HERE, "experiments", "sweep_timeline3.py"), sw,
                         os.path.join(HERE, f"{tag}_sweep_timeline.json")], stdout=subprocess.DEVNULL, check=True)
+    ms_src = os.path.join(OUT, "final_memory_sensitivity.json")
+    if os.path.exists(ms_src) and os.path.getsize(ms_src) > 2:
+        json.dump(json.load(open(ms_src)), open(os.path.join(HERE, f"{tag}_memory_shape_sensitivity.json"), "w"), indent=1)
+    rs = newest("final_reint_stats/*/*kernel_stats.csv", required=False)
+    if rs:
+        shutil.copy(rs, os.path.join(HERE, f"{tag}_reintegration_kernel_stats.csv"))
+    # the maintenance path per kernel: the stats file as it is, and -- from the trace of the same run -- the longest launches
+    # of the streaming kernels, which are the calls on the S-stress map (1 GiB of voxels, 262144 blocks): GB/s against the peak
+    ms = newest("final_maint_stats/*/*kernel_stats.csv", required=False)
+    mt = newest("final_maint_stats/*/*kernel_trace.csv", required=False)
+    if ms and mt:
+        shutil.copy(ms, os.path.join(HERE, f"{tag}_maintenance_kernel_stats.csv"))
+        import collections
+        durs = collections.defaultdict(list)
+        for r in csv.DictReader(open(mt)):
+            durs[r["Kernel_Name"].split("(")[0]].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1000.0)
+        gib = 262144 * 4096
+        table = {}
+        for kern, nbytes, what in (("dslam::k_decay_blocks", gib, "read-only sweep of every block (4 KiB read per block)"),
+                                   ("dslam::k_release_and_leaders", gib, "release of every block (4 KiB reset per block)"),
+                                   ("dslam::k_fill_voxels", gib, "ResetScene's fill"),
+                                   ("void dslam::k_integrate<true, true, false, false>", 2 * gib + 262144 * 20, "de-integration of every block"),
+                                   ("void dslam::k_integrate<false, true, true, false>", 2 * gib + 262144 * 20, "fusion into every block")):
+            v = sorted(durs.get(kern, []), reverse=True)
+            if not v:
+                continue
+            # (k_decay_blocks: its longest launch is the sweep that also resets every voxel -- 2 GiB; the read-only ones follow)
+            pick = v[1] if kern == "dslam::k_decay_blocks" and len(v) > 1 else v[0]
+            table[kern] = {"what": what, "launch_us": round(pick, 1), "algorithmic_bytes": nbytes,
+                           "GBps": round(nbytes / pick / 1e3, 1), "frac_of_8TBps": round(nbytes / pick / 1e3 / 8000.0, 3),
+                           "longest_launches_us": [round(x, 1) for x in v[:5]]}
+        mj = os.path.join(HERE, f"{tag}_maintenance.json")
+        if os.path.exists(mj):
+            d = json.load(open(mj))
+            d["kernels_on_the_s_stress_map"] = table
+            d["per_kernel_summary"] = f"profiles/{tag}_maintenance_kernel_stats.csv (rocprofv3 --kernel-trace --stats of the same script)"
+            json.dump(d, open(mj, "w"), indent=1)
     print(f"{tag}: {bench['value']:.0f} frames/s, roofline frac {bench['roofline']['frac']:.3f}, "
           f"traffic/algorithmic {traffic / algo:.3f}")
 
