@@ -431,17 +431,26 @@ __device__ void walk_requests(const SweepParams &p, int limit_word, int avail_vb
   f1s = v[2];
 }
 
-template <bool SWAPPING>
+// One workgroup per tile of kSweepWords bitmap words, WPT consecutive words per thread.  The tile size is a trade: every
+// phase below is a round trip (or a chain of them) that all tiles go through side by side, so at the bench's 8 k visible
+// entries the launch takes as long as its slowest tile; the tile that ends the table holds the -- contiguous, mostly
+// visible -- recent part of the excess area, and a map with 262 k visible entries has 7 k of them per 32768-entry tile.
+// 8192-entry tiles: 144 for the default table (look-back: one word per lane), the excess area spread over 16 of them.
+constexpr int kSweepWpt = 1;
+constexpr int kSweepWords = 256 * kSweepWpt;
+
+template <bool SWAPPING, int WPT>
 __global__ __launch_bounds__(256) void k_alloc_sweep(SweepParams p) {
+  constexpr int TW = 256 * WPT, TE = TW * 32;
   __shared__ int red[16];
   __shared__ int s_ticket;
-  __shared__ unsigned s_newx[kBitTileWords];   // entries other tiles' commits create in this tile (excess area)
-  __shared__ unsigned s_mk[kBitTileWords], s_qx[kBitTileWords];   // the tile's mark bits / entries this pass made visible
-  constexpr int kEmitWindow = 8192;
+  __shared__ unsigned s_newx[TW];   // entries other tiles' commits create in this tile (excess area)
+  __shared__ unsigned s_mk[TW], s_qx[TW];   // the tile's mark bits / entries this pass made visible
+  constexpr int kEmitWindow = TE < 8192 ? TE : 8192;
   __shared__ unsigned short s_list[kEmitWindow];
   constexpr int kReqWindow = 2048;
-  __shared__ uint2 s_req[kReqWindow];                             // requests of the tile: entry | type, ranks inside the tile
-  __shared__ unsigned s_qv[kBitTileWords], s_qf[kBitTileWords];   // requests that made their entry visible / that found no block
+  __shared__ uint2 s_req[kReqWindow];       // requests of the tile: entry | type, ranks inside the tile
+  __shared__ unsigned s_qv[TW], s_qf[TW];   // requests that made their entry visible / that found no block
   // (snapshot taken by k_mark)
   const int base_free = __builtin_amdgcn_readfirstlane(p.cnt->base_free), base_free_ex = __builtin_amdgcn_readfirstlane(p.cnt->base_free_ex);
   const int avail_vba = base_free + 1, avail_ex = base_free_ex + 1;
@@ -452,31 +461,33 @@ __global__ __launch_bounds__(256) void k_alloc_sweep(SweepParams p) {
   if (p.dbg && threadIdx.x == 0) p.dbg[(size_t)b * 8] = t_start;
   STAMP(1);
   {
-    const int w0 = b * kBitTileWords + threadIdx.x * 4;   // this thread's four words
-    const uint4 q1 = *reinterpret_cast<const uint4 *>(p.q1 + w0), q2 = *reinterpret_cast<const uint4 *>(p.q2 + w0);
-    const uint4 mk = *reinterpret_cast<const uint4 *>(p.mark + w0), rt = *reinterpret_cast<const uint4 *>(p.retest + w0);
-    const uint4 pold = *reinterpret_cast<const uint4 *>(p.vis_bits + w0);
-    const int tile_first = b * kBitTileEntries;
+    const int lw0 = threadIdx.x * WPT;   // this thread's words inside the tile
+    const int w0 = b * TW + lw0;
+    unsigned q1[WPT], q2[WPT], mk[WPT], rt[WPT], pold[WPT];
+#pragma unroll
+    for (int i = 0; i < WPT; i++) { q1[i] = p.q1[w0 + i]; q2[i] = p.q2[w0 + i]; mk[i] = p.mark[w0 + i]; rt[i] = p.retest[w0 + i]; pold[i] = p.vis_bits[w0 + i]; }
+    const int tile_first = b * TE;
     // `mark` only holds found entries that were not visible before (see k_mark); one that was is known by its type byte,
     // which carries this pass' generation bit.  The re-test job has accepted every such byte it saw -- but it ran while
     // the pixels were still marking, and an entry that fails the block frustum test can be marked all the same (a block
     // that cuts a corner of the image without one of its own corners inside).  So the bytes of the entries the job turned
     // down are looked at once more, now that the marking is over; dense, through the LDS list, because those entries
     // cluster like the visible ones do.  Usually there are none to a few dozen per tile.
-    uint4 late = make_uint4(0, 0, 0, 0);
+    unsigned late[WPT];
     {
-      const uint4 cand = andn4v(pold, rt);
-      *reinterpret_cast<uint4 *>(&s_qx[threadIdx.x * 4]) = make_uint4(0, 0, 0, 0);
+      int cpop = 0;
+#pragma unroll
+      for (int i = 0; i < WPT; i++) { late[i] = 0; s_qx[lw0 + i] = 0; cpop += __popc(pold[i] & ~rt[i]); }
       int ctot;
-      const int crank = block_excl_scan<4>(popc4(cand), red, ctot);
+      const int crank = block_excl_scan<4>(cpop, red, ctot);
       if (ctot > 0) {
         for (int win = 0; win < ctot; win += kEmitWindow) {
           __syncthreads();
           int r = crank - win;
-#pragma unroll 1
-          for (int i = 0; i < 4; i++)
-            for (unsigned m = sel4(cand, i); m; m &= m - 1) {
-              if (r >= 0 && r < kEmitWindow) s_list[r] = (unsigned short)((threadIdx.x * 4 + i) * 32 + __ffs((int)m) - 1);
+#pragma unroll
+          for (int i = 0; i < WPT; i++)
+            for (unsigned m = pold[i] & ~rt[i]; m; m &= m - 1) {
+              if (r >= 0 && r < kEmitWindow) s_list[r] = (unsigned short)((lw0 + i) * 32 + __ffs((int)m) - 1);
               r++;
             }
           __syncthreads();
@@ -488,37 +499,39 @@ __global__ __launch_bounds__(256) void k_alloc_sweep(SweepParams p) {
           }
         }
         __syncthreads();
-        late = *reinterpret_cast<const uint4 *>(&s_qx[threadIdx.x * 4]);
+#pragma unroll
+        for (int i = 0; i < WPT; i++) late[i] = s_qx[lw0 + i];
         __syncthreads();   // (s_qx is used again further down)
       }
     }
-    const uint4 seen = or4v(or4v(rt, mk), late);
+    unsigned seen[WPT];
+    int c1 = 0, c2 = 0, n_seen = 0, n_q1new = 0;
+#pragma unroll
+    for (int i = 0; i < WPT; i++) {
+      seen[i] = rt[i] | mk[i] | late[i];
+      c1 += __popc(q1[i]); c2 += __popc(q2[i]);
+      n_seen += __popc(seen[i]); n_q1new += __popc(q1[i] & ~seen[i]);
+    }
     STAMP(2);
     // ---- counts out first: nothing a tile publishes depends on another tile -------------------------------------------
-    const int c1 = popc4(q1), c2 = popc4(q2);
     int r1, r2, tot1, tot2;
     block_excl_scan2<4>(c1, c2, red, r1, r2, tot1, tot2);
-    int tv[4] = {popc4(seen), popc4(andn4v(q1, seen)), 0, 0};
+    int tv[4] = {n_seen, n_q1new, 0, 0};
     block_sum4(tv, red);
     if (threadIdx.x == 0) {
       publish(p.agg_req, b, p.epoch, tot1, tot2);
       publish(p.agg_vis, b, p.epoch, tv[0], tv[1]);
     }
     // the other set of bitmaps starts the next pass clean
-    {
-      const uint4 z = make_uint4(0, 0, 0, 0);
-      *reinterpret_cast<uint4 *>(p.oq1 + w0) = z;
-      *reinterpret_cast<uint4 *>(p.oq2 + w0) = z;
-      *reinterpret_cast<uint4 *>(p.omark + w0) = z;
-    }
+#pragma unroll
+    for (int i = 0; i < WPT; i++) { p.oq1[w0 + i] = 0; p.oq2[w0 + i] = 0; p.omark[w0 + i] = 0; s_newx[lw0 + i] = 0; }
     const bool last = b == p.n_tiles - 1;
-    const bool has_excess = tile_first + kBitTileEntries > p.num_buckets || last;   // other tiles' commits may create entries here
-    s_newx[threadIdx.x * 4] = 0; s_newx[threadIdx.x * 4 + 1] = 0; s_newx[threadIdx.x * 4 + 2] = 0; s_newx[threadIdx.x * 4 + 3] = 0;
+    const bool has_excess = tile_first + TE > p.num_buckets || last;   // other tiles' commits may create entries here
     // requests of the tiles behind this one: only the tiles of the excess area need them (for the totals), and there
     // only excess requests exist -- counted straight from the bitmap
     int later2 = 0;
     if (has_excess)
-      for (int w = (b + 1) * kBitTileWords + threadIdx.x * 4; w < p.n_words; w += 1024) later2 += popc4(*reinterpret_cast<const uint4 *>(p.q2 + w));
+      for (int w = (b + 1) * TW + threadIdx.x; w < p.n_words; w += 256) later2 += __popc(p.q2[w]);
     STAMP(3);
     int pre[4];  // requests (type 1, type 2) and visible entries (retest | mark; new type-1 requests) in front of this tile
     if (!lookback2(p.agg_req, p.agg_vis, b, p.epoch, red, pre) && threadIdx.x == 0) atomicOr(&p.cnt->error_flags, 2);
@@ -536,7 +549,7 @@ __global__ __launch_bounds__(256) void k_alloc_sweep(SweepParams p) {
       const bool dry_total = has_excess && all1 + (all2 < avail_ex ? all2 : avail_ex) > avail_vba;
       if (dry_before || dry_total) {
         int s1q, f1s, s2;
-        walk_requests(p, b * kBitTileWords, avail_vba, avail_ex, red, s1q, f1s, s2);
+        walk_requests(p, b * TW, avail_vba, avail_ex, red, s1q, f1s, s2);
         if (dry_before) { vq_before = s1q; seen_before -= f1s; }
         succ2_all = s2;
       } else {
@@ -548,22 +561,22 @@ __global__ __launch_bounds__(256) void k_alloc_sweep(SweepParams p) {
     // lane and round -- a request is a chain of dependent reads (key -> depth pixel -> free-list slot), and a lane that holds
     // two of them in its own words would walk it twice while the rest of the workgroup waits at the next barrier (per-tile
     // timeline: 4.6 + 1.8 us of a 16 us launch went there).
-    *reinterpret_cast<uint4 *>(&s_qv[threadIdx.x * 4]) = make_uint4(0, 0, 0, 0);
-    *reinterpret_cast<uint4 *>(&s_qf[threadIdx.x * 4]) = make_uint4(0, 0, 0, 0);
+#pragma unroll
+    for (int i = 0; i < WPT; i++) { s_qv[lw0 + i] = 0; s_qf[lw0 + i] = 0; }
     const int req_tot = tot1 + tot2;
     for (int win = 0; win < req_tot; win += kReqWindow) {
       __syncthreads();   // (s_qv / s_qf zeroed; the previous window read)
       {
         int k1 = r1, k2 = r2;   // ranks inside the tile
-#pragma unroll 1
-        for (int i = 0; i < 4; i++) {
-          const unsigned a1 = sel4(q1, i), a2 = sel4(q2, i);
+#pragma unroll
+        for (int i = 0; i < WPT; i++) {
+          const unsigned a1 = q1[i], a2 = q2[i];
           for (unsigned m = a1 | a2; m; m &= m - 1) {
             const int bit = __ffs((int)m) - 1;
             const bool is2 = (a2 >> bit) & 1u;
             const int idx = k1 + k2 - win;
             if (idx >= 0 && idx < kReqWindow)
-              s_req[idx] = make_uint2((unsigned)((threadIdx.x * 4 + i) * 32 + bit) | (is2 ? 0x80000000u : 0u), (unsigned)k1 | ((unsigned)k2 << 16));
+              s_req[idx] = make_uint2((unsigned)((lw0 + i) * 32 + bit) | (is2 ? 0x80000000u : 0u), (unsigned)k1 | ((unsigned)k2 << 16));
             if (is2) k2++; else k1++;
           }
         }
@@ -616,8 +629,9 @@ __global__ __launch_bounds__(256) void k_alloc_sweep(SweepParams p) {
       }
     }
     __syncthreads();
-    const uint4 qvis = *reinterpret_cast<const uint4 *>(&s_qv[threadIdx.x * 4]);    // type-1 requests that make their entry visible in this pass
-    const uint4 qfail = *reinterpret_cast<const uint4 *>(&s_qf[threadIdx.x * 4]);   // type-1 requests that found no block: the entry is not visible, whatever it was
+    unsigned qvis[WPT], qfail[WPT];   // type-1 requests that make their entry visible in this pass / that found no block
+#pragma unroll
+    for (int i = 0; i < WPT; i++) { qvis[i] = s_qv[lw0 + i]; qfail[i] = s_qf[lw0 + i]; }
     STAMP(5);
     // ---- entries other tiles create in the excess area: the first succ2_all slots off the excess free list ---------------
     int newx_before = 0;   // ... of them in front of this tile and not counted as (retest | mark) there
@@ -625,43 +639,51 @@ __global__ __launch_bounds__(256) void k_alloc_sweep(SweepParams p) {
       for (int j = threadIdx.x; j < succ2_all; j += 256) {
         const int t = p.num_buckets + p.excess_list[base_free_ex - j];
         const int rel = t - tile_first;
-        if (rel >= 0 && rel < kBitTileEntries) atomicOr(&s_newx[rel >> 5], 1u << (rel & 31));
+        if (rel >= 0 && rel < TE) atomicOr(&s_newx[rel >> 5], 1u << (rel & 31));
         else if (rel < 0 && !(((p.retest[t >> 5] | p.mark[t >> 5]) >> (t & 31)) & 1u)) newx_before++;
       }
       int nv[4] = {newx_before, 0, 0, 0};
       block_sum4(nv, red);   // (has a barrier: s_newx is complete behind it)
       newx_before = nv[0];
     }
-    const uint4 newx = has_excess ? *reinterpret_cast<const uint4 *>(&s_newx[threadIdx.x * 4]) : make_uint4(0, 0, 0, 0);
     STAMP(6);
     // ---- the visible list -----------------------------------------------------------------------------------------------
-    const uint4 vis = or4v(or4v(andn4v(seen, qfail), qvis), newx);
+    unsigned vis[WPT];
+    int vpop = 0;
+#pragma unroll
+    for (int i = 0; i < WPT; i++) {
+      const unsigned newx = has_excess ? s_newx[lw0 + i] : 0u;
+      vis[i] = (seen[i] & ~qfail[i]) | qvis[i] | newx;
+      vpop += __popc(vis[i]);
+      qvis[i] |= newx;   // (the pass made these visible itself: type 1)
+    }
     int vis_tot;
-    const int vis_rank = block_excl_scan<4>(popc4(vis), red, vis_tot);   // (its barriers also order the request lanes' type bytes)
+    const int vis_rank = block_excl_scan<4>(vpop, red, vis_tot);   // (its barriers also order the request lanes' type bytes)
     const int vis_first = seen_before + vq_before + newx_before;
     // entries that are no longer visible (stores only: nothing to wait for)
-#pragma unroll 1
-    for (int i = 0; i < 4; i++)
-      for (unsigned m = sel4(pold, i) & ~sel4(vis, i); m; m &= m - 1) p.vis_type[(w0 + i) * 32 + __ffs((int)m) - 1] = 0;
+#pragma unroll
+    for (int i = 0; i < WPT; i++)
+      for (unsigned m = pold[i] & ~vis[i]; m; m &= m - 1) p.vis_type[(w0 + i) * 32 + __ffs((int)m) - 1] = 0;
     // The visible entries are written densely: expanded into an LDS list (a window of kEmitWindow ranks at a time), then
     // one entry per lane and round -- coalesced list stores, and the visible entries of the excess area, which fill a few
     // words completely (excess slots are handed out contiguously), do not queue up behind a single lane.
-    *reinterpret_cast<uint4 *>(&s_mk[threadIdx.x * 4]) = mk;
-    *reinterpret_cast<uint4 *>(&s_qx[threadIdx.x * 4]) = or4v(qvis, newx);   // (the pass made these visible itself: type 1)
-    // The words are expanded by OTHER lanes than the ones that own them: word k by lane k % 256.  A lane owns four
-    // consecutive words, and the recently allocated -- mostly visible -- entries of the excess area are consecutive: the
-    // eight lanes that own them would each write 128 list entries one after the other while 248 lanes wait (the tile that ends
-    // the table took 8.5 us for its list where the others take 2.6).  (s_qv / s_qf are free again: the words and their ranks.)
+    // The words are expanded by OTHER lanes than the ones that own them: word k by lane k % 256.  With several consecutive
+    // words per lane the lanes that own the consecutive -- mostly visible -- recent entries of the excess area would each write
+    // 128 list entries one after the other while the rest waits (32768-entry tiles: the tile that ends the table took 8.5 us
+    // for its list where the others took 2.6).  (s_qv / s_qf are free again: the words and their ranks.)
     {
-      const int c0 = __popc(vis.x), c1v = __popc(vis.y), c2v = __popc(vis.z);
-      *reinterpret_cast<uint4 *>(&s_qv[threadIdx.x * 4]) = vis;
-      *reinterpret_cast<uint4 *>(&s_qf[threadIdx.x * 4]) = make_uint4((unsigned)vis_rank, (unsigned)(vis_rank + c0), (unsigned)(vis_rank + c0 + c1v),
-                                                                     (unsigned)(vis_rank + c0 + c1v + c2v));
+      int r = vis_rank;
+#pragma unroll
+      for (int i = 0; i < WPT; i++) {
+        s_mk[lw0 + i] = mk[i]; s_qx[lw0 + i] = qvis[i];
+        s_qv[lw0 + i] = vis[i]; s_qf[lw0 + i] = (unsigned)r;
+        r += __popc(vis[i]);
+      }
     }
     for (int win = 0; win < vis_tot; win += kEmitWindow) {
       __syncthreads();   // (s_mk / s_qx / words / ranks written; the previous window read)
-#pragma unroll 1
-      for (int q = 0; q < 4; q++) {
+#pragma unroll
+      for (int q = 0; q < WPT; q++) {
         const int k = threadIdx.x + 256 * q;
         int r = (int)s_qf[k] - win;
         for (unsigned m = s_qv[k]; m; m &= m - 1) {
@@ -671,8 +693,8 @@ __global__ __launch_bounds__(256) void k_alloc_sweep(SweepParams p) {
       }
       __syncthreads();
       const int n_win = (vis_tot - win) < kEmitWindow ? (vis_tot - win) : kEmitWindow;
-      // (four entries per lane at a time, their type bytes requested together: the tile that ends the table holds the
-      // visible entries of the whole excess area -- several rounds where the others need one -- and a round is a round trip)
+      // (four entries per lane at a time, their type bytes requested together: a tile of the excess area can hold a few
+      // thousand visible entries -- several rounds where the others need one -- and a round is a round trip)
       constexpr int kEmitBatch = 4;
       for (int j0 = threadIdx.x; j0 < n_win; j0 += 256 * kEmitBatch) {
         int tt[kEmitBatch];
@@ -719,7 +741,8 @@ __global__ __launch_bounds__(256) void k_alloc_sweep(SweepParams p) {
         }
       }
     }
-    *reinterpret_cast<uint4 *>(p.vis_bits + w0) = vis;
+#pragma unroll
+    for (int i = 0; i < WPT; i++) p.vis_bits[w0 + i] = vis[i];
     STAMP(7);
     if (last && threadIdx.x == 0) {
       const int n = vis_first + vis_tot;
@@ -840,7 +863,7 @@ int launch_allocate(dslam_engine *e, dslam_scene *s, const dslam_view *v, dslam_
   const unsigned old_gen = r->gen;
   r->gen ^= 0x80u;
   mp.gen = r->gen;
-  const int n_tiles = bit_tiles(N), n_words = n_tiles * kBitTileWords;
+  const int n_words = bit_tiles(N) * kBitTileWords, n_tiles = n_words / kSweepWords;
   if (!r->types_follow_list) {
     hipLaunchKernelGGL(k_types_keep, dim3(n_words / 256), dim3(256), 0, e->stream, r->visible_type, r->vis_bits, n_words, (unsigned)r->gen);
     hipLaunchKernelGGL(k_types_rearm, dim3(64), dim3(256), 0, e->stream, r->visible_ids, r->counters, r->visible_type, r->vis_bits, old_gen);
@@ -900,8 +923,8 @@ int launch_allocate(dslam_engine *e, dslam_scene *s, const dslam_view *v, dslam_
     memset(dbg_host, 0, (size_t)n_tiles * 64);
     sp.dbg = dbg_host;
   }
-  if (s->p.use_swapping) hipLaunchKernelGGL(k_alloc_sweep<true>, dim3(grid), dim3(256), 0, e->stream, sp);
-  else hipLaunchKernelGGL(k_alloc_sweep<false>, dim3(grid), dim3(256), 0, e->stream, sp);
+  if (s->p.use_swapping) hipLaunchKernelGGL((k_alloc_sweep<true, kSweepWpt>), dim3(grid), dim3(256), 0, e->stream, sp);
+  else hipLaunchKernelGGL((k_alloc_sweep<false, kSweepWpt>), dim3(grid), dim3(256), 0, e->stream, sp);
   dbg_sync(e, "k_alloc_sweep");
   if (dbg_host) {
     DSLAM_HIP(hipStreamSynchronize(e->stream));
@@ -910,7 +933,7 @@ int launch_allocate(dslam_engine *e, dslam_scene *s, const dslam_view *v, dslam_
   }
   if (s->p.use_swapping) {
     SelNeedsBlock sel{s->hash, s->alloc_list, s->alloc_bits, s->counters};
-    launch_bits_select(e, r->vis_bits, N, sel, (int *)nullptr, N, (int *)nullptr);
+    launch_bits_select(e, r->vis_bits, N, sel, (int *)nullptr, N, (int *)nullptr, &s->counters->error_flags);
   }
   DSLAM_HIP(hipGetLastError());
   return DSLAM_OK;

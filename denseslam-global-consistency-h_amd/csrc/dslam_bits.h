@@ -4,31 +4,24 @@
 // (decay candidates, blocks leaving the window, blocks to swap, live blocks to mesh, FindVisibleBlocks, the rebuild of a
 // visible list).  On the device that is an ordered compaction; up to round 2 each one read all 1.18 M entries (19 MB, plus
 // byte flags).  Here the candidates come from a bitmap -- allocated entries, entries with a type -- of which a set bit
-// costs one sparse read and a clear one nothing.  Two launches, both balanced:
-//   k_bits_test     tile = 32 words = 1024 entries per 256-thread workgroup.  The set bits of the tile are expanded into an
-//                   LDS list and tested DENSELY, one candidate per lane and round: excess entries are handed out
-//                   contiguously, so some bitmap words are full while most are nearly empty -- a lane that walks "its" word
-//                   bit by bit ends up with 32 dependent gathers where its neighbours have none (measured: 100 us for
-//                   FindVisibleBlocks that way).  Out: the selection as a bitmap + the tile's count.
-//   k_bits_compact  tile = 256 words = 8192 entries.  Rank = sum of the test tiles' counts in front + popcounts; the
-//                   selected entries are again expanded into LDS and emitted densely (coalesced list stores).
-// No look-back, no spin, no ticket: the only hand-off is the kernel boundary.
+// costs one sparse read and a clear one nothing.  One launch (k_bits_select, below): the set bits of a tile are expanded
+// into an LDS list and tested densely, the tiles hand their counts to each other inside the launch, the selected entries
+// are emitted in index order by the lanes that tested them.
 // A selection is a functor with
-//   void prologue()                          an independent grid-stride job run by the compaction launch (optional work)
+//   void prologue()                          an independent grid-stride job (stores nobody in the launch waits for)
 //   Payload load(int t)                      what test / emit need to read about entry t (a hash entry, or nothing): the
 //                                            kernels request it for four entries per lane before they look at the first,
 //                                            so that the rounds of a crowded tile -- the one that ends the table holds the
 //                                            whole dense part of the excess area -- do not each pay their own round trip
 //   bool test(int t, const Payload &)        is entry t (its bit is set in the source bitmap) selected?  May have side
 //                                            effects on state that belongs to entry t alone.
-//   int  emit(int t, int rank, bool listed, const Payload &)
+//   Staged stage(int t, const Payload &)     what emit can work out about a selected entry without knowing its rank (runs
+//                                            while the tile counts travel between the workgroups)
+//   int  emit(int t, int rank, bool listed, const Staged &)
 //                                            called for every selected entry (listed: rank < capacity; rank ascending with
-//                                            t); the return values are summed per compaction tile (tile_sum_out)
+//                                            t); the return values are summed per tile (tile_sum_out)
 //   void finish(int total)                   called once (one thread of the tile that ends the table), behind every emit of
 //                                            that tile
-// `gate` (optional device flag): the selection runs only if *gate != 0 -- for passes that are needed only if an earlier
-// kernel of the same call found work (the launches themselves are unconditional: no host round trip).  The test launch
-// copies the flag to gate[1], which the compaction launch obeys, so that finish() may re-arm gate[0].
 #pragma once
 #include "dslam_internal.h"
 
@@ -36,125 +29,27 @@ namespace dslam {
 
 struct NoPayload {};
 // for selections whose test / emit read what they need themselves
-#define DSLAM_SEL_NO_LOAD typedef NoPayload Payload; __device__ NoPayload load(int) const { return NoPayload(); }
+// for selections whose emit has nothing to prepare: it gets the payload
+#define DSLAM_SEL_NO_STAGE typedef Payload Staged; __device__ const Payload &stage(int, const Payload &p) const { return p; }
+#define DSLAM_SEL_NO_LOAD typedef NoPayload Payload; __device__ NoPayload load(int) const { return NoPayload(); } DSLAM_SEL_NO_STAGE
 constexpr int kSelBatch = 4;            // entries per lane whose loads are in flight together
 
-constexpr int kTestTileWords = 32;      // k_bits_test: 1024 entries per workgroup
-constexpr int kCompactTileWords = 256;  // k_bits_compact: 8192 entries per workgroup
+constexpr int kCompactTileWords = 256;  // (tiles of the list rebuild in maintain.hip)
+#ifndef DSLAM_SEL_THREADS
+#define DSLAM_SEL_THREADS 1024
+#endif
+#ifndef DSLAM_SEL_BITS
+#define DSLAM_SEL_BITS 8
+#endif
+constexpr int kSelThreads = DSLAM_SEL_THREADS;
+constexpr int kSelBits = DSLAM_SEL_BITS;         // a selection tile: kSelBits bits of the bitmap per thread
+constexpr int kSelTileWords = kSelThreads * kSelBits / 32;
+static inline int select_tiles(int n_entries) { return bit_tiles(n_entries) * (kBitTileWords / kSelTileWords); }
 
 // the set bits of `w` as entry indices relative to the tile, ascending, to list[rank ...]
 __device__ __forceinline__ int expand_bits(unsigned w, int rel0, int rank, unsigned short *list) {
   for (; w; w &= w - 1) list[rank++] = (unsigned short)(rel0 + __ffs((int)w) - 1);
   return rank;
-}
-
-template <class Sel>
-__global__ __launch_bounds__(256) void k_bits_test(const unsigned *__restrict__ src_bits, Sel sel, unsigned *__restrict__ pick_bits,
-                                                   int *__restrict__ tile_counts, int *gate) {
-  __shared__ int red[4];
-  __shared__ unsigned short s_list[kTestTileWords * 32];
-  __shared__ unsigned s_pick[kTestTileWords];
-  if (gate) {
-    const int g = __builtin_amdgcn_readfirstlane(gate[0]);
-    if (blockIdx.x == 0 && threadIdx.x == 0) gate[1] = g;
-    if (g == 0) return;
-  }
-  // thread = 4 entries: nibble (tid & 7) of word (tid >> 3)
-  const int word = blockIdx.x * kTestTileWords + (threadIdx.x >> 3);
-  const unsigned nib = (src_bits[word] >> ((threadIdx.x & 7) * 4)) & 0xfu;
-  if (threadIdx.x < kTestTileWords) s_pick[threadIdx.x] = 0;
-  int tot;
-  const int rank = block_excl_scan<4>(__popc(nib), red, tot);   // (its barriers also cover s_pick)
-  expand_bits(nib, threadIdx.x * 4, rank, s_list);
-  __syncthreads();
-  const int t0 = blockIdx.x * (kTestTileWords * 32);
-  for (int j0 = threadIdx.x; j0 < tot; j0 += 256 * kSelBatch) {
-    typename Sel::Payload pl[kSelBatch];
-    int rel[kSelBatch];
-#pragma unroll
-    for (int q = 0; q < kSelBatch; q++) {
-      const int j = j0 + q * 256;
-      rel[q] = j < tot ? (int)s_list[j] : -1;
-      if (rel[q] >= 0) pl[q] = sel.load(t0 + rel[q]);
-    }
-#pragma unroll
-    for (int q = 0; q < kSelBatch; q++)
-      if (rel[q] >= 0 && sel.test(t0 + rel[q], pl[q])) atomicOr(&s_pick[rel[q] >> 5], 1u << (rel[q] & 31));
-  }
-  __syncthreads();
-  if (threadIdx.x < kTestTileWords) {
-    const unsigned p = s_pick[threadIdx.x];
-    pick_bits[blockIdx.x * kTestTileWords + threadIdx.x] = p;
-    int c = __popc(p);
-    for (int d = 16; d > 0; d >>= 1) c += __shfl_xor(c, d, 64);   // (kTestTileWords = 32 lanes of wave 0)
-    if (threadIdx.x == 0) tile_counts[blockIdx.x] = c;
-  }
-}
-
-template <class Sel>
-__global__ __launch_bounds__(256) void k_bits_compact(const unsigned *__restrict__ pick_bits, const int *__restrict__ tile_counts,
-                                                      Sel sel, int *__restrict__ out, int capacity, int *total_out,
-                                                      int *tile_sum_out, const int *gate) {
-  __shared__ int red[4];
-  __shared__ unsigned short s_list[kCompactTileWords * 32];
-  if (gate && __builtin_amdgcn_readfirstlane(gate[1]) == 0) return;
-  sel.prologue();
-  const unsigned w = pick_bits[blockIdx.x * kCompactTileWords + threadIdx.x];
-  // the test tiles in front of this tile: (kCompactTileWords / kTestTileWords) per compaction tile
-  const int before = block_sum_strided(tile_counts, blockIdx.x * (kCompactTileWords / kTestTileWords), 1, red);
-  int tot;
-  const int rank = block_excl_scan<4>(__popc(w), red, tot);
-  const bool last = blockIdx.x == gridDim.x - 1;
-  if (tot == 0 && !last) {
-    if (tile_sum_out && threadIdx.x == 0) tile_sum_out[blockIdx.x] = 0;
-    return;
-  }
-  expand_bits(w, threadIdx.x * 32, rank, s_list);
-  __syncthreads();
-  const int t0 = blockIdx.x * (kCompactTileWords * 32);
-  int sum = 0;
-  for (int j0 = threadIdx.x; j0 < tot; j0 += 256 * kSelBatch) {
-    typename Sel::Payload pl[kSelBatch];
-    int tt[kSelBatch];
-#pragma unroll
-    for (int q = 0; q < kSelBatch; q++) {
-      const int j = j0 + q * 256;
-      tt[q] = j < tot ? t0 + (int)s_list[j] : -1;
-      if (tt[q] >= 0) pl[q] = sel.load(tt[q]);
-    }
-#pragma unroll
-    for (int q = 0; q < kSelBatch; q++) {
-      if (tt[q] < 0) continue;
-      const int r = before + j0 + q * 256;
-      if (r < capacity && out) out[r] = tt[q];
-      sum += sel.emit(tt[q], r, r < capacity, pl[q]);
-    }
-  }
-  if (tile_sum_out) {
-    for (int d = 32; d > 0; d >>= 1) sum += __shfl_xor(sum, d, 64);
-    __syncthreads();
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = sum;
-    __syncthreads();
-    if (threadIdx.x == 0) tile_sum_out[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
-  }
-  if (last) {
-    __syncthreads();   // (every emit of this tile is behind us)
-    if (threadIdx.x == 0) {
-      if (total_out) *total_out = (before + tot) < capacity ? (before + tot) : capacity;
-      sel.finish(before + tot);
-    }
-  }
-}
-
-// out[0 .. min(total, capacity)) = the selected entries, ascending; *total_out = min(total, capacity)
-template <class Sel>
-inline void launch_bits_select(dslam_engine *e, const unsigned *src_bits, int n_entries, const Sel &sel, int *out, int capacity,
-                               int *total_out, int *tile_sum_out = nullptr, int *gate = nullptr) {
-  const int n_words = bit_tiles(n_entries) * kBitTileWords;
-  hipLaunchKernelGGL(k_bits_test<Sel>, dim3(n_words / kTestTileWords), dim3(256), 0, e->stream, src_bits, sel, e->bits_tmp,
-                     e->tile_counts, gate);
-  hipLaunchKernelGGL(k_bits_compact<Sel>, dim3(n_words / kCompactTileWords), dim3(256), 0, e->stream, e->bits_tmp, e->tile_counts,
-                     sel, out, capacity, total_out, tile_sum_out, gate);
 }
 
 // ---- tiles taken by ticket + one in-launch look-back (list-tile compactions of the release pipeline) ---------------------
@@ -164,13 +59,15 @@ struct TileChain {
   unsigned *ticket;
   unsigned ticket_base;
   int n_tiles;
+  unsigned long long *dbg;   // diagnostics (DSLAM_DBG_SELECT=<file>): 8 timestamps per tile
 };
 
 // single-channel look-back: a 32-bit count per tile ({epoch, count} in one word); bounded spin
-static __device__ __forceinline__ bool lookback1(const unsigned long long *agg, int n, unsigned epoch, int *lds4, int &sum) {
+template <int THREADS = 256>
+static __device__ __forceinline__ bool lookback1(const unsigned long long *agg, int n, unsigned epoch, int *lds /* [THREADS / 64] */, int &sum) {
   int s = 0;
   bool ok = true;
-  for (int j = threadIdx.x; j < n; j += 256) {
+  for (int j = threadIdx.x; j < n; j += THREADS) {
     unsigned long long w = __hip_atomic_load(&agg[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     int spins = 0;
     while ((unsigned)(w >> 32) != epoch) {
@@ -181,9 +78,12 @@ static __device__ __forceinline__ bool lookback1(const unsigned long long *agg, 
     s += (int)(unsigned)w;
   }
   for (int d = 32; d > 0; d >>= 1) s += __shfl_xor(s, d, 64);
-  if ((threadIdx.x & 63) == 0) lds4[threadIdx.x >> 6] = s;
+  if ((threadIdx.x & 63) == 0) lds[threadIdx.x >> 6] = s;
   const int all_ok = __syncthreads_and(ok ? 1 : 0);
-  sum = __builtin_amdgcn_readfirstlane(lds4[0] + lds4[1] + lds4[2] + lds4[3]);
+  int tot = 0;
+#pragma unroll
+  for (int w = 0; w < THREADS / 64; w++) tot += lds[w];
+  sum = __builtin_amdgcn_readfirstlane(tot);
   __syncthreads();
   return __builtin_amdgcn_readfirstlane(all_ok) != 0;
 }
@@ -195,6 +95,7 @@ static __device__ __forceinline__ void publish1(unsigned long long *agg, int til
 // `second`: the chain runs next to another one in the same launch (own counter, own channel of per-tile words)
 inline TileChain next_chain(dslam_engine *e, int n_tiles, int *grid_out, bool second = false) {
   TileChain ch;
+  ch.dbg = nullptr;
   if (++e->epoch == 0) e->epoch = 1;
   ch.agg = second ? e->agg + e->agg_tiles : e->agg;
   ch.epoch = e->epoch;
@@ -206,6 +107,189 @@ inline TileChain next_chain(dslam_engine *e, int n_tiles, int *grid_out, bool se
   base += (unsigned)grid;
   *grid_out = grid;
   return ch;
+}
+
+
+// One launch: tile = kCompactTileWords words = 8192 entries per 1024-thread workgroup, tiles taken by ticket.
+//   1. the set bits of the tile are expanded into an LDS list (thread = one byte of a word) and tested DENSELY, one candidate
+//      per lane and round: excess entries are handed out contiguously, so some bitmap words are full while most are nearly
+//      empty -- a lane that walks "its" word bit by bit ends up with 32 dependent gathers where its neighbours have none
+//      (measured: 100 us for FindVisibleBlocks that way).  1024 threads, so that the tile that holds the dense part of
+//      the excess area needs two rounds of four loads per lane at most.
+//   2. the verdicts (wave ballots, by list position) give the ranks inside the tile; the tile's count goes out, the counts of
+//      the tiles in front come in (one look-back: tiles are taken in starting order, so every word waited for belongs to a
+//      workgroup that is running; the spin is bounded all the same);
+//   3. the selected entries are emitted, each by the lane that tested it (the payload of the first round is still in
+//      registers).
+// Up to the middle of round 3 this was two launches (test -> bitmap + counts | compact), 7.5 + 7.8 us for GetImage's
+// FindVisibleBlocks where this one takes 8: the second launch had to read back what the first had in registers, and the
+// boundary between them cost more than the look-back does.
+template <class Sel>
+__global__ __launch_bounds__(kSelThreads) void k_bits_select(const unsigned *__restrict__ src_bits, Sel sel, int *__restrict__ out,
+                                                             int capacity, int *total_out, int *tile_sum_out, TileChain ch,
+                                                             int *error_flags) {
+  constexpr int kWaves = kSelThreads / 64;
+  constexpr int kTileEntries = kSelTileWords * 32;
+  constexpr int kRounds = (kTileEntries + kSelThreads * kSelBatch - 1) / (kSelThreads * kSelBatch);
+  __shared__ int red[kWaves];
+  __shared__ int s_ticket;
+  __shared__ unsigned short s_list[kTileEntries];
+  __shared__ unsigned s_pick[kTileEntries / 32];   // verdicts by list position
+  __shared__ int s_pref[kTileEntries / 32];
+  const unsigned long long t_start = ch.dbg ? __builtin_amdgcn_s_memtime() : 0ull;
+  const int b = take_ticket(ch.ticket, ch.ticket_base, &s_ticket);
+  if (b >= ch.n_tiles) return;
+#define DSLAM_SEL_STAMP(i) do { if (ch.dbg && threadIdx.x == 0) ch.dbg[(size_t)b * 8 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+  if (ch.dbg && threadIdx.x == 0) ch.dbg[(size_t)b * 8] = t_start;
+  DSLAM_SEL_STAMP(1);
+  const bool last = b == ch.n_tiles - 1;
+  const int tid = threadIdx.x, lane = tid & 63;
+  // thread = kSelBits entries: field (tid % kPerWord) of word (tid / kPerWord)
+  constexpr int kPerWord = 32 / kSelBits;
+  const unsigned byte = (src_bits[b * kSelTileWords + tid / kPerWord] >> ((tid % kPerWord) * kSelBits)) & ((1u << kSelBits) - 1u);
+  int tot;
+  const int rank0 = block_excl_scan<kWaves>(__popc(byte), red, tot);
+  if (tot == 0) {   // (most tiles of a sparse bitmap)
+    if (tid == 0) {
+      publish1(ch.agg, b, ch.epoch, 0);
+      if (tile_sum_out) tile_sum_out[b] = 0;
+    }
+    if (!last) { sel.prologue(); return; }
+  }
+  DSLAM_SEL_STAMP(2);
+  if (tid < kTileEntries / 32) s_pick[tid] = 0;
+  expand_bits(byte, tid * kSelBits, rank0, s_list);
+  __syncthreads();
+  DSLAM_SEL_STAMP(3);
+  const int t0 = b * kTileEntries;
+  // ---- test: four candidates per lane in flight; the first round's payloads stay in registers for the emit --------------
+  typename Sel::Payload pl0[kSelBatch];
+  int tt0[kSelBatch];
+  unsigned pass0 = 0;
+#pragma unroll
+  for (int q = 0; q < kSelBatch; q++) {
+    const int j = tid + q * kSelThreads;
+    tt0[q] = j < tot ? t0 + (int)s_list[j] : -1;
+    if (tt0[q] >= 0) pl0[q] = sel.load(tt0[q]);
+  }
+#pragma unroll
+  for (int q = 0; q < kSelBatch; q++) {
+    const bool ok = tt0[q] >= 0 && sel.test(tt0[q], pl0[q]);
+    pass0 |= ok ? (1u << q) : 0u;
+    const unsigned long long m = __ballot(ok);
+    if (lane == 0 && m) { const int wi = (tid + q * kSelThreads) >> 5; s_pick[wi] = (unsigned)m; s_pick[wi + 1] = (unsigned)(m >> 32); }
+  }
+  for (int rd = 1; rd < kRounds; rd++) {
+    if (rd * kSelThreads * kSelBatch >= tot) break;   // (uniform)
+    typename Sel::Payload pl[kSelBatch];
+    int tt[kSelBatch];
+#pragma unroll
+    for (int q = 0; q < kSelBatch; q++) {
+      const int j = tid + (rd * kSelBatch + q) * kSelThreads;
+      tt[q] = j < tot ? t0 + (int)s_list[j] : -1;
+      if (tt[q] >= 0) pl[q] = sel.load(tt[q]);
+    }
+#pragma unroll
+    for (int q = 0; q < kSelBatch; q++) {
+      const bool ok = tt[q] >= 0 && sel.test(tt[q], pl[q]);
+      const unsigned long long m = __ballot(ok);
+      if (lane == 0 && m) { const int wi = (tid + (rd * kSelBatch + q) * kSelThreads) >> 5; s_pick[wi] = (unsigned)m; s_pick[wi + 1] = (unsigned)(m >> 32); }
+    }
+  }
+  __syncthreads();
+  DSLAM_SEL_STAMP(4);
+  // ---- ranks inside the tile; count out, counts of the tiles in front in ---------------------------------------------------
+  int picked;
+  {
+    const int c = tid < kTileEntries / 32 ? __popc(s_pick[tid]) : 0;
+    const int pre = block_excl_scan<kWaves>(c, red, picked);
+    if (tid < kTileEntries / 32) s_pref[tid] = pre;
+  }
+  if (tid == 0) publish1(ch.agg, b, ch.epoch, picked);
+  __syncthreads();   // (s_pref)
+  DSLAM_SEL_STAMP(5);
+  // what an emit can work out without its rank is worked out while the counts travel
+  typename Sel::Staged st0[kSelBatch];
+  int rk0[kSelBatch];
+#pragma unroll
+  for (int q = 0; q < kSelBatch; q++) {
+    const int j = tid + q * kSelThreads;
+    rk0[q] = 0;
+    if ((pass0 >> q) & 1u) {
+      rk0[q] = s_pref[j >> 5] + __popc(s_pick[j >> 5] & ((1u << (j & 31)) - 1u));
+      st0[q] = sel.stage(tt0[q], pl0[q]);
+    }
+  }
+  int before;
+  if (!lookback1<kSelThreads>(ch.agg, b, ch.epoch, red, before) && tid == 0 && error_flags) atomicOr(error_flags, 2);
+  DSLAM_SEL_STAMP(6);
+  // ---- emit -----------------------------------------------------------------------------------------------------------------
+  int sum = 0;
+#pragma unroll
+  for (int q = 0; q < kSelBatch; q++) {
+    if (!((pass0 >> q) & 1u)) continue;
+    const int r = before + rk0[q];
+    if (r < capacity && out) out[r] = tt0[q];
+    sum += sel.emit(tt0[q], r, r < capacity, st0[q]);
+  }
+  for (int rd = 1; rd < kRounds; rd++) {
+    if (rd * kSelThreads * kSelBatch >= tot) break;
+#pragma unroll
+    for (int q = 0; q < kSelBatch; q++) {
+      const int j = tid + (rd * kSelBatch + q) * kSelThreads;
+      if (j >= tot || !((s_pick[j >> 5] >> (j & 31)) & 1u)) continue;
+      const int t = t0 + (int)s_list[j];
+      const int r = before + s_pref[j >> 5] + __popc(s_pick[j >> 5] & ((1u << (j & 31)) - 1u));
+      if (r < capacity && out) out[r] = t;
+      sum += sel.emit(t, r, r < capacity, sel.stage(t, sel.load(t)));
+    }
+  }
+  if (tile_sum_out && tot != 0) {
+    for (int d = 32; d > 0; d >>= 1) sum += __shfl_xor(sum, d, 64);
+    __syncthreads();
+    if (lane == 0) red[tid >> 6] = sum;
+    __syncthreads();
+    if (tid == 0) {
+      int v = 0;
+      for (int w = 0; w < kWaves; w++) v += red[w];
+      tile_sum_out[b] = v;
+    }
+  }
+  DSLAM_SEL_STAMP(7);
+  sel.prologue();   // (the independent job: stores nobody in this launch waits for, so behind everything that is waited for)
+  if (last) {
+    __syncthreads();   // (every emit of this tile is behind us)
+    if (tid == 0) {
+      if (total_out) *total_out = (before + picked) < capacity ? (before + picked) : capacity;
+      sel.finish(before + picked);
+    }
+  }
+#undef DSLAM_SEL_STAMP
+}
+
+// out[0 .. min(total, capacity)) = the selected entries, ascending; *total_out = min(total, capacity).
+// error_flags: bit 1 is set if a tile count never arrived (bounded spin; dslam_get_stats reports it)
+template <class Sel>
+inline void launch_bits_select(dslam_engine *e, const unsigned *src_bits, int n_entries, const Sel &sel, int *out, int capacity,
+                               int *total_out, int *error_flags, int *tile_sum_out = nullptr) {
+  const int n_words = bit_tiles(n_entries) * kBitTileWords;
+  int grid;
+  TileChain ch = next_chain(e, n_words / kSelTileWords, &grid);
+  // diagnostics: per-tile timeline of the 60th selection that has per-tile sums (GetImage's FindVisibleBlocks)
+  static const char *dbg_file = getenv("DSLAM_DBG_SELECT");
+  static int dbg_calls = 0;
+  unsigned long long *dbg_host = nullptr;
+  if (dbg_file && tile_sum_out && ++dbg_calls == 60 && hipHostMalloc((void **)&dbg_host, (size_t)grid * 64, hipHostMallocDefault) == hipSuccess) {
+    memset(dbg_host, 0, (size_t)grid * 64);
+    ch.dbg = dbg_host;
+  }
+  hipLaunchKernelGGL(k_bits_select<Sel>, dim3(grid), dim3(kSelThreads), 0, e->stream, src_bits, sel, out, capacity, total_out,
+                     tile_sum_out, ch, error_flags);
+  if (dbg_host) {
+    (void)hipStreamSynchronize(e->stream);
+    if (FILE *f = fopen(dbg_file, "wb")) { fwrite(dbg_host, 64, grid, f); fclose(f); }
+    (void)hipHostFree(dbg_host);
+  }
 }
 
 }  // namespace dslam

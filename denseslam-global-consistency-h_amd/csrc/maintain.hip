@@ -35,28 +35,32 @@ namespace dslam {
 //   SelDecayAged   block carries bit `bit` of ring `ring` (aged-list decay)
 //   SelSlidePop    same, and the bit is cleared; selected only if no queued list references the block any more
 //   SelDecaySweep  block not seen since `threshold` and not yet swept in this observation epoch (full-sweep decay)
+// (the payload of these three is the entry's block slot: the kernel requests it for all of a lane's candidates before the
+// first test follows it to the block's history words / age)
 struct SelDecayAged {
-  DSLAM_SEL_NO_LOAD
+  typedef int Payload;
+  DSLAM_SEL_NO_STAGE
   const HashEntry *hash;
   const unsigned long long *masks;
   int words, ring, bit;
-  __device__ bool test(int t, const NoPayload &) const {
-    const int ptr = hash[t].ptr;
+  __device__ int load(int t) const { return hash[t].ptr; }
+  __device__ bool test(int, const int &ptr) const {
     if (ptr < 0) return false;
     return (masks[((size_t)ptr * 2 + ring) * words + (bit >> 6)] >> (bit & 63)) & 1ull;
   }
   __device__ void prologue() const {}
-  __device__ int emit(int, int, bool, const NoPayload &) const { return 0; }
+  __device__ int emit(int, int, bool, const int &) const { return 0; }
   __device__ void finish(int) const {}
 };
 struct SelSlidePop {
-  DSLAM_SEL_NO_LOAD
+  typedef int Payload;
+  DSLAM_SEL_NO_STAGE
   const HashEntry *hash;
   unsigned long long *masks;
   int words, ring, bit;
   unsigned char *flags;   // (optional) byte flag per selected entry: the release pipeline's removal flags
-  __device__ bool test(int t, const NoPayload &) const {
-    const int ptr = hash[t].ptr;
+  __device__ int load(int t) const { return hash[t].ptr; }
+  __device__ bool test(int, const int &ptr) const {
     if (ptr < 0) return false;
     unsigned long long *m = masks + ((size_t)ptr * 2) * words;
     unsigned long long &w = m[(size_t)ring * words + (bit >> 6)];
@@ -68,23 +72,24 @@ struct SelSlidePop {
     return any == 0;
   }
   __device__ void prologue() const {}
-  __device__ int emit(int t, int, bool, const NoPayload &) const { if (flags) flags[t] = 1; return 0; }
+  __device__ int emit(int t, int, bool, const int &) const { if (flags) flags[t] = 1; return 0; }
   __device__ void finish(int) const {}
 };
 struct SelDecaySweep {
-  DSLAM_SEL_NO_LOAD
+  typedef int Payload;
+  DSLAM_SEL_NO_STAGE
   const HashEntry *hash;
   int *last_seen;
   int threshold;
-  __device__ bool test(int t, const NoPayload &) const {
-    const int ptr = hash[t].ptr;
+  __device__ int load(int t) const { return hash[t].ptr; }
+  __device__ bool test(int, const int &ptr) const {
     if (ptr < 0) return false;
     const int ls = last_seen[ptr];
     if (ls >= 0 && ls <= threshold) { last_seen[ptr] = -2 - ls; return true; }
     return false;
   }
   __device__ void prologue() const {}
-  __device__ int emit(int, int, bool, const NoPayload &) const { return 0; }
+  __device__ int emit(int, int, bool, const int &) const { return 0; }
   __device__ void finish(int) const {}
 };
 
@@ -508,14 +513,14 @@ int launch_decay(dslam_engine *e, dslam_scene *s, dslam_render_state *r, int max
     int k = s->decay_cursor[q] > s->ring_head[q] ? s->decay_cursor[q] : s->ring_head[q];
     for (; k <= newest - min_age; k++) {
       SelDecayAged sel{s->hash, s->masks, s->history_words, q, k % bits};
-      launch_bits_select(e, s->alloc_bits, N, sel, m.cand_list, s->p.num_local_blocks, &s->counters->swap_count);
+      launch_bits_select(e, s->alloc_bits, N, sel, m.cand_list, s->p.num_local_blocks, &s->counters->swap_count, &s->counters->error_flags);
       if ((rc = decay_candidates(e, s, r, m, max_weight))) return rc;
     }
     if (k > s->decay_cursor[q]) s->decay_cursor[q] = k;
   } else {
     const int threshold = (s->frame_counter - 1) - min_age;
     SelDecaySweep sel{s->hash, s->last_seen, threshold};
-    launch_bits_select(e, s->alloc_bits, N, sel, m.cand_list, s->p.num_local_blocks, &s->counters->swap_count);
+    launch_bits_select(e, s->alloc_bits, N, sel, m.cand_list, s->p.num_local_blocks, &s->counters->swap_count, &s->counters->error_flags);
     dbg_sync(e, "select decay sweep");
     if ((rc = decay_candidates(e, s, r, m, max_weight))) return rc;
   }
@@ -543,7 +548,11 @@ struct SelSwapFresh {
   DSLAM_SEL_NO_LOAD
   const HashEntry *hash;
   const unsigned char *swap_state;
-  __device__ bool test(int t, const NoPayload &) const { return swap_state[t] == 0 && hash[t].ptr >= 0; }
+  __device__ bool test(int t, const NoPayload &) const {
+    const unsigned char st = swap_state[t];
+    const int ptr = hash[t].ptr;   // (both requested before either is looked at)
+    return (st == 0) & (ptr >= 0);
+  }
   __device__ void prologue() const {}
   __device__ int emit(int, int, bool, const NoPayload &) const { return 0; }
   __device__ void finish(int) const {}
@@ -553,7 +562,12 @@ struct SelSwapOut {
   const HashEntry *hash;
   const unsigned char *swap_state;
   const unsigned char *vis_type;   // null: whatever the visibility
-  __device__ bool test(int t, const NoPayload &) const { return swap_state[t] == 2 && hash[t].ptr >= 0 && (vis_type == nullptr || vis_type[t] == 0); }
+  __device__ bool test(int t, const NoPayload &) const {
+    const unsigned char st = swap_state[t];
+    const int ptr = hash[t].ptr;
+    const unsigned char ty = vis_type ? vis_type[t] : (unsigned char)0;
+    return (st == 2) & (ptr >= 0) & (ty == 0);
+  }
   __device__ void prologue() const {}
   __device__ int emit(int, int, bool, const NoPayload &) const { return 0; }
   __device__ void finish(int) const {}
@@ -707,9 +721,9 @@ template <int MODE>
 static int swap_select(dslam_engine *e, dslam_scene *s, const unsigned char *vis_type, const MaintScratch &m) {
   const int N = s->n_entries;
   int *count = &s->counters->swap_count;
-  if (MODE == 0) launch_bits_select(e, s->swap1_bits, N, SelSwapPending{s->swap_state}, m.cand_list, kTransferBlocks, count);
-  else if (MODE == 1) launch_bits_select(e, s->alloc_bits, N, SelSwapFresh{s->hash, s->swap_state}, m.cand_list, kTransferBlocks, count);
-  else launch_bits_select(e, s->alloc_bits, N, SelSwapOut{s->hash, s->swap_state, vis_type}, m.cand_list, kTransferBlocks, count);
+  if (MODE == 0) launch_bits_select(e, s->swap1_bits, N, SelSwapPending{s->swap_state}, m.cand_list, kTransferBlocks, count, &s->counters->error_flags);
+  else if (MODE == 1) launch_bits_select(e, s->alloc_bits, N, SelSwapFresh{s->hash, s->swap_state}, m.cand_list, kTransferBlocks, count, &s->counters->error_flags);
+  else launch_bits_select(e, s->alloc_bits, N, SelSwapOut{s->hash, s->swap_state, vis_type}, m.cand_list, kTransferBlocks, count, &s->counters->error_flags);
   DSLAM_HIP(hipGetLastError());
   return DSLAM_OK;
 }
@@ -843,14 +857,14 @@ int launch_slide_pop(dslam_engine *e, dslam_scene *s, dslam_render_state *r, int
   if (!s->p.use_swapping) {
     // released: the list and the release pipeline's removal flags come out of one selection
     SelSlidePop sel{s->hash, s->masks, s->history_words, q, bit, m.rem_flags};
-    launch_bits_select(e, s->alloc_bits, N, sel, m.rem_list, s->p.num_local_blocks, &s->counters->remove_count);
+    launch_bits_select(e, s->alloc_bits, N, sel, m.rem_list, s->p.num_local_blocks, &s->counters->remove_count, &s->counters->error_flags);
     DSLAM_HIP(hipGetLastError());
     return release_listed(e, s, r, m, 1);
   }
 
   // scene with swapping: the blocks move to the host store, their entries stay (ptr = -1)
   SelSlidePop sel{s->hash, s->masks, s->history_words, q, bit, nullptr};
-  launch_bits_select(e, s->alloc_bits, N, sel, m.cand_list, s->p.num_local_blocks, &s->counters->swap_count);
+  launch_bits_select(e, s->alloc_bits, N, sel, m.cand_list, s->p.num_local_blocks, &s->counters->swap_count, &s->counters->error_flags);
   DSLAM_HIP(hipGetLastError());
   int *host_count = reinterpret_cast<int *>(e->pinned) + 48;
   DSLAM_HIP(hipMemcpyAsync(host_count, &s->counters->swap_count, sizeof(int), hipMemcpyDeviceToHost, e->stream));

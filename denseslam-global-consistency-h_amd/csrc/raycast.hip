@@ -118,7 +118,7 @@ struct SelFrustum {
   int npix;
   __device__ void prologue() const {
     if (PROJECT)   // (independent job) reset the range image to (FAR_AWAY, VERY_CLOSE)
-      for (int i = blockIdx.x * 256 + threadIdx.x; i < npix; i += gridDim.x * 256) range[i] = make_float2(kFarAway, kVeryClose);
+      for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < npix; i += gridDim.x * blockDim.x) range[i] = make_float2(kFarAway, kVeryClose);
   }
   typedef HashEntry Payload;
   __device__ HashEntry load(int t) const { return load_entry(hash, t); }
@@ -128,16 +128,21 @@ struct SelFrustum {
     check_block_vis<false>(vis, vis_enl, e.pos[0], e.pos[1], e.pos[2], fp.M, fp.fx, fp.fy, fp.cx, fp.cy, fp.voxel_size, fp.W, fp.H);
     return vis;
   }
-  __device__ int emit(int, int r, bool listed, const HashEntry &e) const {
-    if (!PROJECT || !listed) return 0;
+  struct Staged { int4 box; float2 zr; int req; };
+  __device__ Staged stage(int, const HashEntry &e) const {
+    Staged s;
+    s.req = 0;
+    if (!PROJECT) return s;
     ProjParams pp;
     pp.M = fp.M; pp.fx = fp.fx; pp.fy = fp.fy; pp.cx = fp.cx; pp.cy = fp.cy; pp.voxel_size = fp.voxel_size; pp.W = fp.W; pp.H = fp.H;
-    int4 box;
-    float2 zr;
-    const int req = project_single_block(e, pp, box, zr);
-    if (req) { boxes[r] = box; zr_out[r] = zr; }
-    req_out[r] = req;
-    return req;
+    s.req = project_single_block(e, pp, s.box, s.zr);
+    return s;
+  }
+  __device__ int emit(int, int r, bool listed, const Staged &s) const {
+    if (!PROJECT || !listed) return 0;
+    if (s.req) { boxes[r] = s.box; zr_out[r] = s.zr; }
+    req_out[r] = s.req;
+    return s.req;
   }
   __device__ void finish(int) const {}
 };
@@ -157,7 +162,7 @@ int launch_find_visible(dslam_engine *e, const dslam_scene *s, dslam_render_stat
   int rc = ensure_scratch(e, N, s->p.num_local_blocks);
   if (rc) return rc;
   SelFrustum<false> sel{s->hash, make_frustum_params(s, r, M, intr), nullptr, nullptr, nullptr, nullptr, 0};
-  launch_bits_select(e, s->alloc_bits, N, sel, r->visible_ids, r->n_local, &r->counters->no_visible);
+  launch_bits_select(e, s->alloc_bits, N, sel, r->visible_ids, r->n_local, &r->counters->no_visible, &s->counters->error_flags);
   DSLAM_HIP(hipGetLastError());
   return DSLAM_OK;
 }
@@ -328,8 +333,8 @@ int launch_find_visible_and_depths(dslam_engine *e, const dslam_scene *s, dslam_
   int rc = ensure_scratch(e, N, s->p.num_local_blocks);
   if (rc) return rc;
   SelFrustum<true> sel{s->hash, make_frustum_params(s, r, M, intr), r->proj_boxes, r->proj_z, r->proj_req, r->range, r->w * r->h};
-  launch_bits_select(e, s->alloc_bits, N, sel, r->visible_ids, r->n_local, &r->counters->no_visible, r->proj_wg_tiles);
-  return launch_fill_range(e, r, bit_tiles(N) * (kBitTileWords / kCompactTileWords));
+  launch_bits_select(e, s->alloc_bits, N, sel, r->visible_ids, r->n_local, &r->counters->no_visible, &s->counters->error_flags, r->proj_wg_tiles);
+  return launch_fill_range(e, r, select_tiles(N));
 }
 
 // ---------------------------------------------------------------------------------------------------------
