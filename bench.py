@@ -389,6 +389,7 @@ def main():
                 barrier()
                 res["stored_lists"] = tm
                 sums.append(checksum(sc, vox))
+                eng.reintegrate_batch(sc, vw, rstate, store, [], [], [], wl.intr)   # (set-up call: the scratch buffers)
                 tm = {}
                 barrier()
                 reint.reintegrate(eng, sc, vw, rstate, reint.Batch(frames_st, old_poses, new_poses, wl.intr), timers=tm, batched=True, **kw)

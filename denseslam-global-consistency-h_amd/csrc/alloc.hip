@@ -830,7 +830,7 @@ __global__ __launch_bounds__(256) void k_clean_bits_tail(unsigned *q1, unsigned 
 }
 
 int launch_allocate(dslam_engine *e, dslam_scene *s, const dslam_view *v, dslam_render_state *r, const float *M_d,
-                    const float *intr, int only_update_visible_list) {
+                    const float *intr, int only_update_visible_list, int *list_out, void *count_out) {
   const int W = v->w_d, H = v->h_d, N = s->n_entries;
   DSLAM_REQUIRE(r->n_entries == N, "render state was created for a different scene size");
   DSLAM_REQUIRE((N & 15) == 0, "num_buckets + num_excess must be a multiple of 16");
@@ -898,7 +898,9 @@ int launch_allocate(dslam_engine *e, dslam_scene *s, const dslam_view *v, dslam_
   sp.keys = e->order_keys; sp.alloc_type = e->alloc_type; sp.coords = e->block_coords;
   sp.alloc_list = s->alloc_list; sp.excess_list = s->excess_list;
   sp.vis_type = r->visible_type; sp.swap_state = s->swap_state; sp.swap1_bits = s->swap1_bits;
-  sp.cnt = s->counters; sp.rc = r->counters; sp.visible_ids = r->visible_ids; sp.capacity = r->n_local;
+  sp.cnt = s->counters; sp.capacity = r->n_local;
+  sp.rc = count_out ? reinterpret_cast<RenderCounters *>(count_out) : r->counters;
+  sp.visible_ids = list_out ? list_out : r->visible_ids;
   sp.q1 = mp.q1; sp.q2 = mp.q2; sp.mark = mp.mark; sp.retest = e->bits_retest;
   sp.oq1 = e->bits_q1[oth]; sp.oq2 = e->bits_q2[oth]; sp.omark = e->bits_mark[oth];
   sp.vis_bits = r->vis_bits; sp.alloc_bits = s->alloc_bits;

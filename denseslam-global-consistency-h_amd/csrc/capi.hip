@@ -387,9 +387,11 @@ int dslam_scene_destroy(dslam_scene *s) {
   free_dev(s->alloc_list); free_dev(s->excess_list); free_dev(s->last_seen); free_dev(s->masks); free_dev(s->counters);
   free_dev(s->swap_state); free_dev(s->slab_ptrs_dev); free_dev(s->alloc_bits); free_dev(s->swap1_bits);
   free_dev(s->dirty); free_dev(s->dirty_list); free_dev(s->dirty_counts);
-  free_dev(s->batch_born); free_dev(s->batch_opmask); free_dev(s->batch_slot_entry); free_dev(s->batch_list); free_dev(s->batch_order); free_dev(s->batch_counters);
+  free_dev(s->batch_born); free_dev(s->batch_opmask); free_dev(s->batch_slot_entry); free_dev(s->batch_marks); free_dev(s->batch_order); free_dev(s->batch_counters);
   if (s->batch_ops_dev) (void)hipFree(s->batch_ops_dev);
   if (s->batch_lists_dev) (void)hipFree(s->batch_lists_dev);
+  if (s->batch_staging) (void)hipHostFree(s->batch_staging);
+  if (s->batch_staging_ev) (void)hipEventDestroy(s->batch_staging_ev);
   for (uint4 *slab : s->slabs) (void)hipHostFree(slab);
   if (s->next_slot_host) (void)hipHostFree(s->next_slot_host);
   free_dev(s->slot_dev);
@@ -931,14 +933,18 @@ static int batch_scratch(dslam_engine *e, dslam_scene *s, dslam_frame_store *fs)
     DSLAM_HIP(hipMalloc(&s->batch_born, L * sizeof(int)));
     DSLAM_HIP(hipMalloc(&s->batch_opmask, L * sizeof(unsigned long long)));
     DSLAM_HIP(hipMalloc(&s->batch_slot_entry, L * sizeof(int)));
-    DSLAM_HIP(hipMalloc(&s->batch_list, L * sizeof(int)));
-    DSLAM_HIP(hipMalloc(&s->batch_order, L * sizeof(int)));
-    DSLAM_HIP(hipMalloc(&s->batch_counters, 4 * sizeof(int)));
+    DSLAM_HIP(hipMalloc(&s->batch_marks, L * 64));
+    DSLAM_HIP(hipMemsetAsync(s->batch_marks, 0, L * 64, e->stream));   // (every batch leaves them zero again)
+    DSLAM_HIP(hipMalloc(&s->batch_order, 8 * L * sizeof(int)));
+    DSLAM_HIP(hipMalloc(&s->batch_counters, 8 * sizeof(int)));
     DSLAM_HIP(hipMalloc(&s->batch_ops_dev, 2 * kBatchMax * sizeof(HostBatchOp)));
-    DSLAM_HIP(hipMalloc(&s->batch_lists_dev, 2 * kBatchMax * sizeof(HostBatchList)));
+    DSLAM_HIP(hipMalloc(&s->batch_lists_dev, 3 * kBatchMax * sizeof(HostBatchList)));
+    DSLAM_HIP(hipHostMalloc(&s->batch_staging, 2 * kBatchMax * sizeof(HostBatchOp) + 3 * kBatchMax * sizeof(HostBatchList), hipHostMallocDefault));
+    DSLAM_HIP(hipEventCreateWithFlags(&s->batch_staging_ev, hipEventDisableTiming));
   }
   if (!fs->batch_lists) {
     DSLAM_HIP(hipMalloc(&fs->batch_lists, fs->list_bytes * kBatchMax));
+    DSLAM_HIP(hipMemsetAsync(fs->batch_lists, 0, fs->list_bytes * kBatchMax, e->stream));   // (the count headers)
     fs->batch_list_ptr.resize(kBatchMax);
     for (int i = 0; i < kBatchMax; i++) fs->batch_list_ptr[i] = fs->batch_lists + fs->list_bytes * i;
   }
@@ -953,6 +959,7 @@ int dslam_reintegrate_batch(dslam_engine *e, dslam_scene *s, dslam_view *v, dsla
   DSLAM_REQUIRE(s->engine == e && v->engine == e && r->engine == e && fs->engine == e, "objects belong to a different engine");
   DSLAM_REQUIRE(fs->lists, "dslam_frame_store_enable_lists has not been called");
   DSLAM_REQUIRE(v->w_rgb == fs->w_rgb && v->h_rgb == fs->h_rgb && v->w_d == fs->w_d && v->h_d == fs->h_d, "view and frame store sizes differ");
+  DSLAM_REQUIRE(fs->list_cap >= r->n_local, "the store's lists are smaller than this render state's visible list");
   if (s->p.use_swapping || s->p.stop_integrating_at_max_w || v->w_rgb != v->w_d || v->h_rgb != v->h_d) {
     set_last_error("dslam_reintegrate_batch: scenes with host swapping or stopIntegratingAtMaxW and views with a separate colour "
                    "camera take the per-keyframe calls (dslam_deprocess_frame_stored + dslam_process_frame)");
@@ -963,9 +970,9 @@ int dslam_reintegrate_batch(dslam_engine *e, dslam_scene *s, dslam_view *v, dsla
     DSLAM_REQUIRE(fs->has_list[slots[k]], "no visible list was stored for a keyframe of the batch");
     for (int j = 0; j < k; j++) DSLAM_REQUIRE(slots[j] != slots[k], "a keyframe appears twice in the batch");
   }
-  if (n == 0) return DSLAM_OK;
-  int rc = batch_scratch(e, s, fs);
+  int rc = batch_scratch(e, s, fs);   // (n = 0: a set-up call -- the buffers exist before the first batch needs them)
   if (rc) return rc;
+  if (n == 0) return DSLAM_OK;
   e->view_reads++;  // (see dslam_engine::last_fence)
   s->version = next_map_version();  // the map changes: GetImage memos of this scene are stale
   r->memo_valid = false;
@@ -974,25 +981,36 @@ int dslam_reintegrate_batch(dslam_engine *e, dslam_scene *s, dslam_view *v, dsla
   for (int first = 0; first < n; first += kBatchMax) {
     const int K = (n - first) < kBatchMax ? (n - first) : kBatchMax;
     DSLAM_HIP(hipMemsetAsync(s->batch_born, 0, L * sizeof(int), e->stream));
-    DSLAM_HIP(hipMemsetAsync(s->batch_opmask, 0, L * sizeof(unsigned long long), e->stream));
-    DSLAM_HIP(hipMemsetAsync(s->batch_counters, 0, 4 * sizeof(int), e->stream));
-    std::vector<HostBatchOp> ops(2 * K);
-    std::vector<HostBatchList> lists(2 * K);
+    DSLAM_HIP(hipMemsetAsync(s->batch_counters, 0, 8 * sizeof(int), e->stream));
+    // (built in page-locked memory: the copies are queued behind the allocation passes and nothing waits for them here)
+    DSLAM_HIP(hipEventSynchronize(s->batch_staging_ev));   // the previous batch's copies have left the buffer
+    HostBatchOp *ops = reinterpret_cast<HostBatchOp *>(s->batch_staging);
+    HostBatchList *lists = reinterpret_cast<HostBatchList *>(ops + 2 * kBatchMax);   // [2K, 3K): the lists whose block positions are filled in at the end
     // phase 1: the allocation passes of the K re-fusions, in keyframe order (they read the table and the keyframes' depth
     // images, not the voxels); every pass' list goes to a scratch buffer, the blocks it allocates are stamped
     s->alloc_born = s->batch_born;
+    int n_pos_jobs = 0;
     for (int k = 0; k < K; k++) {
       const int slot = slots[first + k];
       const void *rgba = fs->rgba + fs->rgba_bytes * slot, *raw = fs->depth + fs->depth_bytes * slot;
       if ((rc = launch_view_convert(e, v, rgba, raw, affine_a, affine_b))) break;
       s->alloc_born_stamp = k + 1;
-      if ((rc = launch_allocate(e, s, v, r, new_M + 16 * (size_t)(first + k), intr, 0))) break;
+      // the pass writes its list straight into the scratch list of keyframe k; the last one into the render state's own
+      // (what the loop of per-keyframe calls leaves there), from where it is copied
+      unsigned char *nb = fs->batch_list_ptr[k];
+      const bool last_pass = first + k == n - 1;
+      if ((rc = launch_allocate(e, s, v, r, new_M + 16 * (size_t)(first + k), intr, 0, last_pass ? nullptr : reinterpret_cast<int *>(nb + ids_off),
+                                last_pass ? nullptr : nb)))
+        break;
       int bit = 0, frame = 0;
       if ((rc = prepare_push_visible_list(e, s, 1, &bit, &frame))) break;   // (ProcessFrame(isDefusion) queues on ring 1)
-      unsigned char *nb = fs->batch_list_ptr[k];
-      if ((rc = launch_store_visible_list(e, s, r, nb, reinterpret_cast<int *>(nb + ids_off), reinterpret_cast<short4 *>(nb + pos_off),
-                                          fs->list_cap)))
-        break;
+      if (last_pass) {
+        if ((rc = launch_store_visible_list(e, s, r, nb, reinterpret_cast<int *>(nb + ids_off), reinterpret_cast<short4 *>(nb + pos_off),
+                                            fs->list_cap)))
+          break;
+      } else {
+        lists[2 * K + n_pos_jobs++] = {nb, nb + ids_off, nb + pos_off};
+      }
       const unsigned char *ob = list_slot(fs, slot);
       HostBatchOp &d = ops[2 * k], &f = ops[2 * k + 1];
       memcpy(d.M, old_M + 16 * (size_t)(first + k), 64);
@@ -1005,15 +1023,16 @@ int dslam_reintegrate_batch(dslam_engine *e, dslam_scene *s, dslam_view *v, dsla
     s->alloc_born = nullptr;
     if (rc) return rc;
     // phase 2: which operations touch which block, then every touched block once
-    DSLAM_HIP(hipMemcpyAsync(s->batch_ops_dev, ops.data(), ops.size() * sizeof(HostBatchOp), hipMemcpyHostToDevice, e->stream));
-    DSLAM_HIP(hipMemcpyAsync(s->batch_lists_dev, lists.data(), lists.size() * sizeof(HostBatchList), hipMemcpyHostToDevice, e->stream));
-    DSLAM_HIP(hipStreamSynchronize(e->stream));   // (the sources are vectors of this scope)
-    if ((rc = launch_batch_ops(e, s->batch_lists_dev, 2 * K, s, s->batch_born, s->batch_opmask, s->batch_slot_entry, s->batch_list,
-                               s->batch_counters, s->batch_order)))
+    DSLAM_HIP(hipMemcpyAsync(s->batch_ops_dev, ops, 2 * (size_t)K * sizeof(HostBatchOp), hipMemcpyHostToDevice, e->stream));
+    DSLAM_HIP(hipMemcpyAsync(s->batch_lists_dev, lists, 3 * (size_t)K * sizeof(HostBatchList), hipMemcpyHostToDevice, e->stream));
+    DSLAM_HIP(hipEventRecord(s->batch_staging_ev, e->stream));
+    if ((rc = launch_batch_ops(e, s->batch_lists_dev, 2 * K, s, s->batch_born, s->batch_marks, s->batch_opmask, s->batch_slot_entry,
+                               s->batch_order, s->batch_counters)))
       return rc;
     if ((rc = launch_reintegrate_blocks(e, s, v->w_d, v->h_d, v->w_rgb, v->h_rgb, intr, affine_a, affine_b, s->batch_ops_dev,
-                                        s->batch_opmask, s->batch_slot_entry, s->batch_order, s->batch_counters, s->batch_counters + 1, 1, 2 * K)))
+                                        s->batch_opmask, s->batch_slot_entry, s->batch_order, s->batch_counters, 1, 2 * K)))
       return rc;
+    if ((rc = launch_store_list_positions(e, s, reinterpret_cast<const HostBatchList *>(s->batch_lists_dev) + 2 * K, n_pos_jobs))) return rc;
     // the lists of the re-fusions become the keyframes' stored lists: the buffers trade places
     for (int k = 0; k < K; k++) std::swap(fs->list_ptr[slots[first + k]], fs->batch_list_ptr[k]);
   }

@@ -163,8 +163,11 @@ struct dslam_scene {
   // blocks it commits while a batch is being planned
   int *batch_born = nullptr;
   unsigned long long *batch_opmask = nullptr;
-  int *batch_slot_entry = nullptr, *batch_list = nullptr, *batch_order = nullptr, *batch_counters = nullptr;
+  int *batch_slot_entry = nullptr, *batch_order = nullptr, *batch_counters = nullptr;   // (batch_order: 8 class lists)
+  unsigned char *batch_marks = nullptr;   // [num_local_blocks][64]: operation k of the batch touches the block (zero between batches)
   void *batch_ops_dev = nullptr, *batch_lists_dev = nullptr;
+  void *batch_staging = nullptr;          // page-locked: the operations and list references of a batch on their way to the device
+  hipEvent_t batch_staging_ev = nullptr;  // ... the copies out of it have been made
   int *alloc_born = nullptr;
   int alloc_born_stamp = 0;
   int dirty_shards = 0, dirty_chunk = 0;  // the layout of the last dslam_shard_dirty_plan
@@ -282,8 +285,10 @@ int launch_dataset_depth(dslam_engine *e, short *depth_dev, int n, int format, f
 int launch_depth_to_int16(dslam_engine *e, const float *depth_dev, short *out_dev, int n, int scale);
 int launch_depth_post(dslam_engine *e, short *curr_dev, const unsigned short *prev_dev, int cols, int rows,
                       const float *Tpc, const float *intr, float threshold, float area, int *count_dev);
+// list_out / count_out: write the pass' visible list there instead of into the render state's own list (whose bitmap and
+// types follow the pass either way; the re-integration batch keeps the lists of all its passes)
 int launch_allocate(dslam_engine *e, dslam_scene *s, const dslam_view *v, dslam_render_state *r, const float *M_d,
-                    const float *intr, int only_update_visible_list);
+                    const float *intr, int only_update_visible_list, int *list_out = nullptr, void *count_out = nullptr);
 // push_ring >= 0: also queue the frame's visible list on that ring (fused into the integrate kernel)
 int launch_integrate(dslam_engine *e, dslam_scene *s, const dslam_view *v, const dslam_render_state *r,
                      const float *M_d, const float *intr_d, const float *M_rgb, const float *intr_rgb,
@@ -294,11 +299,12 @@ int launch_integrate_list(dslam_engine *e, dslam_scene *s, const dslam_view *v, 
                           const float *intr_rgb, bool deintegrate);
 int launch_store_visible_list(dslam_engine *e, const dslam_scene *s, const dslam_render_state *r, void *header, int *ids,
                               short4 *pos, int capacity);
-int launch_batch_ops(dslam_engine *e, const void *lists_dev, int n_ops, const dslam_scene *s, const int *born,
-                     unsigned long long *opmask, int *slot_entry, int *dirty_list, int *dirty_count, int *ordered_list);
+int launch_store_list_positions(dslam_engine *e, const dslam_scene *s, const void *jobs_dev, int n_jobs);
+int launch_batch_ops(dslam_engine *e, const void *lists_dev, int n_ops, const dslam_scene *s, const int *born, unsigned char *marks,
+                     unsigned long long *opmask, int *slot_entry, int *cls_list, int *cls_count);
 int launch_reintegrate_blocks(dslam_engine *e, dslam_scene *s, int w_d, int h_d, int w_rgb, int h_rgb, const float *intr,
                               float a, float b, const void *ops_dev, const unsigned long long *opmask, const int *slot_entry,
-                              const int *dirty_list, const int *dirty_count, int *cursor, int push_ring, int n_ops);
+                              const int *cls_list, const int *cls_count, int push_ring, int n_ops);
 int ensure_view_depth(dslam_engine *e, const dslam_view *v);
 int launch_selftest_division(dslam_engine *e, long long samples, unsigned long long *mismatches_dev);
 int prepare_push_visible_list(dslam_engine *e, dslam_scene *s, int q, int *bit_out, int *frame_out);

@@ -974,9 +974,9 @@ struct BatchParams {
   const BatchOp *ops;
   const unsigned long long *opmask;
   const int *slot_entry;  // per slot: a hash entry that holds it (its block position)
-  const int *dirty_list;  // slots with a non-zero opmask (any order)
-  const int *dirty_count;
-  int *cursor;
+  const int *cls_list;    // [kBatchClasses][n_local]: the slots with operations, by class of their operation count
+  const int *cls_count;   // [kBatchClasses]
+  int n_local;
   float a, b;             // depth = raw * a + b
   int raw_bytes;
   int n_ops;
@@ -1107,6 +1107,12 @@ __global__ __launch_bounds__(kBatchWgWaves * 64) void k_reintegrate_blocks(Batch
   __shared__ float inv_tab[kInvTab];
   __shared__ BatchColQueue col_q[kBatchWgWaves];
   __shared__ BatchOp s_ops[64];   // the batch's operations: read per operation from LDS, not with a ~1 us scalar load each
+  __shared__ int s_cum[9];        // blocks in the classes in front of class c (k_batch_assemble's lists)
+  if (threadIdx.x == 0) {
+    int run = 0;
+    for (int c = 0; c < 8; c++) { s_cum[c] = run; run += bp.cls_count[c]; }
+    s_cum[8] = run;
+  }
   for (int i = threadIdx.x; i < kInvTab; i += kBatchWgWaves * 64) inv_tab[i] = recip_table_entry(i);
   for (int i = threadIdx.x; i < bp.n_ops * (int)(sizeof(BatchOp) / 4); i += kBatchWgWaves * 64)
     reinterpret_cast<unsigned *>(s_ops)[i] = reinterpret_cast<const unsigned *>(bp.ops)[i];
@@ -1114,11 +1120,15 @@ __global__ __launch_bounds__(kBatchWgWaves * 64) void k_reintegrate_blocks(Batch
   const IntegrateParams &p0 = bp.ip;
   const int lane = threadIdx.x & 63;
   BatchColQueue &Q = col_q[threadIdx.x >> 6];
-  const int n = bp.dirty_count[0] * 2;   // units of work: half blocks
+  const int n = __builtin_amdgcn_readfirstlane(s_cum[8]) * 2;   // units of work: half blocks
   const int vx0 = (lane & 3) * 2, vy = (lane >> 2) & 7, vz0 = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane((int)((blockIdx.x * (kBatchWgWaves * 64) + threadIdx.x) >> 6));
   for (int i = wave; i < n; i += kBatchGrid * kBatchWgWaves) {
-    const int ptr = __builtin_amdgcn_readfirstlane(bp.dirty_list[i >> 1]);
+    const int bi = i >> 1;
+    int cls = 0;
+#pragma unroll
+    for (int c = 1; c < 8; c++) cls += bi >= s_cum[c] ? 1 : 0;
+    const int ptr = __builtin_amdgcn_readfirstlane(bp.cls_list[(size_t)cls * bp.n_local + (bi - s_cum[cls])]);
     const int half = i & 1;
     const unsigned long long mask = bp.opmask[ptr];
     // (before the shard test, as in k_integrate: every rank of a sharded batch ends up with the same marks and the same
@@ -1192,9 +1202,8 @@ struct BatchListRef {
   const int *ids;
   const short4 *pos;             // stored lists: the block each entry held at fusion time; null: a fresh list
 };
-__global__ __launch_bounds__(256) void k_batch_ops(const BatchListRef *__restrict__ lists, const HashEntry *__restrict__ hash,
-                                                   const int *__restrict__ born, unsigned long long *opmask, int *slot_entry,
-                                                   int *dirty_list, int *dirty_count) {
+__global__ __launch_bounds__(256) void k_batch_mark(const BatchListRef *__restrict__ lists, const HashEntry *__restrict__ hash,
+                                                    const int *__restrict__ born, unsigned char *marks, int *slot_entry) {
   const int op = blockIdx.y, k = op >> 1;
   const BatchListRef L = lists[op];
   const int n = L.count->no_visible;
@@ -1204,50 +1213,93 @@ __global__ __launch_bounds__(256) void k_batch_ops(const BatchListRef *__restric
     if (e.ptr < 0) continue;
     if (L.pos) {
       const short4 ep = L.pos[i];
+      const int b = born[e.ptr];   // (requested with the position)
       if (ep.x != e.pos[0] || ep.y != e.pos[1] || ep.z != e.pos[2]) continue;
-      if (born[e.ptr] > k) continue;   // allocated by re-fusion k or a later one: did not exist when keyframe k was de-integrated
+      if (b > k) continue;   // allocated by re-fusion k or a later one: did not exist when keyframe k was de-integrated
     }
-    const unsigned long long old = atomicOr(&opmask[e.ptr], 1ull << op);
-    if (old == 0) {   // first operation on this block: it joins the batch's block list
-      slot_entry[e.ptr] = t;
-      dirty_list[atomicAdd(dirty_count, 1)] = e.ptr;
-    }
+    // One byte per (block, operation), 64 of them next to each other: plain stores.  (A 64-bit mask per block built with
+    // atomicOr -- ~0.5 M device-scope atomics per batch, one per list entry -- took 76 us; these stores and the pass that
+    // gathers them take ~20.)
+    marks[(size_t)e.ptr * 64 + op] = 1;
+    slot_entry[e.ptr] = t;   // (whoever lists the block names the entry that holds it)
   }
 }
 
-// The blocks with the most operations first: a wave fetches its next block from a counter, so the launch ends with whatever
-// was fetched last -- a block with 60 operations must not be that one.  Counting sort by popcount (65 bins), one workgroup.
-__global__ __launch_bounds__(1024) void k_batch_order(const int *__restrict__ list, const int *__restrict__ count,
-                                                      const unsigned long long *__restrict__ opmask, int *__restrict__ out) {
-  __shared__ int s_bin[65];
-  const int n = count[0];
-  if (threadIdx.x < 65) s_bin[threadIdx.x] = 0;
+// The marks of every block slot gathered into its operation mask; the blocks with operations are listed by CLASS of their
+// operation count (kBatchClasses lists, most operations first): the block launch deals its units in that order, so that a
+// block with 60 operations is not what the launch ends with.  Four lanes per slot (16 marks each); the marks are cleared on
+// the way, the next batch finds them zero.
+constexpr int kBatchClasses = 8;
+constexpr int kAsmIter = 16;   // 16-byte pieces per thread: a workgroup gathers 1024 slots and updates each class counter ONCE
+__global__ __launch_bounds__(256) void k_batch_assemble(uint4 *marks16, int n_slots, unsigned long long *opmask, int *cls_list,
+                                                        int *cls_count) {
+  // (one counter update per workgroup and class: updates of one address from all over the device serialise at ~12 ns each --
+  // per wave and class they were 100 us of this launch)
+  __shared__ int s_cnt[kBatchClasses], s_base[kBatchClasses];
+  if (threadIdx.x < kBatchClasses) s_cnt[threadIdx.x] = 0;
   __syncthreads();
-  for (int i = threadIdx.x; i < n; i += 1024) atomicAdd(&s_bin[64 - __popcll(opmask[list[i]])], 1);
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    int run = 0;
-    for (int k = 0; k < 65; k++) { const int c = s_bin[k]; s_bin[k] = run; run += c; }
+  const int quarter = threadIdx.x & 3;
+  int cls[kAsmIter], pos[kAsmIter];
+#pragma unroll
+  for (int it0 = 0; it0 < kAsmIter; it0 += 4) {
+    uint4 m[4];
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      const int gid = (blockIdx.x * kAsmIter + it0 + q) * 256 + threadIdx.x;
+      m[q] = (gid >> 2) < n_slots ? marks16[gid] : make_uint4(0, 0, 0, 0);
+    }
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      const int gid = (blockIdx.x * kAsmIter + it0 + q) * 256 + threadIdx.x;
+      const int slot = gid >> 2;
+      unsigned m16 = 0;
+      if (m[q].x | m[q].y | m[q].z | m[q].w) {
+        const unsigned w[4] = {m[q].x, m[q].y, m[q].z, m[q].w};
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+#pragma unroll
+          for (int bt = 0; bt < 4; bt++) m16 |= ((w[j] >> (8 * bt)) & 0xffu) ? (1u << (j * 4 + bt)) : 0u;
+        marks16[gid] = make_uint4(0, 0, 0, 0);
+      }
+      // the four quarters of a slot sit in neighbouring lanes
+      unsigned lo = quarter < 2 ? (m16 << (16 * quarter)) : 0u, hi = quarter >= 2 ? (m16 << (16 * (quarter - 2))) : 0u;
+      lo |= __shfl_xor(lo, 1, 64); hi |= __shfl_xor(hi, 1, 64);
+      lo |= __shfl_xor(lo, 2, 64); hi |= __shfl_xor(hi, 2, 64);
+      const unsigned long long mask = ((unsigned long long)hi << 32) | lo;
+      cls[it0 + q] = -1; pos[it0 + q] = 0;
+      if (quarter == 0 && mask != 0ull) {
+        opmask[slot] = mask;
+        const int c = (64 - __popcll(mask)) >> 3;   // 0: 57..64 operations ... 7: 1..8
+        cls[it0 + q] = c;
+        pos[it0 + q] = atomicAdd(&s_cnt[c], 1);
+      }
+    }
   }
   __syncthreads();
-  for (int i = threadIdx.x; i < n; i += 1024) {
-    const int slot = list[i];
-    out[atomicAdd(&s_bin[64 - __popcll(opmask[slot])], 1)] = slot;
+  if (threadIdx.x < kBatchClasses) {
+    const int c = s_cnt[threadIdx.x];
+    s_base[threadIdx.x] = c ? atomicAdd(&cls_count[threadIdx.x], c) : 0;
   }
+  __syncthreads();
+#pragma unroll
+  for (int it = 0; it < kAsmIter; it++)
+    if (cls[it] >= 0) cls_list[(size_t)cls[it] * n_slots + s_base[cls[it]] + pos[it]] = ((blockIdx.x * kAsmIter + it) * 256 + threadIdx.x) >> 2;
 }
 
-int launch_batch_ops(dslam_engine *e, const void *lists_dev, int n_ops, const dslam_scene *s, const int *born,
-                     unsigned long long *opmask, int *slot_entry, int *dirty_list, int *dirty_count, int *ordered_list) {
-  hipLaunchKernelGGL(k_batch_ops, dim3(32, n_ops), dim3(256), 0, e->stream, reinterpret_cast<const BatchListRef *>(lists_dev), s->hash,
-                     born, opmask, slot_entry, dirty_list, dirty_count);
-  hipLaunchKernelGGL(k_batch_order, dim3(1), dim3(1024), 0, e->stream, dirty_list, dirty_count, opmask, ordered_list);
+int launch_batch_ops(dslam_engine *e, const void *lists_dev, int n_ops, const dslam_scene *s, const int *born, unsigned char *marks,
+                     unsigned long long *opmask, int *slot_entry, int *cls_list, int *cls_count) {
+  const int L = s->p.num_local_blocks;
+  hipLaunchKernelGGL(k_batch_mark, dim3(32, n_ops), dim3(256), 0, e->stream, reinterpret_cast<const BatchListRef *>(lists_dev), s->hash,
+                     born, marks, slot_entry);
+  hipLaunchKernelGGL(k_batch_assemble, dim3((L * 4 + 256 * kAsmIter - 1) / (256 * kAsmIter)), dim3(256), 0, e->stream, reinterpret_cast<uint4 *>(marks), L, opmask,
+                     cls_list, cls_count);
   DSLAM_HIP(hipGetLastError());
   return DSLAM_OK;
 }
 
 int launch_reintegrate_blocks(dslam_engine *e, dslam_scene *s, int w_d, int h_d, int w_rgb, int h_rgb, const float *intr,
                               float a, float b, const void *ops_dev, const unsigned long long *opmask, const int *slot_entry,
-                              const int *dirty_list, const int *dirty_count, int *cursor, int push_ring, int n_ops) {
+                              const int *cls_list, const int *cls_count, int push_ring, int n_ops) {
   BatchParams bp;
   IntegrateParams &ip = bp.ip;
   memset(&ip, 0, sizeof(ip));
@@ -1268,7 +1320,7 @@ int launch_reintegrate_blocks(dslam_engine *e, dslam_scene *s, int w_d, int h_d,
   ip.push_words = push_ring >= 0 ? s->history_words : 0;
   ip.push_ring = push_ring >= 0 ? push_ring : 0;
   bp.ops = reinterpret_cast<const BatchOp *>(ops_dev);
-  bp.opmask = opmask; bp.slot_entry = slot_entry; bp.dirty_list = dirty_list; bp.dirty_count = dirty_count; bp.cursor = cursor;
+  bp.opmask = opmask; bp.slot_entry = slot_entry; bp.cls_list = cls_list; bp.cls_count = cls_count; bp.n_local = s->p.num_local_blocks;
   bp.a = a; bp.b = b;
   bp.raw_bytes = (w_d * h_d * 2 + 3) & ~3;
   bp.n_ops = n_ops;
@@ -1291,6 +1343,24 @@ __global__ __launch_bounds__(256) void k_store_visible_list(const int *__restric
     out_ids[i] = t;
     out_pos[i] = make_short4(e.pos[0], e.pos[1], e.pos[2], 0);
   }
+}
+
+// the block positions of lists that were written without them (the lists of the re-integration batch's allocation passes:
+// an entry keeps its block from its allocation to the end of the batch, so one launch at the end serves all passes)
+__global__ __launch_bounds__(256) void k_store_list_positions(const BatchListRef *__restrict__ jobs, const HashEntry *__restrict__ hash) {
+  const BatchListRef L = jobs[blockIdx.y];
+  const int n = L.count->no_visible;
+  short4 *out = const_cast<short4 *>(L.pos);
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+    const HashEntry e = load_entry(hash, L.ids[i]);
+    out[i] = make_short4(e.pos[0], e.pos[1], e.pos[2], 0);
+  }
+}
+int launch_store_list_positions(dslam_engine *e, const dslam_scene *s, const void *jobs_dev, int n_jobs) {
+  if (n_jobs <= 0) return DSLAM_OK;
+  hipLaunchKernelGGL(k_store_list_positions, dim3(32, n_jobs), dim3(256), 0, e->stream, reinterpret_cast<const BatchListRef *>(jobs_dev), s->hash);
+  DSLAM_HIP(hipGetLastError());
+  return DSLAM_OK;
 }
 
 int launch_store_visible_list(dslam_engine *e, const dslam_scene *s, const dslam_render_state *r, void *header, int *ids,

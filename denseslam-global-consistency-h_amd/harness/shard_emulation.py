@@ -65,6 +65,8 @@ def main():
             for rank in range(world):
                 rs = build()
                 eng.track_dirty(scene, True)
+                if stored == "batch":
+                    eng.reintegrate_batch(scene, view, rs, store, [], [], [], wl.intr)   # (set-up call: the scratch buffers)
                 eng.synchronize()
                 t0 = time.perf_counter()
                 if world > 1:

@@ -279,7 +279,9 @@ int dslam_deprocess_frame_stored(dslam_engine *e, dslam_scene *s, const dslam_vi
  * keyframes' images and fusion-time visible lists must be in the store; poses are n x 16 floats (column-major world ->
  * camera), one camera (depth = colour).  Scenes with host swapping or stopIntegratingAtMaxW return DSLAM_ERR_UNSUPPORTED:
  * use the per-keyframe calls.  On a sharded scene (dslam_scene_set_shard) every rank runs the allocation passes and
- * updates its own blocks; the exchange is dslam_shard_dirty_plan / _pack / _unpack as for the per-keyframe calls. */
+ * updates its own blocks; the exchange is dslam_shard_dirty_plan / _pack / _unpack as for the per-keyframe calls.
+ * n = 0 changes nothing and allocates the call's scratch buffers (a second copy of 32 stored lists, per-block operation
+ * masks): a set-up call keeps those allocations out of the first batch. */
 int dslam_reintegrate_batch(dslam_engine *e, dslam_scene *s, dslam_view *v, dslam_render_state *r, dslam_frame_store *fs,
                             int n, const int32_t *slots, const float *old_M, const float *new_M, const float intr[4],
                             float affine_a, float affine_b);

@@ -176,6 +176,7 @@ def batch_scenario(api, pkg, synth, wl, params, maintenance, call, n_frames=12, 
             new.append(synth.world_to_camera(wl.pose(i) @ synth.pose_matrix(
                 synth.look_rotation(0.003 * (n + 1 + seed), -0.002 * (1 + seed)), [0.004 + 0.002 * seed, 0.001 * n, -0.003])))
         if call == "batch":
+            api.reintegrate_batch(scene, view, rs, store, [], [], [], wl.intr)   # (the set-up call: an empty batch changes nothing)
             api.reintegrate_batch(scene, view, rs, store, list(ids), [poses[i] for i in ids], new, wl.intr)
         else:
             for i, new_M in zip(ids, new):

@@ -71,20 +71,25 @@ def test_fence_that_was_never_recorded_has_passed(gpu):
     f.close()
 
 
-@pytest.mark.parametrize("pattern", ["fence_destroyed_while_lent", "view_read_after_the_fence", "one_fence_for_all"])
+@pytest.mark.parametrize("pattern", ["fence_destroyed_while_lent", "view_read_after_the_fence", "one_fence_for_all",
+                                     "bilateral_filter_behind_the_fence"])
 def test_callers_fence_as_consumed_mark(pkg, synth, gpu, pattern):
     """The pipelined upload takes a caller's fence recorded behind the last view-reading call as the landing buffer's
     "consumed" mark instead of recording an event of its own (dslam_engine::last_fence).  Call patterns around that:
     the fence is destroyed while a view still waits on its event; a call reads the view AFTER the fence was recorded
-    (the fence then says nothing about that read); one fence re-recorded every frame."""
+    (the fence then says nothing about that read); one fence re-recorded every frame; the update itself enqueues a kernel
+    that reads the landing buffer (the bilateral filter) and two updates follow each other with no other view-reading call
+    in between (round-2 ADVICE: that kernel must count as a read, or the fence recorded before it is taken as the buffer's
+    "consumed" mark and the next refill may land under the filter)."""
     wl = synth.s_tiny()
     p = util.small_params(pkg, wl)
     n_frames = 12
     frames = [wl.frame(i) for i in range(n_frames)]
     s0 = gpu.create_scene(p)
     rs0, v0 = gpu.create_render_state(s0, wl.W, wl.H), gpu.create_view(wl.W, wl.H)
+    bilateral = pattern == "bilateral_filter_behind_the_fence"
     for i, (rgba, mm, M) in enumerate(frames):
-        gpu.view_update(v0, rgba, mm, timestamp=float(i))
+        gpu.view_update(v0, rgba, mm, timestamp=float(i), bilateral=bilateral)
         gpu.process_frame(s0, v0, rs0, M, wl.intr)
     ref = util.snapshot(gpu, s0, rs0)
 
@@ -99,6 +104,14 @@ def test_callers_fence_as_consumed_mark(pkg, synth, gpu, pattern):
     gpu.set_async(True)
     try:
         for i, (rgba, mm, M) in enumerate(frames):
+            if bilateral:
+                # fence, then two filtered updates back to back (the first one is overwritten: frame i - 1 again), nothing
+                # else reading the view in between
+                gpu.fence_record(one)
+                gpu.view_update(v1, rgba_p[max(i - 1, 0)], mm_p[max(i - 1, 0)], timestamp=float(i), bilateral=True)
+                gpu.view_update(v1, rgba_p[i], mm_p[i], timestamp=float(i), bilateral=True)
+                gpu.process_frame(s1, v1, rs1, M, wl.intr)
+                continue
             gpu.view_update(v1, rgba_p[i], mm_p[i], timestamp=float(i))
             gpu.process_frame(s1, v1, rs1, M, wl.intr)
             if pattern == "fence_destroyed_while_lent":
@@ -129,3 +142,16 @@ def test_callers_fence_as_consumed_mark(pkg, synth, gpu, pattern):
     store.close()
     for a in (rgba_p, mm_p):
         gpu.host_free(a)
+
+
+def test_fence_outlives_its_engine(pkg):
+    """A fence closed after the engine it was created on (round-2 ADVICE: dslam_fence_destroy used to follow the fence's engine
+    pointer): the engine's destruction takes its outstanding fences along, closing the handle afterwards is a no-op."""
+    eng = pkg.open_engine(0)
+    f, g = eng.fence_create(), eng.fence_create()
+    eng.fence_record(f)
+    eng.synchronize()
+    assert eng.fence_query(f)
+    eng.close()
+    f.close()
+    g.close()

@@ -160,3 +160,35 @@ def test_stored_visible_list_deintegration_parity(pkg, synth, gpu, oracle, maint
     for stage in ("fused", "after_first_deintegration", "corrected"):
         scenarios.assert_same_full_state(g[stage], o[stage], f"{stage} (maintenance={maintenance})")
     assert g["rs_untouched"] and g["missing_list_refused"]
+
+
+def test_stored_list_deintegration_equals_the_reference_call_on_an_unchanged_map(pkg, synth, gpu):
+    """dslam_deprocess_frame_stored is not the reference's call sequence (the reference runs an allocation pass at the old pose
+    and de-integrates what that pass lists; InfiniTamDriver.h:215-220) -- parity unpinned, like everything on this path.
+    What ties it to the reference-shaped call: while the map has not changed since the keyframe was fused, the stored list IS
+    the list that allocation pass produces, so both calls must leave the same voxels (round-2 ADVICE)."""
+    wl = synth.s_tiny()
+    p = util.small_params(pkg, wl)
+    states = []
+    for stored in (False, True):
+        scene = gpu.create_scene(p)
+        rs, view = gpu.create_render_state(scene, wl.W, wl.H), gpu.create_view(wl.W, wl.H)
+        store = gpu.create_frame_store(wl.W, wl.H, 4)
+        gpu.frame_store_enable_lists(store, scene)
+        for i in range(4):
+            rgba, mm, M = wl.frame(i)
+            gpu.view_update(view, rgba, mm, timestamp=float(i))
+            gpu.frame_store_put_view(store, i, view)
+            gpu.process_frame(scene, view, rs, M, wl.intr)
+            gpu.frame_store_put_visible_list(store, i, scene, rs)
+        # the last keyframe, de-integrated at the pose it was fused with, right after its fusion
+        rgba, mm, M = wl.frame(3)
+        gpu.view_update_from_store(view, store, 3, timestamp=3.0)
+        if stored:
+            gpu.deprocess_frame_stored(scene, view, store, 3, M, wl.intr)
+        else:
+            gpu.deprocess_frame(scene, view, rs, M, wl.intr)
+        states.append((gpu.download_hash_table(scene), gpu.download_voxel_blocks(scene)))
+        assert gpu.stats(scene, rs)["no_visible_entries"] > 50
+    assert np.array_equal(states[0][0], states[1][0]), "hash table"
+    assert np.array_equal(states[0][1], states[1][1]), "voxels"
