@@ -431,6 +431,56 @@ __device__ void walk_requests(const SweepParams &p, int limit_word, int avail_vb
   f1s = v[2];
 }
 
+// A request's rank-independent half: replay the winning pixel's walk up to the winning step -- the block it asked for --
+// and leave allocType / blockCoords as upstream's pass does (and the order keys clean for the next pass).
+__device__ __forceinline__ short4 replay_request(const SweepParams &p, int t, bool is2) {
+  const unsigned kz = p.keys[t] - 1u;
+  p.keys[t] = 0;
+  const int pix = (int)(kz >> p.cap_shift), step = (int)(kz & ((1u << p.cap_shift) - 1u));
+  const int py = pix / p.W, px = pix - py * p.W;
+  Vec3 pt, dir;
+  ray_segment(p.depth[pix], px, py, p.invM, p.inv_fx, p.inv_fy, p.cx, p.cy, p.mu, p.one_over_block, pt, dir);
+  for (int st = 0; st < step; st++) { pt.x += dir.x; pt.y += dir.y; pt.z += dir.z; }
+  const short4 bc = make_short4((short)(int)floorf(pt.x), (short)(int)floorf(pt.y), (short)(int)floorf(pt.z), 1);
+  p.alloc_type[t] = is2 ? 2 : 1;
+  p.coords[t] = bc;
+  return bc;
+}
+
+// ... and the half that needs its ranks (k1, k2: type-1 / type-2 requests in front of it in hash-index order)
+template <bool SWAPPING>
+__device__ __forceinline__ void commit_request(const SweepParams &p, int tile_first, int rel, bool is2, int k1, int k2, short4 bc, int base_free,
+                                               int base_free_ex, int avail_vba, int avail_ex, unsigned *s_qv, unsigned *s_qf) {
+  const int t = tile_first + rel;
+  // voxel-block slots consumed by all earlier requests in hash-index order (closed form)
+  const int vr = k1 + (k2 < avail_ex ? k2 : avail_ex);
+  if (!is2) {
+    const bool ok = p.do_commit && vr < avail_vba;
+    if (ok) {
+      const int slot = p.alloc_list[base_free - vr];
+      store_entry(p.hash, t, bc.x, bc.y, bc.z, 0, slot);
+      bit_set(p.alloc_bits, t);
+      if (p.born) p.born[slot] = p.born_stamp;
+    }
+    // without the commit (onlyUpdateVisibleList) the request alone makes the entry "visible" this pass, like
+    // upstream; with it, only if it got a block
+    if (ok || !p.do_commit) {
+      p.vis_type[t] = (unsigned char)(p.gen | 1u);
+      atomicOr(&s_qv[rel >> 5], 1u << (rel & 31));
+    } else {
+      atomicOr(&s_qf[rel >> 5], 1u << (rel & 31));
+    }
+  } else if (p.do_commit && k2 < avail_ex && vr < avail_vba) {
+    const int ex_off = p.excess_list[base_free_ex - k2];
+    const int slot = p.alloc_list[base_free - vr];
+    p.hash[t].offset = ex_off + 1;
+    store_entry(p.hash, p.num_buckets + ex_off, bc.x, bc.y, bc.z, 0, slot);
+    bit_set(p.alloc_bits, p.num_buckets + ex_off);
+    if (p.born) p.born[slot] = p.born_stamp;
+    // (its type byte and its place in the visible list are the business of the tile that owns the new entry)
+  }
+}
+
 // One workgroup per tile of kSweepWords bitmap words, WPT consecutive words per thread.  The tile size is a trade: every
 // phase below is a round trip (or a chain of them) that all tiles go through side by side, so at the bench's 8 k visible
 // entries the launch takes as long as its slowest tile; the tile that ends the table holds the -- contiguous, mostly
@@ -532,6 +582,40 @@ __global__ __launch_bounds__(256) void k_alloc_sweep(SweepParams p) {
     int later2 = 0;
     if (has_excess)
       for (int w = (b + 1) * TW + threadIdx.x; w < p.n_words; w += 256) later2 += __popc(p.q2[w]);
+    // The rank-independent half of a request -- its key, the winning pixel's depth, the walk to the block it asked for --
+    // is worked out while the tile counts travel (when the tile has at most one request per lane: the usual case, a frame
+    // allocates a few hundred blocks): two of the request's three dependent round trips are then behind the look-back's.
+    const int req_tot = tot1 + tot2;
+    auto expand_requests = [&](int win) {
+      int k1 = r1, k2 = r2;   // ranks inside the tile
+#pragma unroll
+      for (int i = 0; i < WPT; i++) {
+        const unsigned a1 = q1[i], a2 = q2[i];
+        for (unsigned m = a1 | a2; m; m &= m - 1) {
+          const int bit = __ffs((int)m) - 1;
+          const bool is2 = (a2 >> bit) & 1u;
+          const int idx = k1 + k2 - win;
+          if (idx >= 0 && idx < kReqWindow)
+            s_req[idx] = make_uint2((unsigned)((lw0 + i) * 32 + bit) | (is2 ? 0x80000000u : 0u), (unsigned)k1 | ((unsigned)k2 << 16));
+          if (is2) k2++; else k1++;
+        }
+      }
+    };
+#pragma unroll
+    for (int i = 0; i < WPT; i++) { s_qv[lw0 + i] = 0; s_qf[lw0 + i] = 0; }
+    const bool staged = req_tot > 0 && req_tot <= 256;   // (uniform)
+    bool st_has = false;
+    uint2 st_rq = make_uint2(0, 0);
+    short4 st_bc = make_short4(0, 0, 0, 0);
+    if (staged) {
+      expand_requests(0);
+      __syncthreads();
+      if ((int)threadIdx.x < req_tot) {
+        st_has = true;
+        st_rq = s_req[threadIdx.x];
+        st_bc = replay_request(p, tile_first + (int)(st_rq.x & 0x7fffffffu), st_rq.x >> 31);
+      }
+    }
     STAMP(3);
     int pre[4];  // requests (type 1, type 2) and visible entries (retest | mark; new type-1 requests) in front of this tile
     if (!lookback2(p.agg_req, p.agg_vis, b, p.epoch, red, pre) && threadIdx.x == 0) atomicOr(&p.cnt->error_flags, 2);
@@ -561,72 +645,24 @@ __global__ __launch_bounds__(256) void k_alloc_sweep(SweepParams p) {
     // lane and round -- a request is a chain of dependent reads (key -> depth pixel -> free-list slot), and a lane that holds
     // two of them in its own words would walk it twice while the rest of the workgroup waits at the next barrier (per-tile
     // timeline: 4.6 + 1.8 us of a 16 us launch went there).
-#pragma unroll
-    for (int i = 0; i < WPT; i++) { s_qv[lw0 + i] = 0; s_qf[lw0 + i] = 0; }
-    const int req_tot = tot1 + tot2;
-    for (int win = 0; win < req_tot; win += kReqWindow) {
-      __syncthreads();   // (s_qv / s_qf zeroed; the previous window read)
-      {
-        int k1 = r1, k2 = r2;   // ranks inside the tile
-#pragma unroll
-        for (int i = 0; i < WPT; i++) {
-          const unsigned a1 = q1[i], a2 = q2[i];
-          for (unsigned m = a1 | a2; m; m &= m - 1) {
-            const int bit = __ffs((int)m) - 1;
-            const bool is2 = (a2 >> bit) & 1u;
-            const int idx = k1 + k2 - win;
-            if (idx >= 0 && idx < kReqWindow)
-              s_req[idx] = make_uint2((unsigned)((lw0 + i) * 32 + bit) | (is2 ? 0x80000000u : 0u), (unsigned)k1 | ((unsigned)k2 << 16));
-            if (is2) k2++; else k1++;
-          }
+    if (!staged) {
+      for (int win = 0; win < req_tot; win += kReqWindow) {
+        __syncthreads();   // (s_qv / s_qf zeroed; the previous window read)
+        expand_requests(win);
+        __syncthreads();
+        const int n_win = (req_tot - win) < kReqWindow ? (req_tot - win) : kReqWindow;
+        for (int j = threadIdx.x; j < n_win; j += 256) {
+          const uint2 rq = s_req[j];
+          const int rel = (int)(rq.x & 0x7fffffffu);
+          const bool is2 = rq.x >> 31;
+          const short4 bc = replay_request(p, tile_first + rel, is2);
+          commit_request<SWAPPING>(p, tile_first, rel, is2, pre[0] + (int)(rq.y & 0xffffu), pre[1] + (int)(rq.y >> 16), bc, base_free, base_free_ex,
+                                   avail_vba, avail_ex, s_qv, s_qf);
         }
       }
-      __syncthreads();
-      const int n_win = (req_tot - win) < kReqWindow ? (req_tot - win) : kReqWindow;
-      for (int j = threadIdx.x; j < n_win; j += 256) {
-        const uint2 rq = s_req[j];
-        const int rel = (int)(rq.x & 0x7fffffffu), t = tile_first + rel;
-        const bool is2 = rq.x >> 31;
-        const int k1 = pre[0] + (int)(rq.y & 0xffffu), k2 = pre[1] + (int)(rq.y >> 16);
-        // replay the winning pixel's walk up to the winning step: the block it asked for
-        const unsigned kz = p.keys[t] - 1u;
-        p.keys[t] = 0;   // leave the keys clean for the next pass
-        const int pix = (int)(kz >> p.cap_shift), step = (int)(kz & ((1u << p.cap_shift) - 1u));
-        const int py = pix / p.W, px = pix - py * p.W;
-        Vec3 pt, dir;
-        ray_segment(p.depth[pix], px, py, p.invM, p.inv_fx, p.inv_fy, p.cx, p.cy, p.mu, p.one_over_block, pt, dir);
-        for (int st = 0; st < step; st++) { pt.x += dir.x; pt.y += dir.y; pt.z += dir.z; }
-        const short4 bc = make_short4((short)(int)floorf(pt.x), (short)(int)floorf(pt.y), (short)(int)floorf(pt.z), 1);
-        p.alloc_type[t] = is2 ? 2 : 1;
-        p.coords[t] = bc;
-        // voxel-block slots consumed by all earlier requests in hash-index order (closed form)
-        const int vr = k1 + (k2 < avail_ex ? k2 : avail_ex);
-        if (!is2) {
-          const bool ok = p.do_commit && vr < avail_vba;
-          if (ok) {
-            const int slot = p.alloc_list[base_free - vr];
-            store_entry(p.hash, t, bc.x, bc.y, bc.z, 0, slot);
-            bit_set(p.alloc_bits, t);
-            if (p.born) p.born[slot] = p.born_stamp;
-          }
-          // without the commit (onlyUpdateVisibleList) the request alone makes the entry "visible" this pass, like
-          // upstream; with it, only if it got a block
-          if (ok || !p.do_commit) {
-            p.vis_type[t] = (unsigned char)(p.gen | 1u);
-            atomicOr(&s_qv[rel >> 5], 1u << (rel & 31));
-          } else {
-            atomicOr(&s_qf[rel >> 5], 1u << (rel & 31));
-          }
-        } else if (p.do_commit && k2 < avail_ex && vr < avail_vba) {
-          const int ex_off = p.excess_list[base_free_ex - k2];
-          const int slot = p.alloc_list[base_free - vr];
-          p.hash[t].offset = ex_off + 1;
-          store_entry(p.hash, p.num_buckets + ex_off, bc.x, bc.y, bc.z, 0, slot);
-          bit_set(p.alloc_bits, p.num_buckets + ex_off);
-          if (p.born) p.born[slot] = p.born_stamp;
-          // (its type byte and its place in the visible list are the business of the tile that owns the new entry)
-        }
-      }
+    } else if (st_has) {
+      commit_request<SWAPPING>(p, tile_first, (int)(st_rq.x & 0x7fffffffu), st_rq.x >> 31, pre[0] + (int)(st_rq.y & 0xffffu), pre[1] + (int)(st_rq.y >> 16),
+                               st_bc, base_free, base_free_ex, avail_vba, avail_ex, s_qv, s_qf);
     }
     __syncthreads();
     unsigned qvis[WPT], qfail[WPT];   // type-1 requests that make their entry visible in this pass / that found no block

@@ -203,7 +203,11 @@ __global__ __launch_bounds__(256) void k_project_blocks(const int *__restrict__ 
 // slice of the visible list.  Overlapping blocks are accumulated with LDS atomics (ds_min/ds_max), then every touched cell
 // is flushed with ONE global atomic pair -- instead of one contended global atomic pair per (block, cell).
 constexpr int kRangeTile = 16;
-constexpr int kRangeSlices = 32;  // workgroups per tile; each strides over the visible list
+constexpr int kRangeSlices = 32;
+#ifndef DSLAM_RANGE_BIG
+#define DSLAM_RANGE_BIG 32
+#endif
+constexpr int kRangeBigBox = DSLAM_RANGE_BIG;   // cells of a tile above which a box is taken by the whole workgroup  // workgroups per tile; each strides over the visible list
 
 __global__ __launch_bounds__(256) void k_fill_range_tiles(const RenderCounters *rc, const int4 *__restrict__ boxes,
                                                           const float2 *__restrict__ zr, const int *__restrict__ req,
@@ -220,7 +224,7 @@ __global__ __launch_bounds__(256) void k_fill_range_tiles(const RenderCounters *
   int4 b0 = make_int4(0, 0, 0, 0);
   float2 z0 = make_float2(0.0f, 0.0f);
   if (i0 < capacity) { r0 = req[i0]; b0 = boxes[i0]; z0 = zr[i0]; }
-  const int n = rc->no_visible;
+  const int n = __builtin_amdgcn_readfirstlane(rc->no_visible);   // (uniform, and the compiler should know: a loop with barriers hangs off it)
   // The render-tile budget (MAX_RENDERING_BLOCKS) is applied in visible-list order; only when the total (the sum of
   // the projection pass' per-workgroup counts) exceeds it does the order matter.  That case (> 262144 tiles) is
   // replayed below, by every workgroup for itself.
@@ -245,9 +249,53 @@ __global__ __launch_bounds__(256) void k_fill_range_tiles(const RenderCounters *
   };
   auto splat = [&](int i) { splat_box(boxes[i], zr[i]); };
   if (!over_budget) {
-    if (i0 < n && r0 != 0) splat_box(b0, z0);
-    for (int i = i0 + gridDim.y * 256; i < n; i += gridDim.y * 256)
-      if (req[i] != 0) splat(i);
+    // A box that covers many cells of this tile (a block next to the camera: up to all 256) is not walked by the lane that
+    // holds it -- 2 x 256 LDS atomics one after the other while the lanes with distant blocks are done after a handful --
+    // but queued, and taken by the whole workgroup: thread c looks at cell c of the tile, in registers.
+    __shared__ int4 s_big[256];
+    __shared__ int2 s_bigz[256];
+    __shared__ int s_nbig;
+    int mn_c = far_i, mx_c = close_i;
+    const int cx = tx0 + (threadIdx.x % kRangeTile), cy = ty0 + (threadIdx.x / kRangeTile);
+    auto take = [&](bool have, const int4 &b, const float2 &z) {
+      if (threadIdx.x == 0) s_nbig = 0;
+      __syncthreads();
+      if (have) {
+        const int x0 = b.x > tx0 ? b.x : tx0, x1 = b.z < tx0 + kRangeTile - 1 ? b.z : tx0 + kRangeTile - 1;
+        const int y0 = b.y > ty0 ? b.y : ty0, y1 = b.w < ty0 + kRangeTile - 1 ? b.w : ty0 + kRangeTile - 1;
+        if (x0 <= x1 && y0 <= y1) {
+          if ((x1 - x0 + 1) * (y1 - y0 + 1) > kRangeBigBox) {
+            const int k = atomicAdd(&s_nbig, 1);
+            s_big[k] = make_int4(x0, y0, x1, y1);
+            s_bigz[k] = make_int2(__float_as_int(z.x), __float_as_int(z.y));
+          } else {
+            splat_box(b, z);
+          }
+        }
+      }
+      __syncthreads();
+      const int nb = s_nbig;
+      for (int k = 0; k < nb; k++) {
+        const int4 bb = s_big[k];
+        const int2 zz = s_bigz[k];
+        if (cx >= bb.x && cx <= bb.z && cy >= bb.y && cy <= bb.w) {
+          mn_c = zz.x < mn_c ? zz.x : mn_c;
+          mx_c = zz.y > mx_c ? zz.y : mx_c;
+        }
+      }
+      __syncthreads();   // (the queue is refilled by the next round)
+    };
+    take(i0 < n && r0 != 0, b0, z0);
+    for (int ib = blockIdx.y * 256 + gridDim.y * 256; ib < n; ib += gridDim.y * 256) {   // (uniform trip count: barriers inside)
+      const int i = ib + threadIdx.x;
+      const bool have = i < n && req[i] != 0;
+      int4 b = make_int4(0, 0, -1, -1);
+      float2 z = make_float2(0.0f, 0.0f);
+      if (have) { b = boxes[i]; z = zr[i]; }
+      take(have, b, z);
+    }
+    if (mn_c != far_i) atomicMin(&s_min[threadIdx.x], mn_c);
+    if (mx_c != close_i) atomicMax(&s_max[threadIdx.x], mx_c);
   } else {
     // sequential rule of the reference's tile list: entry i is dropped when the tiles accepted so far plus its own
     // reach the budget (a dropped entry does not count).  Chunks of the request list are staged in LDS, lane 0
