@@ -172,6 +172,7 @@ struct MarkParams {
   Mat4 M;
   float fx, fy, voxel_size;
   int swapping;
+  unsigned long long *dbg;   // diagnostics (DSLAM_DBG_MARK=<file>): per workgroup 4 timestamps of its first wave (s_memtime)
 };
 
 // the +-mu segment of a pixel in block units: start point, step vector, number of steps (buildHashAllocAndVisibleTypePP)
@@ -246,8 +247,13 @@ __device__ __forceinline__ void retest_job(const MarkParams &p) {
   if (threadIdx.x < kRetestWords) p.retest[blockIdx.x * kRetestWords + threadIdx.x] = s_res[threadIdx.x];
 }
 
+// (diagnostics: [0] kernel entry, [1] exit, [2] depth pixel arrived, [3] walk over | wave_steps << 56.  The stamps are written
+// from the kernel itself, not from a wrapper around a body function: with the argument struct handed on by reference the
+// same code ran 23 us instead of 11.)
+#define MARK_STAMP(i, extra) do { if (p.dbg && threadIdx.x == 0) p.dbg[(size_t)blockIdx.x * 4 + (i)] = __builtin_amdgcn_s_memtime() | (extra); } while (0)
 __global__ __launch_bounds__(256) void k_mark(MarkParams p) {
-  if ((int)blockIdx.x < p.retest_wgs) { retest_job(p); return; }
+  MARK_STAMP(0, 0ull);
+  if ((int)blockIdx.x < p.retest_wgs) { retest_job(p); MARK_STAMP(1, 0ull); return; }
   const int idx = ((int)blockIdx.x - p.retest_wgs) * 256 + threadIdx.x;
   const int lane = threadIdx.x & 63;
   // every lane stays in the kernel (invalid pixels march zero steps): the order-key atomics below are aggregated
@@ -274,6 +280,7 @@ __global__ __launch_bounds__(256) void k_mark(MarkParams p) {
   }
   int wave_steps = no_steps;
   for (int o = 32; o > 0; o >>= 1) { const int v = __shfl_xor(wave_steps, o, 64); wave_steps = v > wave_steps ? v : wave_steps; }
+  MARK_STAMP(2, 0ull);
 
   // The bucket heads of the first kPre steps are requested together, before any of them is looked at: a pixel's walk is
   // 2-3 steps of one dependent 16-byte read each, and the positions of all of them are known up front (the same
@@ -349,7 +356,10 @@ __global__ __launch_bounds__(256) void k_mark(MarkParams p) {
       todo &= ~grp;
     }
   }
+  MARK_STAMP(3, (unsigned long long)wave_steps << 56);
+  MARK_STAMP(1, 0ull);
 }
+#undef MARK_STAMP
 
 struct SweepParams {
   HashEntry *hash;
@@ -925,8 +935,22 @@ int launch_allocate(dslam_engine *e, dslam_scene *s, const dslam_view *v, dslam_
   mp.fx = intr[0]; mp.fy = intr[1]; mp.voxel_size = s->p.voxel_size;
   mp.swapping = s->p.use_swapping ? 1 : 0;
   const int pix_blocks = (W * H + 255) / 256;
+  mp.dbg = nullptr;
+  static const char *dbg_mark_file = getenv("DSLAM_DBG_MARK");
+  static int dbg_mark_calls = 0;
+  unsigned long long *dbg_mark_host = nullptr;
+  if (dbg_mark_file && ++dbg_mark_calls == 60) {
+    DSLAM_HIP(hipHostMalloc((void **)&dbg_mark_host, (size_t)(mp.retest_wgs + pix_blocks) * 32, hipHostMallocDefault));
+    memset(dbg_mark_host, 0, (size_t)(mp.retest_wgs + pix_blocks) * 32);
+    mp.dbg = dbg_mark_host;
+  }
   hipLaunchKernelGGL(k_mark, dim3(mp.retest_wgs + pix_blocks), dim3(256), 0, e->stream, mp);
   dbg_sync(e, "k_mark");
+  if (dbg_mark_host) {
+    DSLAM_HIP(hipStreamSynchronize(e->stream));
+    if (FILE *f = fopen(dbg_mark_file, "wb")) { fwrite(dbg_mark_host, 32, mp.retest_wgs + pix_blocks, f); fclose(f); }
+    (void)hipHostFree(dbg_mark_host);
+  }
   v->depth_dirty = false;
 
   SweepParams sp;
