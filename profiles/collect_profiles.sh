@@ -17,7 +17,7 @@ rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $R/gpurun_out/f
 rocprofv3 --pmc SQ_INSTS_VALU SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_SALU --kernel-trace --output-format csv -d $R/gpurun_out/final_sq -- python3 $R/bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-stress --no-extra-rates --reint 0 --mode device > $R/gpurun_out/final_sq.log 2>&1; echo sq rc=$?
 cd $R
 # per-wave dump of the ray march, per-tile timeline of the allocation sweep, per-wave timeline of the fusion kernel (diagnostic instantiations)
-DSLAM_DBG_WAVETIME=gpurun_out/final_wavetime.bin DSLAM_DBG_SWEEP=gpurun_out/final_sweep.bin DSLAM_DBG_INTEGRATE=gpurun_out/final_integrate_waves.bin python bench.py $BENCH_FAST --mode device > /dev/null 2>&1; ls -la gpurun_out/final_wavetime.bin gpurun_out/final_sweep.bin gpurun_out/final_integrate_waves.bin
+DSLAM_DBG_WAVETIME=gpurun_out/final_wavetime.bin DSLAM_DBG_SWEEP=gpurun_out/final_sweep.bin DSLAM_DBG_INTEGRATE=gpurun_out/final_integrate_waves.bin DSLAM_DBG_SELECT=gpurun_out/final_select.bin DSLAM_DBG_MARK=gpurun_out/final_mark.bin python bench.py $BENCH_FAST --mode device > /dev/null 2>&1; ls -la gpurun_out/final_wavetime.bin gpurun_out/final_sweep.bin gpurun_out/final_integrate_waves.bin gpurun_out/final_select.bin gpurun_out/final_mark.bin
 python bench.py --mode sync --steps 100 --warmup 10 --no-cpu-baseline --no-stress --no-extra-rates --reint 0 > gpurun_out/final_bench_sync.json 2>/dev/null
 python denseslam-global-consistency-h_amd/harness/stress.py 64 > gpurun_out/final_stress.json; cat gpurun_out/final_stress.json
 python profiles/experiments/pipeline_breakdown.py 100 > gpurun_out/final_pipeline.json 2>/dev/null; cat gpurun_out/final_pipeline.json
@@ -28,5 +28,8 @@ python denseslam-global-consistency-h_amd/harness/maint_bench.py > gpurun_out/fi
 (cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/final_maint_stats -- python3 $R/denseslam-global-consistency-h_amd/harness/maint_bench.py > /dev/null 2> $R/gpurun_out/final_maint_stats.err); echo maint_stats rc=$?
 # per-kernel times of the three forms of the re-integration batch
 (cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/final_reint_stats -- python3 $R/bench.py --steps 100 --warmup 10 --no-cpu-baseline --no-stress --no-extra-rates --mode device > $R/gpurun_out/final_reint_stats.log 2>&1); echo reint_stats rc=$?
+# instruction / wave-time counters of the block-major batch launch (one pass of SQ counters; TCC counters are NOT mixed into it:
+# a pass with FETCH_SIZE + WRITE_SIZE + SQ_INSTS_VMEM_* went silent for 7 minutes on this pool)
+(cd /tmp && rocprofv3 --pmc SQ_INSTS_VALU SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_SALU --kernel-trace --output-format csv -d $R/gpurun_out/final_reint_sq -- python3 $R/bench.py --steps 100 --warmup 10 --no-cpu-baseline --no-stress --no-extra-rates --mode device > $R/gpurun_out/final_reint_sq.log 2>&1); echo reint_sq rc=$?
 python denseslam-global-consistency-h_amd/harness/memory_sensitivity.py 1500 > gpurun_out/final_memory_sensitivity.json 2> gpurun_out/final_memory_sensitivity.err; echo sensitivity rc=$?
 python denseslam-global-consistency-h_amd/harness/shard_emulation.py 120 32 > gpurun_out/final_shard_emulation.json 2>/dev/null; tail -c 300 gpurun_out/final_shard_emulation.json

@@ -102,7 +102,7 @@ def main():
         # where the waves' time goes (quad-cycle counters, MI355X_MICROARCH.md "rocprofv3 PMC slots"): parked on
         # s_waitcnt / barrier, stalled at issue, issuing -- for the kernels of the frame
         breakdown = {}
-        for kern in ("k_integrate", "k_render", "k_alloc_sweep", "k_mark"):
+        for kern in ("k_integrate", "k_render", "k_alloc_sweep", "k_mark", "k_bits_select", "k_fill_range_tiles"):
             c = {n: counter_rows("final_sq", n, kern)[warm:] for n in
                  ("SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "SQ_ACTIVE_INST_VALU", "SQ_INSTS_VALU",
                   "SQ_INSTS_SALU", "SQ_WAVES")}
@@ -167,6 +167,51 @@ def main():
     if os.path.exists(sw):
         subprocess.run([sys.executable, os.path.join(HERE, "experiments", "sweep_timeline3.py"), sw,
                         os.path.join(HERE, f"{tag}_sweep_timeline.json")], stdout=subprocess.DEVNULL, check=True)
+    sel = os.path.join(OUT, "final_select.bin")
+    if os.path.exists(sel):
+        subprocess.run([sys.executable, os.path.join(HERE, "experiments", "select_timeline.py"), sel,
+                        os.path.join(HERE, f"{tag}_select_timeline.json")], stdout=subprocess.DEVNULL, check=True)
+    mk = os.path.join(OUT, "final_mark.bin")
+    if os.path.exists(mk):
+        d = np.fromfile(mk, dtype=np.uint64).reshape(-1, 4)
+        n_pix = 1200   # 640 x 480 / 256
+        re_, pix = d[:len(d) - n_pix].astype(np.int64), d[len(d) - n_pix:]
+        t = pix.astype(np.int64)
+        t3 = (pix[:, 3] & np.uint64((1 << 56) - 1)).astype(np.int64)
+        a, b, c = (t[:, 2] - t[:, 0]) / 2400.0, (t3 - t[:, 2]) / 2400.0, (t[:, 1] - t3) / 2400.0
+        rl = (re_[:, 1] - re_[:, 0]) / 2400.0
+        json.dump({"kernel": "k_mark", "source": "DSLAM_DBG_MARK dump of the 60th pass of the bench loop: 4 stamps of the first wave of every workgroup "
+                   "(s_memtime, taken as 2.4 GHz; counters of different CUs are not aligned: only differences inside a workgroup)",
+                   "retest_workgroups": int(len(re_)), "retest_life_us": {"mean": round(float(rl.mean()), 2), "max": round(float(rl.max()), 2)},
+                   "pixel_workgroups": n_pix,
+                   "pixel_first_wave_us": {"entry_to_depth_pixel": round(float(a.mean()), 2), "walk": round(float(b.mean()), 2), "tail": round(float(c.mean()), 2),
+                                           "total_mean": round(float((a + b + c).mean()), 2), "total_p99": round(float(np.percentile(a + b + c, 99)), 2),
+                                           "total_max": round(float((a + b + c).max()), 2)}},
+                  open(os.path.join(HERE, f"{tag}_mark_timeline.json"), "w"), indent=1)
+    rq = newest("final_reint_sq/*/*counter_collection.csv", required=False)
+    if rq:
+        import collections
+        acc = collections.defaultdict(lambda: collections.defaultdict(float))
+        disp = collections.defaultdict(set)
+        for r in csv.DictReader(open(rq)):
+            k = r["Kernel_Name"].split("(")[0]
+            if "k_reintegrate_blocks" in k or "k_batch_" in k:
+                acc[k][r["Counter_Name"]] += float(r["Counter_Value"])
+                disp[k].add(r["Dispatch_Id"])
+        out = {"command": "rocprofv3 --pmc SQ_INSTS_VALU SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_SALU "
+                          "--kernel-trace -- python3 bench.py --steps 100 --warmup 10 --no-cpu-baseline --no-stress --no-extra-rates --mode device "
+                          "(the re-integration leg: 32 keyframes of the 110-keyframe map)", "kernels": {}}
+        for k, c in acc.items():
+            n = len(disp[k])
+            m = {kk: v / n for kk, v in c.items()}
+            wc = m.get("SQ_WAVE_CYCLES", 0.0)
+            if not wc:
+                continue
+            out["kernels"][k] = {"launches": n, "waves": m["SQ_WAVES"], "valu_instructions": m["SQ_INSTS_VALU"], "salu_instructions": m["SQ_INSTS_SALU"],
+                                 "frac_of_wave_time_with_a_valu_instruction_active": round(m["SQ_ACTIVE_INST_VALU"] / wc, 3),
+                                 "frac_issuing": round(m["SQ_ACTIVE_INST_ANY"] / wc, 3), "frac_stalled_at_issue": round(m["SQ_WAIT_INST_ANY"] / wc, 3),
+                                 "frac_parked_on_waitcnt_or_barrier": round(m["SQ_WAIT_ANY"] / wc, 3)}
+        json.dump(out, open(os.path.join(HERE, f"{tag}_reintegration_pmc.json"), "w"), indent=1)
     ms_src = os.path.join(OUT, "final_memory_sensitivity.json")
     if os.path.exists(ms_src) and os.path.getsize(ms_src) > 2:
         json.dump(json.load(open(ms_src)), open(os.path.join(HERE, f"{tag}_memory_shape_sensitivity.json"), "w"), indent=1)
