@@ -22,6 +22,7 @@ attached to its dispatch packets on the engine stream, plus (`roofline.stress`) 
 -O3 -march=native on this box, OpenMP over visible blocks / pixels like upstream's CPU engine, warm-up excluded.
 """
 import argparse
+import gc
 import json
 import os
 import sys
@@ -299,13 +300,26 @@ def main():
         for i in range(Wm):
             step(i)
         eng.synchronize()
+        # (the driver script's own garbage collector: a full collection over the frame generator's objects took 30-50 ms in
+        # the middle of the S-room loop -- as much as 200 frames' worth of time; what exists now is exempted from collections)
+        gc.collect()
+        gc.freeze()
         if timed_roofline:
             eng.kernel_timer_enable(True)
         barrier()
         t0 = time.perf_counter()
+        trace = os.environ.get("DSLAM_BENCH_TRACE")   # diagnostics: which steps' calls keep the host for more than a millisecond?
         for i in range(Wm, Wm + K):
+            if trace:
+                ta = time.perf_counter()
             step(i)
+            if trace and time.perf_counter() - ta > 1e-3:
+                print(f"[bench trace] step {i}: {(time.perf_counter() - ta) * 1e3:.2f} ms on the host", file=sys.stderr)
+        if trace:
+            ta = time.perf_counter()
         eng.synchronize()  # drains the engine stream: every output image of the timed region is in host memory
+        if trace:
+            print(f"[bench trace] final synchronize: {(time.perf_counter() - ta) * 1e3:.2f} ms", file=sys.stderr)
         torch.cuda.synchronize()
         t1 = time.perf_counter()
         barrier()
@@ -408,6 +422,10 @@ def main():
                 reint_out[form] = {"keyframes_per_s": Kre / tot, "total_ms": tot * 1e3, "compute_ms": rei * 1e3, "all_gather_ms": agt * 1e3,
                                    "gathered_bytes": tm["gathered_bytes"], "dirty_blocks": tm["dirty_blocks"],
                                    "all_gather_GBps": (tm["gathered_bytes"] / agt / 1e9) if (use_dist and agt > 0) else None}
+            reint_out["forms"] = ("reference_calls = DeProcessFrame + ProcessFrame per keyframe as DenseSlam.cpp:389-403 calls them; stored_lists / "
+                                  "block_major de-integrate the blocks of the keyframe's own fusion-time list (not the reference's call sequence; "
+                                  "like the whole path: parity unpinned, checked against the oracle only); block_major = dslam_reintegrate_batch, "
+                                  "bit-identical to the stored_lists loop")
             reint_out["keyframes_per_s"] = reint_out["block_major"]["keyframes_per_s"]
             reint_out["all_gather_ms"] = reint_out["block_major"]["all_gather_ms"]
             reint_out["gathered_bytes"] = reint_out["block_major"]["gathered_bytes"]
