@@ -955,7 +955,7 @@ static int batch_scratch(dslam_engine *e, dslam_scene *s, dslam_frame_store *fs)
 int dslam_reintegrate_batch(dslam_engine *e, dslam_scene *s, dslam_view *v, dslam_render_state *r, dslam_frame_store *fs,
                             int n, const int32_t *slots, const float *old_M, const float *new_M, const float intr[4],
                             float affine_a, float affine_b) {
-  DSLAM_REQUIRE(e && s && v && r && fs && slots && old_M && new_M && intr && n >= 0, "null argument");
+  DSLAM_REQUIRE(e && s && v && r && fs && intr && n >= 0 && (n == 0 || (slots && old_M && new_M)), "null argument");
   DSLAM_REQUIRE(s->engine == e && v->engine == e && r->engine == e && fs->engine == e, "objects belong to a different engine");
   DSLAM_REQUIRE(fs->lists, "dslam_frame_store_enable_lists has not been called");
   DSLAM_REQUIRE(v->w_rgb == fs->w_rgb && v->h_rgb == fs->h_rgb && v->w_d == fs->w_d && v->h_d == fs->h_d, "view and frame store sizes differ");

@@ -1,4 +1,6 @@
 # A/B of two builds of the library on one box: the maintenance bench with the tree's library, then with profiles/experiments/ab_old.so
+# (the other build: `git archive <commit> denseslam-global-consistency-h_amd/csrc include | tar -x -C scratch/old`, make there, copy its
+# libdslam_fusion.so to profiles/experiments/ab_old.so -- git-ignored, removed after use)
 L=denseslam-global-consistency-h_amd/csrc/libdslam_fusion.so
 show() { python -c "
 import json,sys;m=json.load(open(sys.argv[1]))
