@@ -222,13 +222,32 @@ class FusionFrameDatabase:
         culled = [ts for ts in sorted(self.entries) if self.entries[ts][2] == 0]
         return order, culled
 
+    def enable_visible_lists(self, scene):
+        """(extension) room for one visible list per keyframe: what the batched correction de-integrates from"""
+        self.api.frame_store_enable_lists(self.store, scene)
+
+    def keep_visible_list(self, ts, scene, rs):
+        """after every fusion of keyframe `ts` (itmlib: FusionFrameDataBase / ITMDenseMapper::KeepVisibleList)"""
+        self.api.frame_store_put_visible_list(self.store, self.entries[ts][1], scene, rs)
+
     def online_correction(self, scene, view, rs, intr, keyframes, correction_num, start_to_correction_num,
-                          identity_eps=0.0):
+                          identity_eps=0.0, batched=False):
         """DenseSlam::OnlineCorrection: de-integrate each selected keyframe at its old pose, re-integrate it at the
-        optimised one with isDefusion, then take culled keyframes out of the map.  No image leaves the device."""
+        optimised one with isDefusion, then take culled keyframes out of the map.  No image leaves the device.
+        batched: the re-fusions as ONE dslam_reintegrate_batch call (itmlib: OnlineCorrectionBatched); the keyframes'
+        visible lists must have been kept (enable_visible_lists + keep_visible_list)."""
         api = self.api
         order, culled = self.plan(keyframes, correction_num, start_to_correction_num, identity_eps)
-        for ts, new_Twc in order:
+        if batched and order:
+            ents = [self.entries[ts] for ts, _ in order]
+            api.reintegrate_batch(scene, view, rs, self.store, [e[1] for e in ents], [self.pose_to_M(e[0]) for e in ents],
+                                  [self.pose_to_M(T) for _, T in order], intr)
+            for e, (_, T) in zip(ents, order):
+                e[0] = T
+            order_loop = []
+        else:
+            order_loop = order
+        for ts, new_Twc in order_loop:
             ent = self.entries[ts]
             api.view_update_from_store(view, self.store, ent[1], timestamp=float(ts))
             api.deprocess_frame(scene, view, rs, self.pose_to_M(ent[0]), intr)

@@ -106,6 +106,13 @@ class FusionFrameDataBase {
     db_[timestamp] = fusionFrameInfo{pose, slot, 0};
   }
 
+  /// (extension) room for one visible list per keyframe; the driver then calls KeepVisibleList after every fusion of a
+  /// keyframe, and OnlineCorrectionBatched can replace OnlineCorrection
+  void EnableVisibleLists(const dslam_scene *scene) {
+    ITMLib::dslam_check(dslam_frame_store_enable_lists(eng_, store_, scene), "dslam_frame_store_enable_lists");
+  }
+  int SlotOf(double timestamp) const { return db_.at(timestamp).slot; }
+
   /// DenseSlam::SlideWindowPose: drop the oldest entries until max_age remain
   void SlideWindowPose(int max_age) {
     int cullSize = (int)db_.size() - max_age;
@@ -167,6 +174,58 @@ class FusionFrameDataBase {
     }
     if (culled) *culled = n_culled;
     return countNum;
+  }
+
+  /// (extension) OnlineCorrection with the re-fusions of the selected keyframes as ONE batch on the device.  Same selection,
+  /// same order, same culling; the Driver supplies, instead of the per-keyframe calls,
+  ///   ReIntegrateLocalMapBatch(map, store, n, slots, oldTwc, newTwc, timestamps)
+  /// and must have kept every keyframe's visible list (EnableVisibleLists + KeepVisibleList after each fusion).
+  template <class Driver, class LocalMap>
+  int OnlineCorrectionBatched(Driver &static_scene_, const LocalMap *currentLocalMap, const std::vector<MapKeyFrame> &currAllKeyFrame,
+                              const OnlineCorrectionParams &online_correction_, int *culled = nullptr) {
+    std::map<float, mapKeyframeInfo, std::greater<float>> mapPoseError;
+    for (size_t i = 0; i < currAllKeyFrame.size(); i++) {
+      const MapKeyFrame &kf = currAllKeyFrame[i];
+      if (kf.bad) continue;
+      Map::iterator fusioniter = db_.find(kf.mTimeStamp);
+      if (fusioniter == db_.end()) continue;
+      fusioniter->second.flaginfo = 1;
+      float rightError;
+      if (!PoseError(fusioniter->second.poseinfo, kf.poseInverse, &rightError)) continue;
+      mapPoseError[rightError] = mapKeyframeInfo{kf.mTimeStamp, kf.poseInverse};
+    }
+    std::vector<int> slots;
+    std::vector<Matrix4f> oldTwc, newTwc;
+    std::vector<double> stamps;
+    if ((int)mapPoseError.size() > online_correction_.StartToCorrectionNum - 1) {
+      for (auto errorIter = mapPoseError.begin(); errorIter != mapPoseError.end(); ++errorIter) {
+        Map::iterator defusioniter = db_.find(errorIter->second.timestampinfo);
+        if (defusioniter != db_.end()) {
+          slots.push_back(defusioniter->second.slot);
+          oldTwc.push_back(defusioniter->second.poseinfo);
+          newTwc.push_back(errorIter->second.poseinfok);
+          stamps.push_back(errorIter->second.timestampinfo);
+          defusioniter->second.poseinfo = errorIter->second.poseinfok;
+        }
+        if ((int)slots.size() > online_correction_.CorrectionNum - 1) break;
+      }
+    }
+    if (!slots.empty())
+      static_scene_.ReIntegrateLocalMapBatch(currentLocalMap, store_, (int)slots.size(), slots.data(), oldTwc.data(), newTwc.data(), stamps.data());
+    int n_culled = 0;
+    for (Map::iterator iter = db_.begin(); iter != db_.end();) {
+      if (iter->second.flaginfo == 0) {
+        static_scene_.SetPoseLocalMap(currentLocalMap, iter->second.poseinfo);
+        static_scene_.UpdateViewFromStore(store_, iter->second.slot, 0.0);
+        static_scene_.DeIntegrateLocalMap(currentLocalMap);
+        iter = erase(iter);
+        n_culled++;
+      } else {
+        ++iter;
+      }
+    }
+    if (culled) *culled = n_culled;
+    return (int)slots.size();
   }
 
  private:

@@ -86,6 +86,24 @@ class ITMDenseMapper {
                 "dslam_deprocess_frame");
     scene->refreshCounters(eng_, rs, &decayedBlocks_);
   }
+  /// (extension of this engine, not in upstream) keep the visible list of the fusion that has just run with the keyframe's
+  /// images in the device-resident store: what ReProcessFrames de-integrates from (dslam_frame_store_put_visible_list)
+  void KeepVisibleList(dslam_frame_store *store, int slot, ITMScene<ITMVoxel, ITMVoxelIndex> *scene, ITMRenderState *rs) {
+    dslam_check(dslam_frame_store_put_visible_list(eng_, store, slot, scene->handle, rs->handle), "dslam_frame_store_put_visible_list");
+  }
+  /// (extension) the re-fusion loop of DenseSlam::OnlineCorrection [REF DenseSlam.cpp:389-403] -- per keyframe DeProcessFrame at
+  /// the old pose, ProcessFrame(isDefusion) at the new one -- as ONE call, run block-major on the device (dslam_reintegrate_batch;
+  /// one camera).  De-integration visits the blocks of the keyframe's own stored list, not what an allocation pass at the old
+  /// pose finds today: not the reference's call sequence.
+  void ReProcessFrames(const ITMView *view, ITMScene<ITMVoxel, ITMVoxelIndex> *scene, ITMRenderState *rs, dslam_frame_store *store,
+                       int n, const int *slots, const Matrix4f *oldM_d, const Matrix4f *newM_d) {
+    const Vector4f kd = view->calib->intrinsics_d.projectionParamsSimple.all;
+    const Vector2f ab = calib_->disparityCalib.params;
+    static_assert(sizeof(Matrix4f) == 16 * sizeof(float), "poses are handed over as n x 16 floats");
+    dslam_check(dslam_reintegrate_batch(eng_, scene->handle, view->handle, rs->handle, store, n, slots, n ? oldM_d[0].m : nullptr,
+                                        n ? newM_d[0].m : nullptr, kd.v, ab.x, ab.y), "dslam_reintegrate_batch");
+    scene->refreshCounters(eng_, rs, &decayedBlocks_);
+  }
   void Decay(ITMScene<ITMVoxel, ITMVoxelIndex> *scene, ITMRenderState *rs, int maxWeight, int minAge, bool forceAllVoxels) {
     dslam_check(dslam_decay(eng_, scene->handle, rs ? rs->handle : nullptr, maxWeight, minAge, forceAllVoxels), "dslam_decay");
     scene->refreshCounters(eng_, rs, &decayedBlocks_);

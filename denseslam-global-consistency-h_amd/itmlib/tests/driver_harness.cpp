@@ -76,6 +76,23 @@ class DriverHarness : public ITMMainEngine {
     this->denseMapper->SetFusionWeightParams(fusion_weight_params_);
     this->denseMapper->DeProcessFrame(this->view, m->trackingState, m->scene, m->renderState);
   }
+  // (extension) the visible list of the fusion that has just run, kept with the keyframe; the re-fusion loop as one batch
+  void KeepVisibleList(const ITMLocalMap *m, dslam_frame_store *store, int slot) const {
+    this->denseMapper->KeepVisibleList(store, slot, m->scene, m->renderState);
+  }
+  void ReIntegrateLocalMapBatch(const ITMLocalMap *m, dslam_frame_store *store, int n, const int *slots, const Matrix4f *oldTwc,
+                                const Matrix4f *newTwc, const double *) const {
+    const Matrix4f Tcurrmap_w = m->estimatedGlobalPose.GetM();
+    std::vector<Matrix4f> oldM(n), newM(n);
+    ITMPose tmp;
+    for (int k = 0; k < n; k++) {   // the matrices SetPoseLocalMap would have put into trackingState->pose_d
+      tmp.SetInvM(Tcurrmap_w * oldTwc[k]); oldM[k] = tmp.GetM();
+      tmp.SetInvM(Tcurrmap_w * newTwc[k]); newM[k] = tmp.GetM();
+    }
+    this->denseMapper->SetFusionWeightParams(fusion_weight_params_);
+    this->denseMapper->ReProcessFrames(this->view, m->scene, m->renderState, store, n, slots, oldM.data(), newM.data());
+    if (n > 0) m->trackingState->pose_d->SetInvM(Tcurrmap_w * newTwc[n - 1]);   // where the loop's last SetPoseLocalMap leaves it
+  }
   // InfiniTamDriver::Decay (InfiniTamDriver.h:274-282)
   void Decay(const ITMLocalMap *m) {
     if (voxel_decay_params_.enabled)
@@ -211,8 +228,15 @@ int main(int argc, char **argv) {
         void UpdateViewFromStore(const dslam_frame_store *s, int slot, double ts) { last_ts = ts; d.UpdateViewFromStore(s, slot, ts); }
         void DeIntegrateLocalMap(const ITMLocalMap *m) { d.DeIntegrateLocalMap(m); }
         void IntegrateLocalMap(const ITMLocalMap *m, bool a, bool b) { order->push_back(last_ts); d.IntegrateLocalMap(m, a, b); }
+        void ReIntegrateLocalMapBatch(const ITMLocalMap *m, dslam_frame_store *s, int n, const int *slots, const Matrix4f *o, const Matrix4f *nw,
+                                      const double *ts) {
+          for (int k = 0; k < n; k++) order->push_back(ts[k]);
+          d.ReIntegrateLocalMapBatch(m, s, n, slots, o, nw, ts);
+        }
       };
+      const bool batched = getenv("DRIVER_HARNESS_BATCHED") != nullptr;   // OnlineCorrectionBatched instead of OnlineCorrection
       SparsetoDense::FusionFrameDataBase mfusionFrameDataBase(drv.GetDslamEngine(), Vector2i(W, H), Vector2i(W, H), N);
+      if (batched) mfusionFrameDataBase.EnableVisibleLists(currentLocalMap->scene->handle);
       for (int i = 0; i < N; i++) {
         const double currBAKFTime = (double)i;
         Matrix4f orbSLAM2_Pose;
@@ -221,11 +245,13 @@ int main(int argc, char **argv) {
         mfusionFrameDataBase.InsertFromView(currBAKFTime, orbSLAM2_Pose, drv.GetView());  // DenseSlam.cpp:156-157
         Recorder rec{drv, &oc_order[i], 0.0};
         int culled = 0;
-        const int corrected = mfusionFrameDataBase.OnlineCorrection(rec, currentLocalMap, keyframes[i], oc, &culled);  // :178-181
+        const int corrected = batched ? mfusionFrameDataBase.OnlineCorrectionBatched(rec, currentLocalMap, keyframes[i], oc, &culled)
+                                      : mfusionFrameDataBase.OnlineCorrection(rec, currentLocalMap, keyframes[i], oc, &culled);  // :178-181
         drv.SetPoseLocalMap(currentLocalMap, orbSLAM2_Pose);                    // :189
         if (mfusionFrameDataBase.entries().count(currBAKFTime)) {
           drv.UpdateViewFromStore(mfusionFrameDataBase.store(), mfusionFrameDataBase.entries().at(currBAKFTime).slot, currBAKFTime);  // :212
           drv.IntegrateLocalMap(currentLocalMap);                               // :213
+          if (batched) drv.KeepVisibleList(currentLocalMap, mfusionFrameDataBase.store(), mfusionFrameDataBase.SlotOf(currBAKFTime));
         }
         if ((int)mfusionFrameDataBase.size() > sw.max_age && sw.enabled) {      // :215-225
           drv.SlideWindow(currentLocalMap);

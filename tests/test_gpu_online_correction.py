@@ -110,7 +110,10 @@ def test_python_scheduler_gpu_matches_oracle(pkg, synth, gpu, oracle):
     util.assert_same_state(snaps["gpu"], snaps["oracle"], "after online correction")
 
 
-def test_cpp_scheduler_matches_oracle_replay(pkg, synth, oracle, tmp_path):
+@pytest.mark.parametrize("batched", [False, True], ids=["per_keyframe_calls", "one_batch_call"])
+def test_cpp_scheduler_matches_oracle_replay(pkg, synth, oracle, tmp_path, batched):
+    """batched: FusionFrameDataBase::OnlineCorrectionBatched -- the re-fusions of a correction as ONE dslam_reintegrate_batch call,
+    de-integrating from the visible lists kept with the keyframes -- against the oracle's replay of the same schedule."""
     from dslam_amd.harness import reintegrate
     assert os.path.exists(HARNESS), "run python __graft_entry__.py (build) first"
     wl = synth.s_tiny()
@@ -137,7 +140,8 @@ def test_cpp_scheduler_matches_oracle_replay(pkg, synth, oracle, tmp_path):
             f.write(struct.pack("<i", len(kfs)))
             for ts, T, bad in kfs:
                 f.write(struct.pack("<d", ts)); f.write(pkg.mat_to_abi(T).tobytes()); f.write(struct.pack("<i", int(bad)))
-    res = subprocess.run([HARNESS, str(fin), str(fout), "1", str(max_age), str(fkf)], capture_output=True, text=True, timeout=120)
+    env = dict(os.environ, DRIVER_HARNESS_BATCHED="1") if batched else dict(os.environ)
+    res = subprocess.run([HARNESS, str(fin), str(fout), "1", str(max_age), str(fkf)], capture_output=True, text=True, timeout=120, env=env)
     assert res.returncode == 0, res.stdout + res.stderr
 
     raw = open(fout, "rb").read()
@@ -156,6 +160,8 @@ def test_cpp_scheduler_matches_oracle_replay(pkg, synth, oracle, tmp_path):
     rs, v = oracle.create_render_state(s, wl.W, wl.H), oracle.create_view(wl.W, wl.H)
     to_M = lambda T: _inv_abi(oracle, np.asarray(T, np.float32) + np.float32(0.0))
     db = reintegrate.FusionFrameDatabase(oracle, wl.W, wl.H, n_frames, pose_to_M=to_M)
+    if batched:
+        db.enable_visible_lists(s)
     py_log = []
     for i in range(n_frames):
         rgba, mm, _ = frames[i]
@@ -163,10 +169,12 @@ def test_cpp_scheduler_matches_oracle_replay(pkg, synth, oracle, tmp_path):
         slot = db.insert_from_view(float(i), Twc[i], v)
         # unmoved keyframes give pose differences of rounding size (never exactly the identity in the C++ float
         # arithmetic either, unless bit-identical); they rank last and are never selected with these parameters
-        order, culled = db.online_correction(s, v, rs, wl.intr, sets[i], corr_num, start_num)
+        order, culled = db.online_correction(s, v, rs, wl.intr, sets[i], corr_num, start_num, batched=batched)
         if float(i) in db.entries:
             oracle.view_update_from_store(v, db.store, slot, timestamp=float(i))
             oracle.process_frame(s, v, rs, to_M(Twc[i]), wl.intr)
+            if batched:
+                db.keep_visible_list(float(i), s, rs)
         if len(db) > max_age:
             oracle.slide_window(s, rs, max_age)
             for _ in range(corr_num):
