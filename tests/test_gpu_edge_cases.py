@@ -436,3 +436,38 @@ def test_get_image_into_page_locked_caller_image(pkg, synth, gpu):
     finally:
         gpu.host_free(pin_f)
         gpu.host_free(pin_c)
+
+
+def test_range_image_with_blocks_next_to_the_camera(pkg, synth, gpu, oracle):
+    """Free-camera views from a few centimetres off the fused surface: the nearest blocks project onto boxes that cover whole
+    16x16-cell tiles of the range image -- the boxes k_fill_range_tiles hands to the whole workgroup (thread = cell) instead of
+    splatting them from one lane (round 3) -- next to thousands of small ones.  Range image (the corner the raycaster reads)
+    and depth image against the oracle, 640x480."""
+    wl = synth.s_street(640, 480)
+    p = pkg.SceneParams(num_local_blocks=0x8000, **wl.scene_kwargs)
+    out = {}
+    for name, api in (("gpu", gpu), ("oracle", oracle)):
+        s = api.create_scene(p)
+        rs, v = api.create_render_state(s, wl.W, wl.H), api.create_view(wl.W, wl.H)
+        for i in range(3):
+            rgba, mm, M = wl.frame(i)
+            api.view_update(v, rgba, mm, timestamp=float(i))
+            api.process_frame(s, v, rs, M, wl.intr)
+        free = api.create_render_state(s, wl.W, wl.H)
+        res = []
+        for drop, pitch in ((1.3, -0.5), (1.45, -0.3), (1.48, 0.0)):   # metres towards the ground, looking down by -`pitch` rad
+            T = wl.pose(2) @ synth.pose_matrix(synth.look_rotation(0.0, pitch), [0.0, drop, 0.0])
+            Mf = synth.world_to_camera(T)
+            img = api.get_image(s, free, Mf, wl.intr, pkg.IMAGE_DEPTH)
+            res.append((img, api.download_range_image(free)[:(wl.H + 7) // 8, :(wl.W + 7) // 8].copy(), api.stats(s, free)["no_visible_entries"]))
+        out[name] = res
+    big_tiles = 0
+    for k, ((gi, gr, gn), (oi, orr, on)) in enumerate(zip(out["gpu"], out["oracle"])):
+        assert gn == on and gn > 1000, f"view {k}: {gn} / {on} visible blocks"
+        assert np.array_equal(gr, orr), f"view {k}: range image"
+        assert np.array_equal(gi > 0, oi > 0) and np.abs(gi - oi).max() <= 1e-4, f"view {k}: depth image"
+        valid = orr[..., 1] > orr[..., 0]
+        assert orr[..., 0][valid].min() < 1.0, f"view {k}: nothing closer than a metre"
+        big_tiles += int((orr[..., 0][valid] < 1.5).sum())
+    # a 0.4 m block at 0.7 m spans ~300 pixels = 38 range-image cells: more than two 16-cell tiles in each direction
+    assert big_tiles > 500, "the views must contain many cells whose nearest block is closer than 1.5 m"
