@@ -100,6 +100,10 @@ struct SelDecaySweep {
 // first is looked at.  (One candidate per wave-step with a scalar chain in front of every block: 3.8 TB/s read-only on
 // the S-stress map; plain 4 KiB-per-wave streaming reaches 5.4.)
 constexpr int kGather = 8;
+#ifndef DSLAM_DECAY_WGS
+#define DSLAM_DECAY_WGS 1024
+#endif
+constexpr int kDecayWgs = DSLAM_DECAY_WGS;
 __global__ __launch_bounds__(256) void k_decay_blocks(const int *__restrict__ cand, const int *count_ptr,
                                                       const HashEntry *__restrict__ hash, uint4 *voxels16,
                                                       int max_weight, unsigned char *remove_flags,
@@ -484,7 +488,7 @@ static int release_listed(dslam_engine *e, dslam_scene *s, dslam_render_state *r
 // m.cand_list[0 .. swap_count) holds the selection: decay those blocks, release the ones left without a measured voxel
 static int decay_candidates(dslam_engine *e, dslam_scene *s, dslam_render_state *r, const MaintScratch &m,
                             int max_weight) {
-  hipLaunchKernelGGL(k_decay_blocks, dim3(1024), dim3(256), 0, e->stream, m.cand_list, &s->counters->swap_count, s->hash,
+  hipLaunchKernelGGL(k_decay_blocks, dim3(kDecayWgs), dim3(256), 0, e->stream, m.cand_list, &s->counters->swap_count, s->hash,
                      reinterpret_cast<uint4 *>(s->voxels), max_weight, m.rem_flags, m.rem_cand, s->p.use_swapping ? 0 : 1);
   dbg_sync(e, "k_decay_blocks");
   DSLAM_HIP(hipGetLastError());
