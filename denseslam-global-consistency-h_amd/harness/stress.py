@@ -44,7 +44,9 @@ def build_lattice_state(pkg, n_side, num_buckets, num_excess):
     return table, visible, excess_list, len(free_ex) - 1
 
 
-def run(pkg, eng, n_side=64, iterations=20, W=640, H=480):
+def run(pkg, eng, n_side=64, iterations=20, W=640, H=480, slots_in_list_order=False):
+    """slots_in_list_order: the r-th visible entry holds voxel-block slot r (the blocks are then visited in memory order);
+    default: slots in lattice order = random with respect to the list (hash) order -- the worse case for HBM page locality."""
     n = n_side ** 3
     params = pkg.SceneParams(voxel_size=0.01, mu=0.04, max_w=100, frustum_min=0.2, frustum_max=100.0,
                              num_local_blocks=n, num_buckets=0x100000, num_excess=0x20000)
@@ -52,6 +54,8 @@ def run(pkg, eng, n_side=64, iterations=20, W=640, H=480):
     rs = eng.create_render_state(scene, W, H)
     view = eng.create_view(W, H)
     table, visible, excess_list, last_free_ex = build_lattice_state(pkg, n_side, params.num_buckets, params.num_excess)
+    if slots_in_list_order:
+        table["ptr"][visible] = np.arange(len(visible), dtype=np.int32)
     eng.upload_scene_state(scene, hash_table=table, allocation_list=np.arange(n, dtype=np.int32), last_free_block_id=-1,
                            excess_list=excess_list, last_free_excess_id=last_free_ex)
     eng.upload_visible_ids(rs, visible)
@@ -74,7 +78,7 @@ def run(pkg, eng, n_side=64, iterations=20, W=640, H=480):
     vox = eng.download_voxel_blocks(scene, 0, 64)
     updated = float((vox["w_depth"] > 0).mean())
     alg_bytes = 8212.0 * nvis + 8.0 * W * H
-    return {"workload": f"S-stress lattice {n_side}^3", "visible_blocks": nvis, "ms_per_launch": ms,
+    return {"workload": f"S-stress lattice {n_side}^3" + (", slots in list order" if slots_in_list_order else ""), "visible_blocks": nvis, "ms_per_launch": ms,
             "algorithmic_bytes_per_launch": alg_bytes, "achieved_GBps": alg_bytes / (ms * 1e-3) / 1e9,
             "frac_of_8TBps": alg_bytes / (ms * 1e-3) / 1e9 / 8000.0, "voxels_updated_frac_sample": updated,
             "iterations": iterations}
@@ -86,4 +90,6 @@ if __name__ == "__main__":
     pkg = ge.load_package()
     eng = pkg.open_engine(0)
     n_side = int(sys.argv[1]) if len(sys.argv) > 1 else 64
-    print(json.dumps(run(pkg, eng, n_side=n_side)))
+    out = run(pkg, eng, n_side=n_side)
+    out["slots_in_list_order"] = run(pkg, pkg.open_engine(0), n_side=n_side, slots_in_list_order=True)
+    print(json.dumps(out))
