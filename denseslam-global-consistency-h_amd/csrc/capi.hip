@@ -93,7 +93,7 @@ int ensure_scratch(dslam_engine *e, int entries, int local_blocks) {
   free_dev(e->list_a); free_dev(e->list_b); free_dev(e->list_c); free_dev(e->list_d); free_dev(e->pos_scratch);
   free_dev(e->agg);
   for (int k = 0; k < 2; k++) { free_dev(e->bits_q1[k]); free_dev(e->bits_q2[k]); free_dev(e->bits_mark[k]); }
-  free_dev(e->bits_retest); free_dev(e->bits_tmp);
+  free_dev(e->bits_retest);
   free_dev(e->rem_flags); free_dev(e->freed_flags); free_dev(e->rem_cand); free_dev(e->maint_flags);
   // order keys and allocType: cleared here once, kept clean by the allocation passes (scenes of different sizes share
   // them, so both start at fixed addresses: a pass only ever touches [0, its entry count) of each)
@@ -115,11 +115,9 @@ int ensure_scratch(dslam_engine *e, int entries, int local_blocks) {
     e->bits_dirty[k] = 0;
   }
   DSLAM_HIP(hipMalloc(&e->bits_retest, bits_bytes));
-  DSLAM_HIP(hipMalloc(&e->bits_tmp, bits_bytes));
   DSLAM_HIP(hipMemsetAsync(e->bits_retest, 0, bits_bytes, e->stream));
-  DSLAM_HIP(hipMemsetAsync(e->bits_tmp, 0, bits_bytes, e->stream));
   int tiles = num_tiles(N > L ? N : L);
-  if (tiles < bit_tiles(N) * (kBitTileWords / 32)) tiles = bit_tiles(N) * (kBitTileWords / 32);  // (per-tile counts of k_bits_test)
+  if (tiles < bit_tiles(N) * (kBitTileWords / 32)) tiles = bit_tiles(N) * (kBitTileWords / 32);  // (room for tiles as small as 1024 entries)
   DSLAM_HIP(hipMalloc(&e->agg, (size_t)tiles * 3 * sizeof(unsigned long long)));
   DSLAM_HIP(hipMemsetAsync(e->agg, 0, (size_t)tiles * 3 * sizeof(unsigned long long), e->stream));
   e->agg_tiles = tiles;
@@ -210,7 +208,7 @@ int dslam_engine_destroy(dslam_engine *e) {
   free_dev(e->list_a); free_dev(e->list_b); free_dev(e->list_c); free_dev(e->list_d); free_dev(e->pos_scratch);
   free_dev(e->agg); free_dev(e->ticket);
   for (int k = 0; k < 2; k++) { free_dev(e->bits_q1[k]); free_dev(e->bits_q2[k]); free_dev(e->bits_mark[k]); }
-  free_dev(e->bits_retest); free_dev(e->bits_tmp);
+  free_dev(e->bits_retest);
   free_dev(e->rem_flags); free_dev(e->freed_flags); free_dev(e->rem_cand); free_dev(e->maint_flags);
   if (e->staging_dev) (void)hipFree(e->staging_dev);
   if (e->staging_host) (void)hipHostFree(e->staging_host);

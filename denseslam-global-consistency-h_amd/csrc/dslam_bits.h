@@ -28,8 +28,8 @@
 namespace dslam {
 
 struct NoPayload {};
-// for selections whose test / emit read what they need themselves
-// for selections whose emit has nothing to prepare: it gets the payload
+// DSLAM_SEL_NO_STAGE: for selections whose emit has nothing to prepare (it gets the payload);
+// DSLAM_SEL_NO_LOAD: for selections whose test / emit read what they need themselves (implies NO_STAGE)
 #define DSLAM_SEL_NO_STAGE typedef Payload Staged; __device__ const Payload &stage(int, const Payload &p) const { return p; }
 #define DSLAM_SEL_NO_LOAD typedef NoPayload Payload; __device__ NoPayload load(int) const { return NoPayload(); } DSLAM_SEL_NO_STAGE
 constexpr int kSelBatch = 4;            // entries per lane whose loads are in flight together
@@ -110,7 +110,7 @@ inline TileChain next_chain(dslam_engine *e, int n_tiles, int *grid_out, bool se
 }
 
 
-// One launch: tile = kCompactTileWords words = 8192 entries per 1024-thread workgroup, tiles taken by ticket.
+// One launch: tile = kSelTileWords words = 8192 entries per 1024-thread workgroup, tiles taken by ticket.
 //   1. the set bits of the tile are expanded into an LDS list (thread = one byte of a word) and tested DENSELY, one candidate
 //      per lane and round: excess entries are handed out contiguously, so some bitmap words are full while most are nearly
 //      empty -- a lane that walks "its" word bit by bit ends up with 32 dependent gathers where its neighbours have none
@@ -119,11 +119,13 @@ inline TileChain next_chain(dslam_engine *e, int n_tiles, int *grid_out, bool se
 //   2. the verdicts (wave ballots, by list position) give the ranks inside the tile; the tile's count goes out, the counts of
 //      the tiles in front come in (one look-back: tiles are taken in starting order, so every word waited for belongs to a
 //      workgroup that is running; the spin is bounded all the same);
+//      while the counts travel, every lane works out what its emits do not need the rank for (Sel::stage);
 //   3. the selected entries are emitted, each by the lane that tested it (the payload of the first round is still in
 //      registers).
 // Up to the middle of round 3 this was two launches (test -> bitmap + counts | compact), 7.5 + 7.8 us for GetImage's
-// FindVisibleBlocks where this one takes 8: the second launch had to read back what the first had in registers, and the
-// boundary between them cost more than the look-back does.
+// FindVisibleBlocks where this one takes 12.8: merely fused, with the look-back in place of the boundary, it took 14.4; the
+// staging is what the fusion made possible.  Other shapes measured: 512 threads x 4096 entries
+// 15.2 us (twice the tickets), 1024 x 4096 20.7 us (two 1024-thread workgroups do not share a CU).
 template <class Sel>
 __global__ __launch_bounds__(kSelThreads) void k_bits_select(const unsigned *__restrict__ src_bits, Sel sel, int *__restrict__ out,
                                                              int capacity, int *total_out, int *tile_sum_out, TileChain ch,

@@ -62,7 +62,6 @@ struct dslam_engine {
   // that were visible before the pass (every word is written by every pass).
   unsigned *bits_q1[2] = {nullptr, nullptr}, *bits_q2[2] = {nullptr, nullptr}, *bits_mark[2] = {nullptr, nullptr};
   unsigned *bits_retest = nullptr;
-  unsigned *bits_tmp = nullptr;       // one more bitmap of scratch (frustum flags of FindVisibleBlocks, selections)
   int bits_words = 0;                 // words per bitmap (whole tiles)
   int bits_dirty[2] = {0, 0};
   unsigned alloc_pass = 0;
