@@ -133,9 +133,9 @@ int ensure_view_depth(dslam_engine *e, const dslam_view *v) {
 //                 in `mark`), race for the order key of every missing block (atomicMax: the last pixel / step in
 //                 row-major order wins) and set the slot's bit in q1 (empty bucket head: ordered request) or q2 (end of
 //                 an occupied bucket's chain: excess request).  Its first workgroups run an independent job: the frustum
-//                 re-test of every entry the render state held visible before the pass (`vis_bits`), one bitmap word per
-//                 lane, outcome in `retest`.
-//   k_alloc_sweep one pass over the bitmaps (36 tiles of 32768 entries instead of 288 tiles of 4096 table entries): the
+//                 re-test of every entry the render state held visible before the pass (`vis_bits`; set bits expanded
+//                 into LDS and tested one per lane), outcome in `retest`.
+//   k_alloc_sweep one pass over the bitmaps (144 tiles of 8192 entries; round 2: 288 tiles of 4096 TABLE entries): the
 //                 r-th requesting entry in hash-index order gets voxelAllocationList[lastFree - r] -- ranks are
 //                 popcounts; the winner of a slot is its final key, whose walk is replayed to the block it asked for;
 //                 visible entries = retest | mark | committed requests, written ascending.  Per-tile counts travel in

@@ -325,9 +325,10 @@ static __device__ __forceinline__ void publish(unsigned long long *agg, int tile
 //   scene         alloc_bits   entry holds a resident voxel block (ptr >= 0)
 //   render state  vis_bits     entriesVisibleType[entry] != 0
 //   engine        q1 / q2 / mark bits (two sets, used alternately: a pass clears the set of the pass before it), retest bits
-// A bitmap tile = kBitTileWords words = 32768 entries, one 256-thread workgroup, 4 consecutive words (one dwordx4) per
-// thread, so thread order = entry order and ordered ranks are popcounts + one block scan.  Arrays are padded to whole
-// tiles (the padding stays zero), so the loads need no bounds checks.
+// The arrays are padded to whole units of kBitTileWords words = 32768 entries (the padding stays zero), so no kernel needs
+// bounds checks; the passes cut them into their own tiles (sweep: 256 words per 256-thread workgroup, selection: 256 words per
+// 1024-thread workgroup) with consecutive words on consecutive threads, so thread order = entry order and ordered ranks are
+// popcounts + one block scan.
 constexpr int kBitTileWords = 1024;
 constexpr int kBitTileEntries = kBitTileWords * 32;
 static inline __host__ __device__ int bit_tiles(int entries) { return (entries + kBitTileEntries - 1) / kBitTileEntries; }
