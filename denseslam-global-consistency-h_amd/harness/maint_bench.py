@@ -6,6 +6,7 @@ latency-bound ones as rates: rays/s of the raycast and pixels/s of the allocatio
 
     python denseslam-global-consistency-h_amd/harness/maint_bench.py        # one JSON line
 """
+import gc
 import json
 import os
 import sys
@@ -191,6 +192,7 @@ def main():
         for i, (c, mm, M_i) in enumerate(frames):
             if i == 70:
                 eng.synchronize()
+                gc.collect(); gc.freeze()   # (this script's own garbage collector is kept out of the timed keyframes, as in bench.py)
                 t0 = time.perf_counter()
             eng.view_update(view, c, mm, timestamp=float(i))
             eng.process_frame(sc, view, r1, M_i, wl.intr)

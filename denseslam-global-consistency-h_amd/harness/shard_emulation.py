@@ -8,6 +8,7 @@ bytes a rank receives and the xGMI link rate, and labelled as a model.
 
 prints one JSON object (profiles/r03_shard_emulation.json).
 """
+import gc
 import json
 import sys
 import time
@@ -68,6 +69,7 @@ def main():
                 if stored == "batch":
                     eng.reintegrate_batch(scene, view, rs, store, [], [], [], wl.intr)   # (set-up call: the scratch buffers)
                 eng.synchronize()
+                gc.collect(); gc.freeze()
                 t0 = time.perf_counter()
                 if world > 1:
                     eng.set_shard(scene, rank, world, chunk)
