@@ -1,0 +1,111 @@
+"""Structural invariants of the map at the bench's size and length -- where the CPU oracle would need minutes per run
+(task statement, 3: "through size-independent properties the domain offers").  S-street 640x480, the default pools
+(0x40000 voxel blocks, 0x100000 buckets, 0x20000 excess entries), 150 keyframes with Decay + SlideWindow as the reference's
+driver calls them, asynchronous calls; every 25 keyframes and at the end the table, the free lists and the visible list are
+brought back and checked:
+
+  * the voxel-block slots held by entries and the slots on the free stack partition the pool (each slot exactly once);
+  * the same for the excess entries: in use (reachable from a bucket head) vs. on the excess free stack;
+  * every chain is well formed: offsets inside the excess area, no entry reachable twice, every resident entry reachable,
+    its position hashes to the bucket it hangs off;
+  * no block position appears twice among the resident entries;
+  * the visible list is strictly ascending, names resident entries only, and an entry has a type byte exactly if it is listed;
+  * the counters of dslam_get_stats agree with what the arrays say.
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _hash_index(pos, mask):
+    x, y, z = (pos[:, k].astype(np.int64) for k in range(3))
+    return ((x * 73856093) ^ (y * 19349669) ^ (z * 83492791)) & mask
+
+
+def check_map(api, scene, rs, p, label):
+    table = api.download_hash_table(scene)
+    st = api.stats(scene, rs)
+    nb, ne, nl = p.num_buckets, p.num_excess, p.num_local_blocks
+    ptr, off = table["ptr"], table["offset"]
+    resident = np.nonzero(ptr >= 0)[0]
+    # voxel-block slots: entries + free stack = the pool
+    free = api.download_allocation_list(scene)[:st["last_free_block_id"] + 1]
+    used = ptr[resident]
+    assert len(np.unique(used)) == len(used), f"{label}: a voxel-block slot is held by two entries"
+    assert len(used) + len(free) == nl, f"{label}: {len(used)} held + {len(free)} free != {nl}"
+    both = np.concatenate([used, free])
+    assert both.min() == 0 and both.max() == nl - 1 and len(np.unique(both)) == nl, f"{label}: slots do not partition the pool"
+    # chains: walk all buckets together
+    assert ((off >= 0) & (off <= ne)).all(), f"{label}: chain offset outside the excess area"
+    seen = np.zeros(nb + ne, dtype=bool)
+    cur = np.nonzero((ptr[:nb] >= -1) | (off[:nb] >= 1))[0]      # bucket heads that hold something or start a chain
+    seen[cur] = True
+    head_of = np.full(nb + ne, -1, dtype=np.int64)
+    head_of[cur] = cur
+    frontier, heads = cur, cur
+    steps = 0
+    while len(frontier):
+        nxt_off = off[frontier]
+        go = nxt_off >= 1
+        nxt = nb + nxt_off[go] - 1
+        assert not seen[nxt].any(), f"{label}: an excess entry is reachable twice"
+        seen[nxt] = True
+        head_of[nxt] = heads[go]
+        frontier, heads = nxt, heads[go]
+        steps += 1
+        assert steps < 64, f"{label}: a chain of more than 64 entries"
+    assert seen[resident].all(), f"{label}: a resident entry hangs off no bucket"
+    assert (_hash_index(table["pos"][resident], nb - 1) == head_of[resident]).all(), f"{label}: an entry sits in the wrong bucket's chain"
+    # excess entries: in a chain or on the free stack
+    in_chain = np.nonzero(seen[nb:])[0]
+    free_ex = api.download_excess_list(scene)[:st["last_free_excess_id"] + 1]
+    both = np.concatenate([in_chain, free_ex])
+    assert len(np.unique(both)) == len(both) == ne, f"{label}: excess entries do not partition ({len(in_chain)} chained + {len(free_ex)} free of {ne})"
+    # positions unique among resident entries
+    pos = table["pos"][resident].astype(np.int64)
+    key = (pos[:, 0] + 32768) | ((pos[:, 1] + 32768) << 16) | ((pos[:, 2] + 32768) << 32)
+    assert len(np.unique(key)) == len(key), f"{label}: a block position is held twice"
+    # visible list
+    ids = api.download_visible_ids(rs)
+    types = api.download_visible_types(rs)
+    assert len(ids) == st["no_visible_entries"]
+    assert (np.diff(ids) > 0).all(), f"{label}: visible list not strictly ascending"
+    assert (ptr[ids] >= 0).all(), f"{label}: a listed entry holds no block"
+    listed = np.zeros(nb + ne, dtype=bool)
+    listed[ids] = True
+    assert np.array_equal(types != 0, listed), f"{label}: type bytes and list disagree"
+    assert st["alloc_failures"] == 0
+    return len(used), len(ids)
+
+
+def test_map_invariants_over_a_long_run(pkg, synth, gpu):
+    wl = synth.s_street(640, 480)
+    p = pkg.SceneParams(num_local_blocks=0x40000, num_buckets=0x100000, num_excess=0x20000, **wl.scene_kwargs)   # upstream's defaults
+    scene = gpu.create_scene(p)
+    rs, free_rs, view = gpu.create_render_state(scene, wl.W, wl.H), gpu.create_render_state(scene, wl.W, wl.H), gpu.create_view(wl.W, wl.H)
+    n, max_age = 150, 50
+    held, seen_peak = [], 0
+    gpu.set_async(True)
+    try:
+        for i in range(n):
+            rgba, mm, M = wl.frame(i)
+            gpu.view_update(view, rgba, mm, timestamp=float(i))
+            gpu.process_frame(scene, view, rs, M, wl.intr)
+            if i + 1 > max_age:
+                gpu.slide_window(scene, rs, max_age)
+            gpu.decay(scene, rs, 3, 30, True)
+            if i % 5 == 4:
+                gpu.get_image(scene, free_rs, M, wl.intr, pkg.IMAGE_DEPTH, download=False)
+            if i % 25 == 24 or i == n - 1:
+                gpu.synchronize()
+                used, vis = check_map(gpu, scene, rs, p, f"keyframe {i}")
+                held.append(used)
+                seen_peak = max(seen_peak, vis)
+    finally:
+        gpu.synchronize()
+        gpu.set_async(False)
+    st = gpu.stats(scene, rs)
+    assert seen_peak > 4000 and max(held) > 20000, "the run must build a map worth checking"
+    assert st["slid_block_count"] > 10000 and st["decayed_block_count"] > 500, "window and decay must have released blocks"
+    assert held[-1] < max(held) or held[-1] < 60000, "the window keeps the map bounded"
