@@ -64,3 +64,48 @@ def test_batch_refuses_what_it_cannot_do(pkg, synth, gpu):
         gpu.reintegrate_batch(scene, view, rs, store, [0], [M], [M], wl.intr)   # a swapping scene
     with pytest.raises(pkg.DslamError):
         gpu.reintegrate_batch(scene, view, rs, store, [1], [M], [M], wl.intr)   # a keyframe without a stored list
+
+
+def test_batch_of_32_keyframes_at_bench_size_equals_the_loop(pkg, synth, gpu):
+    """The bench's batch: 32 keyframes of a 48-keyframe S-street map (640x480, 0x40000-block pool, decay + window before the
+    batch), every one of the 64 operation bits in use, ~30 k touched blocks.  The oracle would need a minute for this; the
+    HIP engine's own per-keyframe loop (checked against the oracle at the sizes above) defines the expected bytes: map,
+    rings, free lists, render state, and the stored lists (a second batch back to the old poses de-integrates from the lists
+    the first one left)."""
+    wl = synth.s_street(640, 480)
+    p = pkg.SceneParams(num_local_blocks=0x40000, num_buckets=0x100000, num_excess=0x20000, history_words=4, **wl.scene_kwargs)
+    n_map, K = 48, 32
+    frames = [wl.frame(i) for i in range(n_map)]
+    ids = list(range(n_map - K, n_map))
+    new = [synth.world_to_camera(wl.pose(i) @ synth.pose_matrix(synth.look_rotation(0.002 * (k + 1), 0.0), [0.01 * (k + 1), 0.0, 0.02])) for k, i in enumerate(ids)]
+    old = [frames[i][2] for i in ids]
+    states = {}
+    for call in ("loop", "batch"):
+        scene = gpu.create_scene(p)
+        rs, view = gpu.create_render_state(scene, wl.W, wl.H), gpu.create_view(wl.W, wl.H)
+        store = gpu.create_frame_store(wl.W, wl.H, n_map)
+        gpu.frame_store_enable_lists(store, scene)
+        for i, (rgba, mm, M) in enumerate(frames):
+            gpu.view_update(view, rgba, mm, timestamp=float(i))
+            gpu.frame_store_put_view(store, i, view)
+            gpu.process_frame(scene, view, rs, M, wl.intr)
+            gpu.frame_store_put_visible_list(store, i, scene, rs)
+            if i + 1 > 40:
+                gpu.slide_window(scene, rs, 40)
+            gpu.decay(scene, rs, 3, 30, True)
+        out = []
+        for a, b in ((old, new), (new, old)):
+            if call == "batch":
+                gpu.reintegrate_batch(scene, view, rs, store, ids, a, b, wl.intr)
+            else:
+                for k, i in enumerate(ids):
+                    gpu.view_update_from_store(view, store, i, timestamp=float(i))
+                    gpu.deprocess_frame_stored(scene, view, store, i, a[k], wl.intr)
+                    gpu.process_frame(scene, view, rs, b[k], wl.intr, is_defusion=True)
+                    gpu.frame_store_put_visible_list(store, i, scene, rs)
+            out.append(scenarios.full_state(gpu, scene, rs))
+        states[call] = out
+        assert gpu.stats(scene, rs)["no_visible_entries"] > 4000
+    for stage in range(2):
+        scenarios.assert_same_full_state(states["batch"][stage], states["loop"][stage], f"batch {stage}: one call vs the per-keyframe loop")
+    assert not np.array_equal(states["batch"][0]["voxels"], states["batch"][1]["voxels"]), "the second batch must have moved the map again"
