@@ -10,10 +10,10 @@ import util
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("workload,n_frames", [("s_tiny", 14), ("s_street", 6)])
+@pytest.mark.parametrize("workload,n_frames", [("s_tiny", 14), ("s_street", 6), ("s_street", 48)])   # (48: the bench's loop at length, every image compared)
 def test_pipelined_frames_equal_synchronous_calls(pkg, synth, gpu, workload, n_frames):
     wl = synth.s_tiny() if workload == "s_tiny" else synth.s_street(640, 480)
-    p = util.small_params(pkg, wl) if workload == "s_tiny" else pkg.SceneParams(num_local_blocks=0x8000, **wl.scene_kwargs)
+    p = util.small_params(pkg, wl) if workload == "s_tiny" else pkg.SceneParams(num_local_blocks=0x8000 if n_frames < 20 else 0x20000, **wl.scene_kwargs)
     frames = [wl.frame(i) for i in range(n_frames)]
 
     # reference behaviour: every call synchronous, pageable images
