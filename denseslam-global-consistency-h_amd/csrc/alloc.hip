@@ -42,7 +42,7 @@ __global__ __launch_bounds__(256) void k_fill_voxels(uint4 *__restrict__ v, size
 
 __global__ __launch_bounds__(256) void k_reset_tables(HashEntry *hash, int n_entries, int *alloc_list, int *last_seen,
                                                       int n_local, int *excess_list, int n_excess,
-                                                      SceneCounters *cnt) {
+                                                      SceneCounters *cnt, int *err_host) {
   const int stride = gridDim.x * blockDim.x;
   const int tid = blockIdx.x * blockDim.x + threadIdx.x;
   for (int i = tid; i < n_entries; i += stride) store_entry(hash, i, 0, 0, 0, 0, -2);
@@ -50,6 +50,7 @@ __global__ __launch_bounds__(256) void k_reset_tables(HashEntry *hash, int n_ent
   for (int i = tid; i < n_excess; i += stride) excess_list[i] = i;
   if (tid == 0) {
     SceneCounters c = {};
+    c.err_host = err_host;
     c.last_free = n_local - 1;
     c.last_free_ex = n_excess - 1;
     *cnt = c;
@@ -61,7 +62,7 @@ int launch_scene_reset(dslam_engine *e, dslam_scene *s) {
   const unsigned fill_wgs = (unsigned)((n16 + 256 * kFillUnroll - 1) / (256 * kFillUnroll));
   hipLaunchKernelGGL(k_fill_voxels, dim3(fill_wgs), dim3(256), 0, e->stream, reinterpret_cast<uint4 *>(s->voxels), n16);
   hipLaunchKernelGGL(k_reset_tables, dim3(2048), dim3(256), 0, e->stream, s->hash, s->n_entries, s->alloc_list,
-                     s->last_seen, s->p.num_local_blocks, s->excess_list, s->p.num_excess, s->counters);
+                     s->last_seen, s->p.num_local_blocks, s->excess_list, s->p.num_excess, s->counters, e->err_host);
   DSLAM_HIP(hipMemsetAsync(s->masks, 0, (size_t)s->p.num_local_blocks * 2 * s->history_words * sizeof(unsigned long long),
                            e->stream));
   if (s->swap_state) {
@@ -275,7 +276,7 @@ __global__ __launch_bounds__(256) void k_mark(MarkParams p) {
   int no_steps = ray_segment(d, x, y, p.invM, p.inv_fx, p.inv_fy, p.cx, p.cy, p.mu, p.one_over_block, pt, dir);
   if (!valid) no_steps = 0;
   if (no_steps > p.step_cap) {  // the order key cannot encode later steps: report instead of mis-ordering
-    atomicOr(&p.cnt->error_flags, 1);
+    report_error(p.cnt, 1);
     no_steps = p.step_cap;
   }
   int wave_steps = no_steps;
@@ -516,7 +517,7 @@ __global__ __launch_bounds__(256) void k_alloc_sweep(SweepParams p) {
   const int avail_vba = base_free + 1, avail_ex = base_free_ex + 1;
   const unsigned long long t_start = p.dbg ? __builtin_amdgcn_s_memtime() : 0ull;
   const int b = take_ticket(p.ticket, p.ticket_base, &s_ticket);   // (one tile per workgroup, in starting order)
-  if (b >= p.n_tiles) return;
+  if ((unsigned)b >= (unsigned)p.n_tiles) return;   // (unsigned: see take_ticket)
 #define STAMP(i) do { if (p.dbg && threadIdx.x == 0) p.dbg[(size_t)b * 8 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
   if (p.dbg && threadIdx.x == 0) p.dbg[(size_t)b * 8] = t_start;
   STAMP(1);
@@ -628,7 +629,7 @@ __global__ __launch_bounds__(256) void k_alloc_sweep(SweepParams p) {
     }
     STAMP(3);
     int pre[4];  // requests (type 1, type 2) and visible entries (retest | mark; new type-1 requests) in front of this tile
-    if (!lookback2(p.agg_req, p.agg_vis, b, p.epoch, red, pre) && threadIdx.x == 0) atomicOr(&p.cnt->error_flags, 2);
+    if (!lookback2(p.agg_req, p.agg_vis, b, p.epoch, red, pre) && threadIdx.x == 0) report_error(p.cnt, 2);
     STAMP(4);
     int lv[4] = {later2, 0, 0, 0};
     if (has_excess) block_sum4(lv, red);
@@ -875,6 +876,19 @@ __global__ __launch_bounds__(256) void k_clean_bits_tail(unsigned *q1, unsigned 
   q1[w] = 0; q2[w] = 0; mark[w] = 0;
 }
 
+// steps along the +-mu segment: ceil(2 * |segment| in blocks) = ceil(mu / (2 * voxel_size)) for a rigid pose; the order
+// key holds pixel * cap + step in 32 bits (also asked by dslam_reintegrate_batch before it changes anything)
+int alloc_step_cap(const dslam_scene *s, int W, int H, int *cap_out) {
+  const int step_bound = (int)ceilf(s->p.mu / (2.0f * s->p.voxel_size)) + 2;
+  const int cap = ceil_pow2(step_bound + 1);
+  if ((double)W * H * cap >= 4294967295.0) {
+    set_last_error("image size x ray steps exceeds the 32-bit allocation order key");
+    return DSLAM_ERR_UNSUPPORTED;
+  }
+  *cap_out = cap;
+  return DSLAM_OK;
+}
+
 int launch_allocate(dslam_engine *e, dslam_scene *s, const dslam_view *v, dslam_render_state *r, const float *M_d,
                     const float *intr, int only_update_visible_list, int *list_out, void *count_out) {
   const int W = v->w_d, H = v->h_d, N = s->n_entries;
@@ -895,13 +909,7 @@ int launch_allocate(dslam_engine *e, dslam_scene *s, const dslam_view *v, dslam_
   mp.keys = e->order_keys; mp.vis_type = r->visible_type;
   mp.cnt = s->counters;
   mp.alloc_type = e->alloc_type;
-  // steps along the +-mu segment: ceil(2 * |segment| in blocks) = ceil(mu / (2 * voxel_size)) for a rigid pose
-  const int step_bound = (int)ceilf(s->p.mu / (2.0f * s->p.voxel_size)) + 2;
-  mp.step_cap = ceil_pow2(step_bound + 1);
-  if ((double)W * H * mp.step_cap >= 4294967295.0) {
-    set_last_error("image size x ray steps exceeds the 32-bit allocation order key");
-    return DSLAM_ERR_UNSUPPORTED;
-  }
+  if ((rc = alloc_step_cap(s, W, H, &mp.step_cap))) return rc;
   int cap_shift = 0;
   while ((1 << cap_shift) < mp.step_cap) cap_shift++;
 
@@ -969,6 +977,7 @@ int launch_allocate(dslam_engine *e, dslam_scene *s, const dslam_view *v, dslam_
   if (++e->epoch == 0) e->epoch = 1;
   sp.epoch = e->epoch;
   const int grid = n_tiles;   // one tile per workgroup, one ticket each
+  (void)tickets_ok(e);
   sp.ticket = e->ticket; sp.ticket_base = e->ticket_base;
   e->ticket_base += (unsigned)grid;
   sp.gen = r->gen;
@@ -995,7 +1004,7 @@ int launch_allocate(dslam_engine *e, dslam_scene *s, const dslam_view *v, dslam_
   }
   if (s->p.use_swapping) {
     SelNeedsBlock sel{s->hash, s->alloc_list, s->alloc_bits, s->counters};
-    launch_bits_select(e, r->vis_bits, N, sel, (int *)nullptr, N, (int *)nullptr, &s->counters->error_flags);
+    launch_bits_select(e, r->vis_bits, N, sel, (int *)nullptr, N, (int *)nullptr, s->counters);
   }
   DSLAM_HIP(hipGetLastError());
   return DSLAM_OK;

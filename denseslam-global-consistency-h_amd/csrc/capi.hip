@@ -18,7 +18,10 @@ namespace dslam {
 
 static thread_local std::string g_last_error;
 void set_last_error(const std::string &msg) { g_last_error = msg; }
+static std::atomic<unsigned long long> g_hip_failures{0};
+unsigned long long hip_failure_count() { return g_hip_failures.load(std::memory_order_relaxed); }
 int hip_fail(hipError_t err, const char *what, const char *file, int line) {
+  g_hip_failures.fetch_add(1, std::memory_order_relaxed);
   char buf[512];
   snprintf(buf, sizeof(buf), "%s failed: %s (%s:%d)", what, hipGetErrorString(err), file, line);
   g_last_error = buf;
@@ -73,8 +76,43 @@ unsigned long long next_map_version() {
   return ++counter;
 }
 
+// Every entry point that waits for the stream ends here: what a kernel reported through report_error (a tile count that
+// never arrived, an allocation ray longer than the order key encodes) is returned by the first call that could know --
+// the call itself on a synchronous engine, the next synchronising call (fence wait, read-back, dslam_engine_synchronize)
+// on an asynchronous one.  Told once per occurrence; the scene's own flags stay set for dslam_get_stats.
+int sync_check(dslam_engine *e) {
+  DSLAM_HIP(hipStreamSynchronize(e->stream));
+  return device_errors(e);
+}
+int device_errors(dslam_engine *e) {
+  volatile int *h = e->err_host;
+  const int flags = h ? *h : 0;
+  if (flags == 0) return DSLAM_OK;
+  *h = 0;
+  if (flags & 2) {
+    set_last_error("a tile count of an ordered compaction never arrived (device made no progress?): the map state is undefined");
+    return DSLAM_ERR_HIP;
+  }
+  set_last_error("allocation ray needed more steps than the order key encodes (non-rigid pose or mu/voxel_size changed?)");
+  return DSLAM_ERR_UNSUPPORTED;
+}
+
 int finish_call(dslam_engine *e) {
-  if (!e->async_mode) DSLAM_HIP(hipStreamSynchronize(e->stream));
+  if (!e->async_mode) return sync_check(e);
+  return DSLAM_OK;
+}
+
+int tickets_resync(dslam_engine *e) {
+  const unsigned long long seen = hip_failure_count();
+  unsigned host[2] = {0, 0};
+  if (hipStreamSynchronize(e->stream) != hipSuccess || hipMemcpy(host, e->ticket, sizeof(host), hipMemcpyDeviceToHost) != hipSuccess) {
+    (void)hipGetLastError();
+    set_last_error("ticket counters could not be read back after a HIP failure");
+    return DSLAM_ERR_HIP;   // (hip_failures_seen stays behind: the next pass tries again)
+  }
+  e->ticket_base = host[0];
+  e->ticket_base2 = host[1];
+  e->hip_failures_seen = seen;
   return DSLAM_OK;
 }
 
@@ -173,6 +211,9 @@ static int engine_allocate(dslam_engine *e) {
   DSLAM_HIP(hipMalloc(&e->ticket, 16 * sizeof(unsigned)));
   DSLAM_HIP(hipMemset(e->ticket, 0, 16 * sizeof(unsigned)));
   e->ticket_base = 0;
+  e->hip_failures_seen = hip_failure_count();
+  DSLAM_HIP(hipHostMalloc((void **)&e->err_host, 64, hipHostMallocDefault));
+  *e->err_host = 0;
   return DSLAM_OK;
 }
 
@@ -213,6 +254,7 @@ int dslam_engine_destroy(dslam_engine *e) {
   if (e->staging_dev) (void)hipFree(e->staging_dev);
   if (e->staging_host) (void)hipHostFree(e->staging_host);
   if (e->pinned) (void)hipHostFree(e->pinned);
+  if (e->err_host) (void)hipHostFree(e->err_host);
   if (e->timer_counts_dev) (void)hipFree(e->timer_counts_dev);
   free_dev(e->misc_counter);
   free_dev(e->mesh_positions); free_dev(e->mesh_colours);
@@ -252,8 +294,7 @@ int dslam_engine_set_async(dslam_engine *e, int async_mode) {
 }
 int dslam_engine_synchronize(dslam_engine *e) {
   DSLAM_REQUIRE(e, "null engine");
-  DSLAM_HIP(hipStreamSynchronize(e->stream));  // (every pipelined upload is waited for by a kernel of this stream)
-  return DSLAM_OK;
+  return sync_check(e);  // (every pipelined upload is waited for by a kernel of this stream)
 }
 
 // ---- fences --------------------------------------------------------------------------------------------------
@@ -300,7 +341,7 @@ int dslam_fence_record(dslam_engine *e, dslam_fence *f) {
 int dslam_fence_wait(dslam_fence *f) {
   DSLAM_REQUIRE(f, "null fence");
   if (f->recorded) DSLAM_HIP(hipEventSynchronize(f->ev));
-  return DSLAM_OK;
+  return f->engine ? device_errors(f->engine) : DSLAM_OK;   // (what kernels in front of the fence reported, see sync_check)
 }
 int dslam_fence_query(dslam_fence *f, int *done) {
   DSLAM_REQUIRE(f && done, "null argument");
@@ -866,10 +907,11 @@ static const size_t kListHeader = 64;  // (a RenderCounters-shaped count block, 
 
 int dslam_frame_store_enable_lists(dslam_engine *e, dslam_frame_store *fs, const dslam_scene *s) {
   DSLAM_REQUIRE(e && fs && s && fs->engine == e, "bad argument");
-  if (fs->lists && fs->list_cap >= s->p.num_local_blocks) return DSLAM_OK;
+  if (fs->lists && fs->list_cap >= s->p.num_local_blocks && fs->list_entries == s->n_entries) return DSLAM_OK;
   DSLAM_HIP(hipStreamSynchronize(e->stream));
   free_dev(fs->lists);
   fs->list_cap = s->p.num_local_blocks;
+  fs->list_entries = s->n_entries;   // the lists hold entry ids of a table of this size (checked wherever a list is read)
   fs->list_bytes = (kListHeader + (size_t)fs->list_cap * (sizeof(int) + sizeof(short4)) + 255) & ~(size_t)255;
   DSLAM_HIP(hipMalloc(&fs->lists, fs->list_bytes * fs->capacity));
   fs->has_list.assign(fs->capacity, 0);
@@ -888,6 +930,7 @@ int dslam_frame_store_put_visible_list(dslam_engine *e, dslam_frame_store *fs, i
   if (rc) return rc;
   DSLAM_REQUIRE(s && r && fs->lists, "dslam_frame_store_enable_lists has not been called");
   DSLAM_REQUIRE(fs->list_cap >= r->n_local, "the store's lists are smaller than this render state's visible list");
+  DSLAM_REQUIRE(fs->list_entries == s->n_entries && r->n_entries == s->n_entries, "the store's lists were enabled for a table of another size");
   unsigned char *base = list_slot(fs, slot);
   rc = launch_store_visible_list(e, s, r, base, reinterpret_cast<int *>(base + kListHeader),
                                  reinterpret_cast<short4 *>(base + kListHeader + (size_t)fs->list_cap * sizeof(int)), fs->list_cap);
@@ -903,6 +946,7 @@ int dslam_deprocess_frame_stored(dslam_engine *e, dslam_scene *s, const dslam_vi
   DSLAM_REQUIRE(s && v && M_d && intr_d && s->engine == e && v->engine == e, "bad argument");
   e->view_reads++;  // (see dslam_engine::last_fence)
   DSLAM_REQUIRE(fs->lists && fs->has_list[slot], "no visible list was stored for this keyframe slot");
+  DSLAM_REQUIRE(fs->list_entries == s->n_entries, "the stored list belongs to a table of another size");   // (its ids index this scene's table)
   s->version = next_map_version();  // the map changes: GetImage memos of this scene are stale
   const unsigned char *base = list_slot(fs, slot);
   rc = launch_integrate_list(e, s, v, base, reinterpret_cast<const int *>(base + kListHeader),
@@ -924,6 +968,18 @@ struct HostBatchList {          // = BatchListRef
   const void *count, *ids, *pos;
 };
 }  // namespace
+
+// A batch that stops after its first mutation (only a HIP failure can do that: every argument was checked before) leaves
+// allocation passes applied whose blocks were never de- or re-integrated: the map is neither the old nor the new one.
+// The header says so; what can be kept consistent is: the render state's list is re-derived by its next pass, and the
+// keyframes of the chunk lose their stored lists (a later batch refuses them instead of de-integrating from stale lists).
+static int batch_failed(dslam_scene *s, dslam_render_state *r, dslam_frame_store *fs, const int32_t *slots, int K, int rc) {
+  s->alloc_born = nullptr;
+  r->types_follow_list = false;
+  r->memo_valid = false;
+  for (int k = 0; k < K; k++) fs->has_list[slots[k]] = 0;
+  return rc;
+}
 
 static int batch_scratch(dslam_engine *e, dslam_scene *s, dslam_frame_store *fs) {
   const size_t L = (size_t)s->p.num_local_blocks;
@@ -958,6 +1014,7 @@ int dslam_reintegrate_batch(dslam_engine *e, dslam_scene *s, dslam_view *v, dsla
   DSLAM_REQUIRE(fs->lists, "dslam_frame_store_enable_lists has not been called");
   DSLAM_REQUIRE(v->w_rgb == fs->w_rgb && v->h_rgb == fs->h_rgb && v->w_d == fs->w_d && v->h_d == fs->h_d, "view and frame store sizes differ");
   DSLAM_REQUIRE(fs->list_cap >= r->n_local, "the store's lists are smaller than this render state's visible list");
+  DSLAM_REQUIRE(fs->list_entries == s->n_entries && r->n_entries == s->n_entries, "the store's lists / the render state belong to a table of another size");
   if (s->p.use_swapping || s->p.stop_integrating_at_max_w || v->w_rgb != v->w_d || v->h_rgb != v->h_d) {
     set_last_error("dslam_reintegrate_batch: scenes with host swapping or stopIntegratingAtMaxW and views with a separate colour "
                    "camera take the per-keyframe calls (dslam_deprocess_frame_stored + dslam_process_frame)");
@@ -968,8 +1025,16 @@ int dslam_reintegrate_batch(dslam_engine *e, dslam_scene *s, dslam_view *v, dsla
     DSLAM_REQUIRE(fs->has_list[slots[k]], "no visible list was stored for a keyframe of the batch");
     for (int j = 0; j < k; j++) DSLAM_REQUIRE(slots[j] != slots[k], "a keyframe appears twice in the batch");
   }
+  // everything that can be refused is refused here, before anything changes: what launch_allocate checks per pass
+  // (table size above, an invertible pose, the order key's range) for every keyframe of the batch
+  for (int k = 0; k < n; k++) {
+    float inv[16];
+    if (!invert_matrix(new_M + 16 * (size_t)k, inv)) { set_last_error("dslam_reintegrate_batch: a new pose matrix is singular"); return DSLAM_ERR_INVALID; }
+  }
+  { int cap; const int rc_cap = alloc_step_cap(s, v->w_d, v->h_d, &cap); if (rc_cap) return rc_cap; }
   int rc = batch_scratch(e, s, fs);   // (n = 0: a set-up call -- the buffers exist before the first batch needs them)
   if (rc) return rc;
+  if ((rc = ensure_scratch(e, s->n_entries, s->p.num_local_blocks))) return rc;
   if (n == 0) return DSLAM_OK;
   e->view_reads++;  // (see dslam_engine::last_fence)
   s->version = next_map_version();  // the map changes: GetImage memos of this scene are stale
@@ -1019,18 +1084,19 @@ int dslam_reintegrate_batch(dslam_engine *e, dslam_scene *s, dslam_view *v, dsla
       lists[2 * k + 1] = {nb, nb + ids_off, nullptr};
     }
     s->alloc_born = nullptr;
-    if (rc) return rc;
+    if (rc) return batch_failed(s, r, fs, slots + first, K, rc);
     // phase 2: which operations touch which block, then every touched block once
     DSLAM_HIP(hipMemcpyAsync(s->batch_ops_dev, ops, 2 * (size_t)K * sizeof(HostBatchOp), hipMemcpyHostToDevice, e->stream));
     DSLAM_HIP(hipMemcpyAsync(s->batch_lists_dev, lists, 3 * (size_t)K * sizeof(HostBatchList), hipMemcpyHostToDevice, e->stream));
     DSLAM_HIP(hipEventRecord(s->batch_staging_ev, e->stream));
     if ((rc = launch_batch_ops(e, s->batch_lists_dev, 2 * K, s, s->batch_born, s->batch_marks, s->batch_opmask, s->batch_slot_entry,
                                s->batch_order, s->batch_counters)))
-      return rc;
+      return batch_failed(s, r, fs, slots + first, K, rc);
     if ((rc = launch_reintegrate_blocks(e, s, v->w_d, v->h_d, v->w_rgb, v->h_rgb, intr, affine_a, affine_b, s->batch_ops_dev,
                                         s->batch_opmask, s->batch_slot_entry, s->batch_order, s->batch_counters, 1, 2 * K)))
-      return rc;
-    if ((rc = launch_store_list_positions(e, s, reinterpret_cast<const HostBatchList *>(s->batch_lists_dev) + 2 * K, n_pos_jobs))) return rc;
+      return batch_failed(s, r, fs, slots + first, K, rc);
+    if ((rc = launch_store_list_positions(e, s, reinterpret_cast<const HostBatchList *>(s->batch_lists_dev) + 2 * K, n_pos_jobs)))
+      return batch_failed(s, r, fs, slots + first, K, rc);
     // the lists of the re-fusions become the keyframes' stored lists: the buffers trade places
     for (int k = 0; k < K; k++) std::swap(fs->list_ptr[slots[first + k]], fs->batch_list_ptr[k]);
   }
@@ -1263,8 +1329,7 @@ static int image_out(dslam_engine *e, dslam_render_state *r, int type, uint8_t *
       DSLAM_REQUIRE(out_rgba, "this image type renders into the rgba output");
       DSLAM_HIP(hipMemcpyAsync(out_rgba, r->image_rgba, npix * 4, hipMemcpyDeviceToHost, e->stream));
     }
-    DSLAM_HIP(hipStreamSynchronize(e->stream));  // host buffers are valid on return
-    return DSLAM_OK;
+    return sync_check(e);  // host buffers are valid on return
   }
   return finish_call(e);
 }
@@ -1328,8 +1393,7 @@ int dslam_get_depth_image_int16(dslam_engine *e, const dslam_scene *s, dslam_ren
   short *tmp = reinterpret_cast<short *>(r->image_rgba);
   if ((rc = launch_depth_to_int16(e, r->image_float, tmp, n, scale))) return rc;
   DSLAM_HIP(hipMemcpyAsync(out_host, tmp, (size_t)n * 2, hipMemcpyDeviceToHost, e->stream));
-  DSLAM_HIP(hipStreamSynchronize(e->stream));
-  return DSLAM_OK;
+  return sync_check(e);
 }
 
 int dslam_create_icp_maps(dslam_engine *e, const dslam_scene *s, dslam_render_state *r, const float M[16],
@@ -1342,7 +1406,7 @@ int dslam_create_icp_maps(dslam_engine *e, const dslam_scene *s, dslam_render_st
   const size_t bytes = (size_t)r->w * r->h * sizeof(float4);
   if (out_points) DSLAM_HIP(hipMemcpyAsync(out_points, r->icp_points, bytes, hipMemcpyDeviceToHost, e->stream));
   if (out_normals) DSLAM_HIP(hipMemcpyAsync(out_normals, r->icp_normals, bytes, hipMemcpyDeviceToHost, e->stream));
-  if (out_points || out_normals) { DSLAM_HIP(hipStreamSynchronize(e->stream)); return DSLAM_OK; }
+  if (out_points || out_normals) return sync_check(e);
   return finish_call(e);
 }
 
@@ -1350,8 +1414,7 @@ int dslam_download_raycast_image(dslam_engine *e, const dslam_render_state *r, u
   DSLAM_REQUIRE(e && r && out_rgba, "null argument");
   DSLAM_REQUIRE(r->raycast_image, "dslam_create_icp_maps has not run on this render state");
   DSLAM_HIP(hipMemcpyAsync(out_rgba, r->raycast_image, (size_t)r->w * r->h * 4, hipMemcpyDeviceToHost, e->stream));
-  DSLAM_HIP(hipStreamSynchronize(e->stream));
-  return DSLAM_OK;
+  return sync_check(e);
 }
 
 int dslam_download_icp_maps(dslam_engine *e, const dslam_render_state *r, float *out_points, float *out_normals) {
@@ -1360,8 +1423,7 @@ int dslam_download_icp_maps(dslam_engine *e, const dslam_render_state *r, float 
   const size_t bytes = (size_t)r->w * r->h * sizeof(float4);
   if (out_points) DSLAM_HIP(hipMemcpyAsync(out_points, r->icp_points, bytes, hipMemcpyDeviceToHost, e->stream));
   if (out_normals) DSLAM_HIP(hipMemcpyAsync(out_normals, r->icp_normals, bytes, hipMemcpyDeviceToHost, e->stream));
-  DSLAM_HIP(hipStreamSynchronize(e->stream));
-  return DSLAM_OK;
+  return sync_check(e);
 }
 
 // ---- meshing export --------------------------------------------------------------------------------------------
@@ -1382,8 +1444,7 @@ int dslam_mesh_download(dslam_engine *e, float *out_positions, float *out_colour
     DSLAM_HIP(hipMemcpyAsync(out_positions, e->mesh_positions, bytes, hipMemcpyDeviceToHost, e->stream));
     if (out_colours) DSLAM_HIP(hipMemcpyAsync(out_colours, e->mesh_colours, bytes, hipMemcpyDeviceToHost, e->stream));
   }
-  DSLAM_HIP(hipStreamSynchronize(e->stream));
-  return DSLAM_OK;
+  return sync_check(e);
 }
 
 // ---- read-back -----------------------------------------------------------------------------------------------
@@ -1394,7 +1455,7 @@ int dslam_get_stats(dslam_engine *e, const dslam_scene *s, const dslam_render_st
   RenderCounters *rc = reinterpret_cast<RenderCounters *>(host + 128);
   DSLAM_HIP(hipMemcpyAsync(sc, s->counters, sizeof(SceneCounters), hipMemcpyDeviceToHost, e->stream));
   if (r) DSLAM_HIP(hipMemcpyAsync(rc, r->counters, sizeof(RenderCounters), hipMemcpyDeviceToHost, e->stream));
-  DSLAM_HIP(hipStreamSynchronize(e->stream));
+  const int rc_engine = sync_check(e);   // (what any scene of the engine reported since the last synchronising call)
   memset(out, 0, sizeof(*out));
   out->num_allocated_blocks = s->p.num_local_blocks;
   out->last_free_block_id = sc->last_free;
@@ -1416,13 +1477,12 @@ int dslam_get_stats(dslam_engine *e, const dslam_scene *s, const dslam_render_st
     set_last_error("allocation ray needed more steps than the order key encodes (non-rigid pose or mu/voxel_size changed?)");
     return DSLAM_ERR_UNSUPPORTED;
   }
-  return DSLAM_OK;
+  return rc_engine;
 }
 
 static int d2h(dslam_engine *e, void *dst, const void *src, size_t bytes) {
   DSLAM_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, e->stream));
-  DSLAM_HIP(hipStreamSynchronize(e->stream));
-  return DSLAM_OK;
+  return sync_check(e);
 }
 static int h2d(dslam_engine *e, void *dst, const void *src, size_t bytes) {
   DSLAM_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, e->stream));
@@ -1549,6 +1609,13 @@ int dslam_upload_visible_ids(dslam_engine *e, dslam_render_state *r, const int32
 
 void *dslam_scene_voxel_blocks_dev(dslam_scene *s) { return s ? s->voxels : nullptr; }
 void *dslam_scene_hash_table_dev(dslam_scene *s) { return s ? s->hash : nullptr; }
+int dslam_scene_table_changed(dslam_engine *e, dslam_scene *s) {
+  DSLAM_REQUIRE(e && s && s->engine == e, "null argument");
+  s->version = next_map_version();  // the map changed: GetImage memos of this scene are stale
+  int rc = launch_build_alloc_bits(e, s);
+  if (rc) return rc;
+  return finish_call(e);
+}
 void *dslam_render_state_image_dev(dslam_render_state *r, int want_float) {
   if (!r) return nullptr;
   return want_float ? (void *)r->image_float : (void *)r->image_rgba;

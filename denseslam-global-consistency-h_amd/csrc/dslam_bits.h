@@ -96,6 +96,7 @@ static __device__ __forceinline__ void publish1(unsigned long long *agg, int til
 inline TileChain next_chain(dslam_engine *e, int n_tiles, int *grid_out, bool second = false) {
   TileChain ch;
   ch.dbg = nullptr;
+  (void)tickets_ok(e);   // (after a HIP failure anywhere in the process: bases re-read from the device)
   if (++e->epoch == 0) e->epoch = 1;
   ch.agg = second ? e->agg + e->agg_tiles : e->agg;
   ch.epoch = e->epoch;
@@ -129,7 +130,7 @@ inline TileChain next_chain(dslam_engine *e, int n_tiles, int *grid_out, bool se
 template <class Sel>
 __global__ __launch_bounds__(kSelThreads) void k_bits_select(const unsigned *__restrict__ src_bits, Sel sel, int *__restrict__ out,
                                                              int capacity, int *total_out, int *tile_sum_out, TileChain ch,
-                                                             int *error_flags) {
+                                                             SceneCounters *err_cnt) {
   constexpr int kWaves = kSelThreads / 64;
   constexpr int kTileEntries = kSelTileWords * 32;
   constexpr int kRounds = (kTileEntries + kSelThreads * kSelBatch - 1) / (kSelThreads * kSelBatch);
@@ -140,7 +141,7 @@ __global__ __launch_bounds__(kSelThreads) void k_bits_select(const unsigned *__r
   __shared__ int s_pref[kTileEntries / 32];
   const unsigned long long t_start = ch.dbg ? __builtin_amdgcn_s_memtime() : 0ull;
   const int b = take_ticket(ch.ticket, ch.ticket_base, &s_ticket);
-  if (b >= ch.n_tiles) return;
+  if ((unsigned)b >= (unsigned)ch.n_tiles) return;   // (unsigned: a ticket in front of the host's base must not index anything)
 #define DSLAM_SEL_STAMP(i) do { if (ch.dbg && threadIdx.x == 0) ch.dbg[(size_t)b * 8 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
   if (ch.dbg && threadIdx.x == 0) ch.dbg[(size_t)b * 8] = t_start;
   DSLAM_SEL_STAMP(1);
@@ -223,7 +224,7 @@ __global__ __launch_bounds__(kSelThreads) void k_bits_select(const unsigned *__r
     }
   }
   int before;
-  if (!lookback1<kSelThreads>(ch.agg, b, ch.epoch, red, before) && tid == 0 && error_flags) atomicOr(error_flags, 2);
+  if (!lookback1<kSelThreads>(ch.agg, b, ch.epoch, red, before) && tid == 0 && err_cnt) report_error(err_cnt, 2);
   DSLAM_SEL_STAMP(6);
   // ---- emit -----------------------------------------------------------------------------------------------------------------
   int sum = 0;
@@ -270,10 +271,10 @@ __global__ __launch_bounds__(kSelThreads) void k_bits_select(const unsigned *__r
 }
 
 // out[0 .. min(total, capacity)) = the selected entries, ascending; *total_out = min(total, capacity).
-// error_flags: bit 1 is set if a tile count never arrived (bounded spin; dslam_get_stats reports it)
+// err_cnt: error bit 1 is reported there if a tile count never arrived (bounded spin; report_error, dslam_device.h)
 template <class Sel>
 inline void launch_bits_select(dslam_engine *e, const unsigned *src_bits, int n_entries, const Sel &sel, int *out, int capacity,
-                               int *total_out, int *error_flags, int *tile_sum_out = nullptr) {
+                               int *total_out, SceneCounters *err_cnt, int *tile_sum_out = nullptr) {
   const int n_words = bit_tiles(n_entries) * kBitTileWords;
   int grid;
   TileChain ch = next_chain(e, n_words / kSelTileWords, &grid);
@@ -286,7 +287,7 @@ inline void launch_bits_select(dslam_engine *e, const unsigned *src_bits, int n_
     ch.dbg = dbg_host;
   }
   hipLaunchKernelGGL(k_bits_select<Sel>, dim3(grid), dim3(kSelThreads), 0, e->stream, src_bits, sel, out, capacity, total_out,
-                     tile_sum_out, ch, error_flags);
+                     tile_sum_out, ch, err_cnt);
   if (dbg_host) {
     (void)hipStreamSynchronize(e->stream);
     if (FILE *f = fopen(dbg_file, "wb")) { fwrite(dbg_host, 64, grid, f); fclose(f); }

@@ -60,7 +60,17 @@ struct SceneCounters {
   int swapped_in;       // blocks merged from / written to the host store by the last swap-in / swap-out
   int swapped_out;
   int pad;
+  int *err_host;        // the engine's page-locked error word (dslam_engine::err_host): report_error() stores there too
 };
+
+// A kernel reports a condition the host must hear about: sticky in the scene's counters (dslam_get_stats), and -- so that
+// a caller that pipelines calls and never asks for stats still learns of it -- in the engine's page-locked error word,
+// which every synchronising entry point looks at once the stream has drained (capi.hip sync_check).  Error paths only.
+__device__ __forceinline__ void report_error(SceneCounters *cnt, int bits) {
+  atomicOr(&cnt->error_flags, bits);
+  int *h = cnt->err_host;
+  if (h) __hip_atomic_store(h, bits | __hip_atomic_load(h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
 
 struct RenderCounters {
   int no_visible;       // ITMRenderState_VH::noVisibleEntries

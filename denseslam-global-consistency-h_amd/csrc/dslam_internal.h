@@ -70,6 +70,11 @@ struct dslam_engine {
   unsigned *ticket = nullptr;         // device [16]: counter k is ticket + k
   unsigned ticket_base = 0;           // counter 0
   unsigned ticket_base2 = 0;          // counter 1 (a second, independent chain inside the same launch)
+  unsigned long long hip_failures_seen = 0;  // ... which is only as good as the launches that were accepted: after any HIP
+                                      // failure of the process the bases are read back from the device (tickets_resync)
+  // what kernels could not tell anybody (report_error, dslam_device.h): one page-locked word, looked at by every entry
+  // point that waits for the stream (sync_check).  Sticky per scene in SceneCounters::error_flags; here: told once.
+  int *err_host = nullptr;
   // single-pass ordered compactions: per-tile aggregates published inside one launch ({epoch, counts} in one 8-byte
   // word per tile; three channels: allocation requests, commit results, visible counts) and the launch counter that
   // tags them, so the arrays never need clearing
@@ -253,6 +258,7 @@ struct dslam_frame_store {
   // [RenderCounters-sized header: count][int ids[list_cap]][short4 pos[list_cap]]
   unsigned char *lists = nullptr;
   int list_cap = 0;
+  int list_entries = 0;   // hash-table size (entries) of the scene the lists were enabled for: their ids index that table
   size_t list_bytes = 0;  // per slot
   std::vector<unsigned char> has_list;
   // where each slot's list lives: a buffer of `lists`, or -- after a re-integration batch, which writes the lists of its
@@ -304,6 +310,7 @@ int launch_batch_ops(dslam_engine *e, const void *lists_dev, int n_ops, const ds
 int launch_reintegrate_blocks(dslam_engine *e, dslam_scene *s, int w_d, int h_d, int w_rgb, int h_rgb, const float *intr,
                               float a, float b, const void *ops_dev, const unsigned long long *opmask, const int *slot_entry,
                               const int *cls_list, const int *cls_count, int push_ring, int n_ops);
+int alloc_step_cap(const dslam_scene *s, int W, int H, int *cap_out);
 int ensure_view_depth(dslam_engine *e, const dslam_view *v);
 int launch_selftest_division(dslam_engine *e, long long samples, unsigned long long *mismatches_dev);
 int prepare_push_visible_list(dslam_engine *e, dslam_scene *s, int q, int *bit_out, int *frame_out);
@@ -332,5 +339,14 @@ int launch_dirty_pack(dslam_engine *e, const dslam_scene *s, int shard, void *se
 int launch_dirty_unpack(dslam_engine *e, dslam_scene *s, int skip_shard, const void *recv_dev, int stride_blocks);
 int ensure_scratch(dslam_engine *e, int entries, int local_blocks);
 int finish_call(dslam_engine *e);  // synchronise unless the engine is in async mode
+int device_errors(dslam_engine *e);  // report (once) what kernels left in dslam_engine::err_host
+int sync_check(dslam_engine *e);   // wait for the engine's stream, then report what kernels left in dslam_engine::err_host
+// The host advances its copy of the ticket counters when it enqueues a launch.  A launch the runtime rejected never moves the
+// device counters, and every later ticket would then lie in front of its base (the kernels compare unsigned, so such a
+// launch does nothing instead of indexing with a negative tile -- but it does nothing).  Any HIP failure bumps a process-
+// wide count (hip_fail); an engine that sees a new value drains its stream and reads the counters back.
+unsigned long long hip_failure_count();
+int tickets_resync(dslam_engine *e);
+inline int tickets_ok(dslam_engine *e) { return e->hip_failures_seen == hip_failure_count() ? DSLAM_OK : tickets_resync(e); }
 inline int num_tiles(int entries) { return (entries + kTileEntries - 1) / kTileEntries; }
 }  // namespace dslam

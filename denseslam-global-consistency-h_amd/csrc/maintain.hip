@@ -151,12 +151,12 @@ __global__ __launch_bounds__(256) void k_decay_blocks(const int *__restrict__ ca
 // leave.  Consumes (clears) the flags.
 __global__ __launch_bounds__(256) void k_compact_candidates(const int *__restrict__ cand, const int *count_ptr,
                                                             unsigned char *flag, int *__restrict__ out, int *total_out,
-                                                            TileChain ch, int *error_flags) {
+                                                            TileChain ch, SceneCounters *err_cnt) {
   __shared__ int red[8];
   __shared__ int s_ticket;
   const int n = __builtin_amdgcn_readfirstlane(*count_ptr);
   const int b = take_ticket(ch.ticket, ch.ticket_base, &s_ticket);   // (one tile per workgroup)
-  if (b >= ch.n_tiles) return;
+  if ((unsigned)b >= (unsigned)ch.n_tiles) return;   // (unsigned: see take_ticket)
   {
     const int i0 = b * kSweepTile + threadIdx.x * kSweepPer;
     unsigned m = 0;
@@ -178,7 +178,7 @@ __global__ __launch_bounds__(256) void k_compact_candidates(const int *__restric
     const bool last = b == ch.n_tiles - 1;
     if (tot > 0 || last) {
       int offset;
-      if (!lookback1(ch.agg, b, ch.epoch, red, offset) && threadIdx.x == 0) atomicOr(error_flags, 2);
+      if (!lookback1(ch.agg, b, ch.epoch, red, offset) && threadIdx.x == 0) report_error(err_cnt, 2);
       if (last && threadIdx.x == 0) *total_out = offset + tot;
       r += offset;
       for (; m; m &= m - 1) out[r++] = cand[i0 + __ffs((int)m) - 1];
@@ -307,7 +307,7 @@ __device__ __forceinline__ void push_freed_job(unsigned char *freed_flags, int n
   const int removed = __builtin_amdgcn_readfirstlane(cnt->remove_count);
   const int base_ex = __builtin_amdgcn_readfirstlane(cnt->last_free_ex);
   const int b = take_ticket(ch.ticket, ch.ticket_base, &s_ticket);   // (one tile per workgroup)
-  if (removed == 0 || b >= ch.n_tiles) return;  // (nothing was released: no slot came free and no flag is set)
+  if (removed == 0 || (unsigned)b >= (unsigned)ch.n_tiles) return;  // (nothing was released: no slot came free and no flag is set)
   {
     const int i0 = b * kSweepTile + threadIdx.x * kSweepPer;
     unsigned m = 0;
@@ -329,7 +329,7 @@ __device__ __forceinline__ void push_freed_job(unsigned char *freed_flags, int n
     const bool last = b == ch.n_tiles - 1;
     if (tot > 0 || last) {
       int offset;
-      if (!lookback1(ch.agg, b, ch.epoch, red, offset) && threadIdx.x == 0) atomicOr(&cnt->error_flags, 2);
+      if (!lookback1(ch.agg, b, ch.epoch, red, offset) && threadIdx.x == 0) report_error(cnt, 2);
       r += offset + base_ex + 1;
       for (; m; m &= m - 1) excess_list[r++] = i0 + __ffs((int)m) - 1;
       if (last) {
@@ -374,7 +374,7 @@ __device__ __forceinline__ void rebuild_visible_job(const RebuildParams &q, cons
   // (every workgroup reads the flag before it takes its tile, hence before anything is published; the last tile re-arms it)
   const bool open = q.force || __builtin_amdgcn_readfirstlane(q.maint_flags[0]) != 0;
   const int b = take_ticket(ch.ticket, ch.ticket_base, &s_ticket);
-  if (!open || b >= ch.n_tiles) return;
+  if (!open || (unsigned)b >= (unsigned)ch.n_tiles) return;
   const unsigned w = q.vis_bits[b * kCompactTileWords + threadIdx.x];
   int tot;
   const int rank = block_excl_scan<4>(__popc(w), red, tot);
@@ -382,7 +382,7 @@ __device__ __forceinline__ void rebuild_visible_job(const RebuildParams &q, cons
   const bool last = b == ch.n_tiles - 1;
   if (tot == 0 && !last) return;
   int before;
-  if (!lookback1(ch.agg, b, ch.epoch, red, before) && threadIdx.x == 0 && q.cnt) atomicOr(&q.cnt->error_flags, 2);
+  if (!lookback1(ch.agg, b, ch.epoch, red, before) && threadIdx.x == 0 && q.cnt) report_error(q.cnt, 2);
   expand_bits(w, threadIdx.x * 32, rank, s_list);
   __syncthreads();
   const int t0 = b * (kCompactTileWords * 32);
@@ -497,7 +497,7 @@ static int decay_candidates(dslam_engine *e, dslam_scene *s, dslam_render_state 
     int grid;
     const TileChain ch = next_chain(e, (s->p.num_local_blocks + kSweepTile - 1) / kSweepTile, &grid);
     hipLaunchKernelGGL(k_compact_candidates, dim3(grid), dim3(256), 0, e->stream, m.cand_list, &s->counters->swap_count,
-                       m.rem_cand, m.rem_list, &s->counters->remove_count, ch, &s->counters->error_flags);
+                       m.rem_cand, m.rem_list, &s->counters->remove_count, ch, s->counters);
   }
   dbg_sync(e, "k_compact_candidates");
   return release_listed(e, s, r, m, 0);
@@ -517,14 +517,14 @@ int launch_decay(dslam_engine *e, dslam_scene *s, dslam_render_state *r, int max
     int k = s->decay_cursor[q] > s->ring_head[q] ? s->decay_cursor[q] : s->ring_head[q];
     for (; k <= newest - min_age; k++) {
       SelDecayAged sel{s->hash, s->masks, s->history_words, q, k % bits};
-      launch_bits_select(e, s->alloc_bits, N, sel, m.cand_list, s->p.num_local_blocks, &s->counters->swap_count, &s->counters->error_flags);
+      launch_bits_select(e, s->alloc_bits, N, sel, m.cand_list, s->p.num_local_blocks, &s->counters->swap_count, s->counters);
       if ((rc = decay_candidates(e, s, r, m, max_weight))) return rc;
     }
     if (k > s->decay_cursor[q]) s->decay_cursor[q] = k;
   } else {
     const int threshold = (s->frame_counter - 1) - min_age;
     SelDecaySweep sel{s->hash, s->last_seen, threshold};
-    launch_bits_select(e, s->alloc_bits, N, sel, m.cand_list, s->p.num_local_blocks, &s->counters->swap_count, &s->counters->error_flags);
+    launch_bits_select(e, s->alloc_bits, N, sel, m.cand_list, s->p.num_local_blocks, &s->counters->swap_count, s->counters);
     dbg_sync(e, "select decay sweep");
     if ((rc = decay_candidates(e, s, r, m, max_weight))) return rc;
   }
@@ -725,9 +725,9 @@ template <int MODE>
 static int swap_select(dslam_engine *e, dslam_scene *s, const unsigned char *vis_type, const MaintScratch &m) {
   const int N = s->n_entries;
   int *count = &s->counters->swap_count;
-  if (MODE == 0) launch_bits_select(e, s->swap1_bits, N, SelSwapPending{s->swap_state}, m.cand_list, kTransferBlocks, count, &s->counters->error_flags);
-  else if (MODE == 1) launch_bits_select(e, s->alloc_bits, N, SelSwapFresh{s->hash, s->swap_state}, m.cand_list, kTransferBlocks, count, &s->counters->error_flags);
-  else launch_bits_select(e, s->alloc_bits, N, SelSwapOut{s->hash, s->swap_state, vis_type}, m.cand_list, kTransferBlocks, count, &s->counters->error_flags);
+  if (MODE == 0) launch_bits_select(e, s->swap1_bits, N, SelSwapPending{s->swap_state}, m.cand_list, kTransferBlocks, count, s->counters);
+  else if (MODE == 1) launch_bits_select(e, s->alloc_bits, N, SelSwapFresh{s->hash, s->swap_state}, m.cand_list, kTransferBlocks, count, s->counters);
+  else launch_bits_select(e, s->alloc_bits, N, SelSwapOut{s->hash, s->swap_state, vis_type}, m.cand_list, kTransferBlocks, count, s->counters);
   DSLAM_HIP(hipGetLastError());
   return DSLAM_OK;
 }
@@ -861,14 +861,14 @@ int launch_slide_pop(dslam_engine *e, dslam_scene *s, dslam_render_state *r, int
   if (!s->p.use_swapping) {
     // released: the list and the release pipeline's removal flags come out of one selection
     SelSlidePop sel{s->hash, s->masks, s->history_words, q, bit, m.rem_flags};
-    launch_bits_select(e, s->alloc_bits, N, sel, m.rem_list, s->p.num_local_blocks, &s->counters->remove_count, &s->counters->error_flags);
+    launch_bits_select(e, s->alloc_bits, N, sel, m.rem_list, s->p.num_local_blocks, &s->counters->remove_count, s->counters);
     DSLAM_HIP(hipGetLastError());
     return release_listed(e, s, r, m, 1);
   }
 
   // scene with swapping: the blocks move to the host store, their entries stay (ptr = -1)
   SelSlidePop sel{s->hash, s->masks, s->history_words, q, bit, nullptr};
-  launch_bits_select(e, s->alloc_bits, N, sel, m.cand_list, s->p.num_local_blocks, &s->counters->swap_count, &s->counters->error_flags);
+  launch_bits_select(e, s->alloc_bits, N, sel, m.cand_list, s->p.num_local_blocks, &s->counters->swap_count, s->counters);
   DSLAM_HIP(hipGetLastError());
   int *host_count = reinterpret_cast<int *>(e->pinned) + 48;
   DSLAM_HIP(hipMemcpyAsync(host_count, &s->counters->swap_count, sizeof(int), hipMemcpyDeviceToHost, e->stream));

@@ -198,7 +198,7 @@ int launch_mesh_scene(dslam_engine *e, const dslam_scene *s, int max_triangles, 
   int rc = ensure_scratch(e, N, s->p.num_local_blocks);
   if (rc) return rc;
   int *live_count = e->misc_counter + 8, *total = e->misc_counter + 9;
-  launch_bits_select(e, s->alloc_bits, N, SelLive{s->hash}, e->list_a, N, live_count, &s->counters->error_flags);
+  launch_bits_select(e, s->alloc_bits, N, SelLive{s->hash}, e->list_a, N, live_count, s->counters);
   MeshParams p;
   p.hash = s->hash; p.voxels = s->voxels; p.num_buckets = s->p.num_buckets; p.mask = (unsigned)(s->p.num_buckets - 1);
   p.live_list = e->list_a; p.live_count = live_count; p.block_counts = e->list_b; p.block_offsets = e->list_c;

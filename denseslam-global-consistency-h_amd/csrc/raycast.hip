@@ -162,7 +162,7 @@ int launch_find_visible(dslam_engine *e, const dslam_scene *s, dslam_render_stat
   int rc = ensure_scratch(e, N, s->p.num_local_blocks);
   if (rc) return rc;
   SelFrustum<false> sel{s->hash, make_frustum_params(s, r, M, intr), nullptr, nullptr, nullptr, nullptr, 0};
-  launch_bits_select(e, s->alloc_bits, N, sel, r->visible_ids, r->n_local, &r->counters->no_visible, &s->counters->error_flags);
+  launch_bits_select(e, s->alloc_bits, N, sel, r->visible_ids, r->n_local, &r->counters->no_visible, s->counters);
   DSLAM_HIP(hipGetLastError());
   return DSLAM_OK;
 }
@@ -381,7 +381,7 @@ int launch_find_visible_and_depths(dslam_engine *e, const dslam_scene *s, dslam_
   int rc = ensure_scratch(e, N, s->p.num_local_blocks);
   if (rc) return rc;
   SelFrustum<true> sel{s->hash, make_frustum_params(s, r, M, intr), r->proj_boxes, r->proj_z, r->proj_req, r->range, r->w * r->h};
-  launch_bits_select(e, s->alloc_bits, N, sel, r->visible_ids, r->n_local, &r->counters->no_visible, &s->counters->error_flags, r->proj_wg_tiles);
+  launch_bits_select(e, s->alloc_bits, N, sel, r->visible_ids, r->n_local, &r->counters->no_visible, s->counters, r->proj_wg_tiles);
   return launch_fill_range(e, r, select_tiles(N));
 }
 

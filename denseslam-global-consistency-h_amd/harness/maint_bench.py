@@ -176,7 +176,8 @@ def main():
     eng.view_update(view, frames[-1][0], frames[-1][1])
     t = min(timed(eng, lambda: eng.allocate_scene_from_depth(scene, view, rs, M, wl.intr)) for _ in range(20))
     out["allocate_scene_from_depth"] = {"us": round(t, 1), "pixels_per_s": round(W * H / t * 1e6),
-                                        "table_bytes_swept": 2 * 16 * (0x100000 + 0x20000), "what": "A6: mark + commit + visible list (two sweeps of the 18.9 MB table)"}
+                                        "bitmap_bytes_walked": 5 * 4 * ((0x100000 + 0x20000 + 32767) // 32768) * 1024,
+                                        "what": "A6: k_mark (pixels + re-test of the previously visible entries) + k_alloc_sweep over five 147 KB bitmaps; the 18.9 MB table is not read as a whole"}
     # BASELINE configs[2]: the same keyframes with the sliding-window memory path switched on (SURVEY 8d's parameters:
     # Decay(maxWeight 3, minAge 30, forceAll) after every keyframe, window of 50 keyframes), with and without host
     # swapping; synchronous calls, one free-view depth raycast per keyframe, frames already on the device side of

@@ -6,6 +6,21 @@
 //           mActiveDataManger                                         InfiniTamDriver.h:133-157,189-241,276-308,363
 //   GetPrimaryLocalMap(), GetImage(out, outFloat, type, pose, intrinsics, localMap), SaveCurrSceneToMesh
 //                                                                      InfiniTamDriver.h:146,169; InfiniTamDriver.cpp:242-275
+//
+// How calls complete.  The reference's driver treats every ITMLib call as done when it returns, but it only ever LOOKS at
+// results in a few places: the image GetImage filled (InfiniTamDriver.cpp:242-250,269-277), the host mirrors view->rgb /
+// view->depth (InfiniTamDriver.h:217-218), the counters lastFreeBlockId / noVisibleEntries / GetDecayedBlockCount
+// (InfiniTamDriver.h:210,345,368), the tracked pose (:157-161), the mesh file (DenseSlam.cpp:641).  Between UpdateView,
+// IntegrateLocalMap, SlideWindow* and Decay (DenseSlam.cpp:210-232) it looks at nothing.  So the mirror runs the engine
+// asynchronously (dslam_engine_set_async): ProcessFrame, DeProcessFrame, Decay*, SlideWindow*, ResetScene, Prepare, the
+// swapping calls and the visualisation steps ENQUEUE their kernels and return; UpdateView waits only for its own upload
+// (which runs on the copy stream under the kernels enqueued before it; the caller may rewrite its images as soon as
+// it returns); everything that hands data to the host WAITS: GetImage, a counter read, GetData on a stale host mirror,
+// Track (per ICP iteration), MeshScene, CountVisibleBlocks.  What the device can only report late (dslam_fusion.h,
+// "conditions only the device can detect") is thrown by the first of those waiting calls.  A caller that observes
+// nothing between two waiting calls cannot tell the difference from the synchronous engine: same kernels, same order,
+// same stream.  DSLAM_MIRROR_SYNC=1 in the environment gives the synchronous engine back (every call waits), for A/B
+// measurements and debugging.
 // Header-only; link with -ldslam_fusion.
 #pragma once
 #include <cstdio>
@@ -32,14 +47,15 @@ template <class TVoxel, class TIndex> class ITMSwappingEngine {
   explicit ITMSwappingEngine(dslam_engine *e) : eng_(e) {}
   void IntegrateGlobalIntoLocal(ITMScene<TVoxel, TIndex> *scene, ITMRenderState *rs) {
     dslam_check(dslam_swap_in(eng_, scene->handle, rs ? rs->handle : nullptr), "dslam_swap_in");
+    scene->MarkCountersStale(rs);
   }
   void SaveToGlobalMemory(ITMScene<TVoxel, TIndex> *scene, ITMRenderState *rs) {
     dslam_check(dslam_swap_out(eng_, scene->handle, rs->handle), "dslam_swap_out");
-    scene->refreshCounters(eng_, rs);
+    scene->MarkCountersStale(rs);
   }
   void SaveToGlobalMemory(ITMScene<TVoxel, TIndex> *scene) {
     dslam_check(dslam_save_to_global_memory(eng_, scene->handle), "dslam_save_to_global_memory");
-    scene->refreshCounters(eng_, nullptr);
+    scene->MarkCountersStale();
   }
 };
 
@@ -48,7 +64,13 @@ class ITMDenseMapper {
   dslam_engine *eng_;
   const ITMRGBDCalib *calib_;
   ITMSwappingEngine<ITMVoxel, ITMVoxelIndex> *swappingEngine_;
-  long long decayedBlocks_;
+  // the scenes this mapper has worked on (GetDecayedBlockCount sums their device-resident counters when asked; scenes
+  // belong to the map manager, which lives as long as the engine that owns this mapper)
+  std::vector<const ITMScene<ITMVoxel, ITMVoxelIndex> *> scenes_;
+  void note(const ITMScene<ITMVoxel, ITMVoxelIndex> *scene) {
+    for (size_t i = 0; i < scenes_.size(); i++) if (scenes_[i] == scene) return;
+    scenes_.push_back(scene);
+  }
 
   void poseArgs(const ITMView *view, const ITMTrackingState *ts, Matrix4f &M_d, Matrix4f &M_rgb, Vector4f &kd, Vector4f &kr) const {
     M_d = ts->pose_d->GetM();
@@ -59,7 +81,7 @@ class ITMDenseMapper {
 
  public:
   ITMDenseMapper(dslam_engine *e, const ITMRGBDCalib *calib)
-      : eng_(e), calib_(calib), swappingEngine_(new ITMSwappingEngine<ITMVoxel, ITMVoxelIndex>(e)), decayedBlocks_(0) {}
+      : eng_(e), calib_(calib), swappingEngine_(new ITMSwappingEngine<ITMVoxel, ITMVoxelIndex>(e)) {}
   ~ITMDenseMapper() { delete swappingEngine_; }
 
   void SetFusionWeightParams(const WeightParams &p) {
@@ -68,7 +90,8 @@ class ITMDenseMapper {
   }
   void ResetScene(ITMScene<ITMVoxel, ITMVoxelIndex> *scene) {
     dslam_check(dslam_scene_reset(eng_, scene->handle), "dslam_scene_reset");
-    scene->refreshCounters(eng_, nullptr, &decayedBlocks_);
+    scene->MarkCountersStale();
+    note(scene);
   }
   void ProcessFrame(const ITMView *view, const ITMTrackingState *ts, ITMScene<ITMVoxel, ITMVoxelIndex> *scene,
                     ITMRenderState *rs, bool onlyUpdateVisibleList = false, bool isDefusion = false) {
@@ -76,7 +99,8 @@ class ITMDenseMapper {
     poseArgs(view, ts, M_d, M_rgb, kd, kr);
     dslam_check(dslam_process_frame(eng_, scene->handle, view->handle, rs->handle, M_d.m, kd.v, M_rgb.m, kr.v,
                                     onlyUpdateVisibleList, isDefusion), "dslam_process_frame");
-    scene->refreshCounters(eng_, rs, &decayedBlocks_);
+    scene->MarkCountersStale(rs);
+    note(scene);
   }
   void DeProcessFrame(const ITMView *view, const ITMTrackingState *ts, ITMScene<ITMVoxel, ITMVoxelIndex> *scene,
                       ITMRenderState *rs) {
@@ -84,7 +108,8 @@ class ITMDenseMapper {
     poseArgs(view, ts, M_d, M_rgb, kd, kr);
     dslam_check(dslam_deprocess_frame(eng_, scene->handle, view->handle, rs->handle, M_d.m, kd.v, M_rgb.m, kr.v),
                 "dslam_deprocess_frame");
-    scene->refreshCounters(eng_, rs, &decayedBlocks_);
+    scene->MarkCountersStale(rs);
+    note(scene);
   }
   /// (extension of this engine, not in upstream) keep the visible list of the fusion that has just run with the keyframe's
   /// images in the device-resident store: what ReProcessFrames de-integrates from (dslam_frame_store_put_visible_list)
@@ -102,27 +127,37 @@ class ITMDenseMapper {
     static_assert(sizeof(Matrix4f) == 16 * sizeof(float), "poses are handed over as n x 16 floats");
     dslam_check(dslam_reintegrate_batch(eng_, scene->handle, view->handle, rs->handle, store, n, slots, n ? oldM_d[0].m : nullptr,
                                         n ? newM_d[0].m : nullptr, kd.v, ab.x, ab.y), "dslam_reintegrate_batch");
-    scene->refreshCounters(eng_, rs, &decayedBlocks_);
+    scene->MarkCountersStale(rs);
+    note(scene);
   }
   void Decay(ITMScene<ITMVoxel, ITMVoxelIndex> *scene, ITMRenderState *rs, int maxWeight, int minAge, bool forceAllVoxels) {
     dslam_check(dslam_decay(eng_, scene->handle, rs ? rs->handle : nullptr, maxWeight, minAge, forceAllVoxels), "dslam_decay");
-    scene->refreshCounters(eng_, rs, &decayedBlocks_);
+    scene->MarkCountersStale(rs);
+    note(scene);
   }
   void DecayDefusionPart(ITMScene<ITMVoxel, ITMVoxelIndex> *scene, ITMRenderState *rs, int maxWeight, int minAge, bool forceAllVoxels) {
     dslam_check(dslam_decay_defusion_part(eng_, scene->handle, rs ? rs->handle : nullptr, maxWeight, minAge, forceAllVoxels),
                 "dslam_decay_defusion_part");
-    scene->refreshCounters(eng_, rs, &decayedBlocks_);
+    scene->MarkCountersStale(rs);
+    note(scene);
   }
   void SlideWindow(ITMScene<ITMVoxel, ITMVoxelIndex> *scene, ITMRenderState *rs, int maxAge) {
     dslam_check(dslam_slide_window(eng_, scene->handle, rs ? rs->handle : nullptr, maxAge), "dslam_slide_window");
-    scene->refreshCounters(eng_, rs, &decayedBlocks_);
+    scene->MarkCountersStale(rs);
+    note(scene);
   }
   void SlideWindowDefusionPart(ITMScene<ITMVoxel, ITMVoxelIndex> *scene, ITMRenderState *rs, int maxAge, int maxSize) {
     dslam_check(dslam_slide_window_defusion_part(eng_, scene->handle, rs ? rs->handle : nullptr, maxAge, maxSize),
                 "dslam_slide_window_defusion_part");
-    scene->refreshCounters(eng_, rs, &decayedBlocks_);
+    scene->MarkCountersStale(rs);
+    note(scene);
   }
-  size_t GetDecayedBlockCount() const { return (size_t)decayedBlocks_; }
+  /// InfiniTamDriver.h:366-370 (the GUI's "saved memory" figure): read from the device when asked, not after every call
+  size_t GetDecayedBlockCount() const {
+    long long n = 0;
+    for (size_t i = 0; i < scenes_.size(); i++) n += scenes_[i]->Counters().decayed_block_count;
+    return (size_t)n;
+  }
   ITMSwappingEngine<ITMVoxel, ITMVoxelIndex> *GetSwappingEngine() { return swappingEngine_; }
 };
 
@@ -210,6 +245,7 @@ template <class TVoxel, class TIndex> class ITMVisualisationEngine {
   ITMRenderState *CreateRenderState(const ITMScene<TVoxel, TIndex> *scene, Vector2i sz) const { return new ITMRenderState_VH(eng_, scene->handle, sz); }
   void FindVisibleBlocks(const ITMScene<TVoxel, TIndex> *scene, const ITMPose *pose, const ITMIntrinsics *intr, ITMRenderState *rs) const {
     dslam_check(dslam_find_visible_blocks(eng_, scene->handle, rs->handle, pose->GetM().m, intr->projectionParamsSimple.all.v), "dslam_find_visible_blocks");
+    rs->MarkCountersStale();
   }
   int CountVisibleBlocks(const ITMScene<TVoxel, TIndex> *scene, const ITMRenderState *rs, int minBlockId, int maxBlockId) const {
     int n = 0;
@@ -271,6 +307,10 @@ class ITMMainEngine {
       : settings(settings_), view(nullptr), engine_(nullptr), freeviewScene_(nullptr), renderState_freeview_(nullptr) {
     if (imgSize_d.x == -1 || imgSize_d.y == -1) imgSize_d = imgSize_rgb;
     dslam_check(dslam_engine_create(settings->hipDeviceIndex, &engine_), "dslam_engine_create");
+    // calls enqueue; the calls that hand data to the host wait (see the head of this file)
+    const char *sync_env = getenv("DSLAM_MIRROR_SYNC");
+    deferred_ = !(sync_env && atoi(sync_env) != 0);
+    dslam_check(dslam_engine_set_async(engine_, deferred_ ? 1 : 0), "dslam_engine_set_async");
     denseMapper = new ITMDenseMapper(engine_, calib);
     viewBuilder = new ITMViewBuilder(engine_, calib);
     trackingController = new ITMTrackingController(engine_, settings);
@@ -329,6 +369,9 @@ class ITMMainEngine {
                                 intrinsics->projectionParamsSimple.all.v, t,
                                 t == DSLAM_IMAGE_DEPTH ? nullptr : &out->GetData(MEMORYDEVICE_CPU)->x,
                                 t == DSLAM_IMAGE_DEPTH ? outFloat->GetData(MEMORYDEVICE_CPU) : nullptr), "dslam_get_image");
+    // the caller reads the image next (ItmToCv / ItmDepthToCv, InfiniTamDriver.cpp:249,276): a page-locked image is filled
+    // by the render kernel itself, so this is where the mirror waits for the stream -- and hears what the device reported
+    if (deferred_) dslam_check(dslam_engine_synchronize(engine_), "dslam_engine_synchronize");
   }
 
   /// SaveCurrSceneToMesh(objFileName, scene) (DenseSlam.cpp:641): meshingEngine->MeshScene(mesh, scene), then
@@ -366,6 +409,7 @@ class ITMMainEngine {
 
  private:
   dslam_engine *engine_;
+  bool deferred_;   ///< the engine runs asynchronously (default; DSLAM_MIRROR_SYNC=1 turns it off)
   const ITMScene<ITMVoxel, ITMVoxelIndex> *freeviewScene_;
   ITMRenderState *renderState_freeview_;
   Vector2i freeviewSize_;

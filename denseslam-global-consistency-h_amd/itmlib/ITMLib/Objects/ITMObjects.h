@@ -171,6 +171,44 @@ class ITMView {
   ~ITMView() { dslam_view_destroy(handle); delete rgb; delete depth; }
 };
 
+/// The pool and list counters the reference reads as plain `int` members -- scene->localVBA.lastFreeBlockId
+/// (InfiniTamDriver.h:345), renderState_vh->noVisibleEntries (:210), denseMapper->GetDecayedBlockCount() (:368) -- live on
+/// the device (kernels chain on them without a host round trip).  The reference reads them in three places only, none of
+/// them between UpdateView / IntegrateLocalMap / SlideWindow* / Decay (DenseSlam.cpp:210-232), so the mirror does not
+/// fetch them after every call: a read fetches them (dslam_get_stats: one small copy + a wait for the engine's stream)
+/// if a call has been enqueued since the last fetch.  Same pattern as MemoryBlock::SetHostPull / MarkHostStale.
+/// A read is also a synchronising call in the sense of dslam_fusion.h: it throws what the device reported late.
+class DeviceCounters {
+  dslam_engine *eng_;
+  const dslam_scene *scene_;
+  const dslam_render_state *rs_;
+  mutable bool stale_;
+  mutable dslam_stats st_;
+ public:
+  DeviceCounters(dslam_engine *e, const dslam_scene *s, const dslam_render_state *r) : eng_(e), scene_(s), rs_(r), stale_(true) { memset(&st_, 0, sizeof(st_)); }
+  void MarkStale() { stale_ = true; }
+  const dslam_stats &Get() const {
+    if (stale_) {
+      dslam_check(dslam_get_stats(eng_, scene_, rs_, &st_), "dslam_get_stats");
+      stale_ = false;
+    }
+    return st_;
+  }
+};
+/// an `int` member of the reference's objects whose value is one field of DeviceCounters (reads as int; never assigned by
+/// the reference's callers, so there is no assignment)
+class LazyCounter {
+  const DeviceCounters *src_;
+  int32_t dslam_stats::*field_;
+ public:
+  LazyCounter() : src_(nullptr), field_(nullptr) {}
+  void Bind(const DeviceCounters *src, int32_t dslam_stats::*field) { src_ = src; field_ = field; }
+  operator int() const { return src_->Get().*field_; }
+ private:
+  LazyCounter(const LazyCounter &);
+  LazyCounter &operator=(const LazyCounter &);
+};
+
 class ITMRenderState;
 class ITMTrackingState {
  public:
@@ -193,40 +231,47 @@ class ITMRenderState {
   dslam_render_state *handle;
   ITMUChar4Image *raycastImage;
   virtual ~ITMRenderState() { dslam_render_state_destroy(handle); delete raycastImage; }
+  /// a call that can change this render state's visible list has been enqueued
+  virtual void MarkCountersStale() {}
  protected:
   ITMRenderState() : handle(nullptr), raycastImage(nullptr) {}
 };
 
 class ITMRenderState_VH : public ITMRenderState {
+  DeviceCounters counters_;
  public:
-  int noVisibleEntries;  ///< InfiniTamDriver.h:209-210
-  ITMRenderState_VH(dslam_engine *eng, const dslam_scene *scene, Vector2i sz) : noVisibleEntries(0) {
+  LazyCounter noVisibleEntries;  ///< InfiniTamDriver.h:209-210 (reads as int; fetched from the device when stale)
+  ITMRenderState_VH(dslam_engine *eng, const dslam_scene *scene, Vector2i sz) : counters_(eng, scene, nullptr) {
     dslam_check(dslam_render_state_create(eng, scene, sz.x, sz.y, &handle), "dslam_render_state_create");
+    counters_ = DeviceCounters(eng, scene, handle);
+    noVisibleEntries.Bind(&counters_, &dslam_stats::no_visible_entries);
     raycastImage = new ITMUChar4Image(sz, true, true);
   }
+  void MarkCountersStale() { counters_.MarkStale(); }
 };
 
 class ITMLocalVBA {
  public:
-  int lastFreeBlockId;  ///< InfiniTamDriver.h:345
+  LazyCounter lastFreeBlockId;  ///< InfiniTamDriver.h:345 (reads as int)
   int allocatedSize;
 };
 
 class ITMVoxelBlockHash {
   int numBlocks_;
  public:
-  int lastFreeExcessListId;
-  explicit ITMVoxelBlockHash(int n) : numBlocks_(n), lastFreeExcessListId(0) {}
+  LazyCounter lastFreeExcessListId;
+  explicit ITMVoxelBlockHash(int n) : numBlocks_(n) {}
   int getNumAllocatedVoxelBlocks() const { return numBlocks_; }  ///< InfiniTamDriver.h:345,350
 };
 
 template <class TVoxel, class TIndex> class ITMScene {
+  DeviceCounters *counters_;
  public:
   const ITMSceneParams *sceneParams;
   TIndex index;
   ITMLocalVBA localVBA;
   dslam_scene *handle;
-  ITMScene(const ITMLibSettings *settings, dslam_engine *eng) : sceneParams(&settings->sceneParams), index(settings->numLocalBlocks), handle(nullptr) {
+  ITMScene(const ITMLibSettings *settings, dslam_engine *eng) : counters_(nullptr), sceneParams(&settings->sceneParams), index(settings->numLocalBlocks), handle(nullptr) {
     dslam_scene_params p;
     memset(&p, 0, sizeof(p));
     p.voxel_size = sceneParams->voxelSize; p.mu = sceneParams->mu; p.max_w = sceneParams->maxW;
@@ -236,19 +281,18 @@ template <class TVoxel, class TIndex> class ITMScene {
     p.use_swapping = settings->useSwapping;
     dslam_check(dslam_scene_create(eng, &p, nullptr, &handle), "dslam_scene_create");
     localVBA.allocatedSize = settings->numLocalBlocks;
-    localVBA.lastFreeBlockId = settings->numLocalBlocks - 1;
-    index.lastFreeExcessListId = settings->numExcess - 1;
+    counters_ = new DeviceCounters(eng, handle, nullptr);
+    localVBA.lastFreeBlockId.Bind(counters_, &dslam_stats::last_free_block_id);
+    index.lastFreeExcessListId.Bind(counters_, &dslam_stats::last_free_excess_id);
   }
-  ~ITMScene() { dslam_scene_destroy(handle); }
-  /// pull the pool counters the driver reads after every call (InfiniTamDriver.h:344-351)
-  void refreshCounters(dslam_engine *eng, ITMRenderState *rs, long long *decayed = nullptr) {
-    dslam_stats st;
-    dslam_check(dslam_get_stats(eng, handle, rs ? rs->handle : nullptr, &st), "dslam_get_stats");
-    localVBA.lastFreeBlockId = st.last_free_block_id;
-    index.lastFreeExcessListId = st.last_free_excess_id;
-    if (rs) static_cast<ITMRenderState_VH *>(rs)->noVisibleEntries = st.no_visible_entries;
-    if (decayed) *decayed = st.decayed_block_count;
+  ~ITMScene() { dslam_scene_destroy(handle); delete counters_; }
+  /// a call that can change the pool counters the driver reads (InfiniTamDriver.h:344-351, 366-370) has been enqueued:
+  /// the next read of one of them fetches all of them
+  void MarkCountersStale(ITMRenderState *rs = nullptr) {
+    counters_->MarkStale();
+    if (rs) rs->MarkCountersStale();
   }
+  const dslam_stats &Counters() const { return counters_->Get(); }
 };
 
 /// ITMMesh: the triangle list SaveCurrSceneToMesh writes (DenseSlam.cpp:638-643).  Host-side copy of the mesh the

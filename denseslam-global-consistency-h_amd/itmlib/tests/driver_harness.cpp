@@ -205,6 +205,7 @@ int main(int argc, char **argv) {
     calib->disparityCalib.SetFrom(1.0f / 1000.0f, 0.0f, ITMDisparityCalib::TRAFO_AFFINE);
 
     VoxelDecayParams dp = {atoi(argv[3]) != 0, 2, 1};
+    if (const char *d = getenv("DRIVER_HARNESS_DECAY")) sscanf(d, "%d,%d", &dp.max_decay_weight, &dp.min_decay_age);   // "maxWeight,minAge" 
     SlideWindowParams sw = {atoi(argv[4]) >= 0, atoi(argv[4])};
     DriverHarness drv(settings, calib, Vector2i(W, H), dp, sw, oc);
 
@@ -263,8 +264,12 @@ int main(int argc, char **argv) {
       }
     }
     int fused = 0;
-    const auto t_loop0 = std::chrono::steady_clock::now();
+    auto t_loop0 = std::chrono::steady_clock::now();
     const bool raycast_each = getenv("DRIVER_HARNESS_RAYCAST_EACH_FRAME") != nullptr;
+    // timing starts at this keyframe (the ones before it warm the engine up and fill the window); the loop's last call is
+    // followed by a counter read -- a synchronising call -- so that the time covers the work, not only its enqueueing
+    const int time_from = getenv("DRIVER_HARNESS_TIME_FROM") ? atoi(getenv("DRIVER_HARNESS_TIME_FROM")) : 0;
+    float image_probe = 0.0f;
     double phase_us[3] = {0, 0, 0};  // UpdateView, fusion + window + decay, per-keyframe raycast
     auto lap = [](std::chrono::steady_clock::time_point &t) {
       const auto now = std::chrono::steady_clock::now();
@@ -273,6 +278,11 @@ int main(int argc, char **argv) {
       return us;
     };
     for (int i = 0; i < N && !oc.enabled; i++) {
+      if (i == time_from && i > 0) {
+        (void)drv.GetLocalMapUsedMemoryBytes(currentLocalMap);   // (counter read: waits for the keyframes before)
+        phase_us[0] = phase_us[1] = phase_us[2] = 0;
+        t_loop0 = std::chrono::steady_clock::now();
+      }
       auto t = std::chrono::steady_clock::now();
       currentLocalMap->trackingState->pose_d->SetM(poses[i]);                 // SetPoseLocalMap (InfiniTamDriver.h:173-178)
       drv.UpdateView(rgba[i].data(), depth[i].data(), (double)i);             // DenseSlam.cpp:212
@@ -285,13 +295,20 @@ int main(int argc, char **argv) {
       if (raycast_each) {                                                     // SaveRaycastDepth's per-keyframe raycast
         free_pose.SetM(poses[i]);
         drv.GetFloatImage(&out_float, free_pose, currentLocalMap);
+        // the reference converts the image right away (ItmDepthToCv / FloatDepthmapToInt16, InfiniTamDriver.cpp:276,
+        // DenseSlam.cpp:586-592): read it through the accessor the reference uses
+        image_probe += out_float.GetData(MEMORYDEVICE_CPU)[((size_t)H / 2) * W + W / 2];
         phase_us[2] += lap(t);
       }
     }
+    const size_t used_bytes_after_loop = N > 0 && !oc.enabled ? drv.GetLocalMapUsedMemoryBytes(currentLocalMap) : 0;   // (waits for the last keyframe)
     const double loop_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_loop0).count();
-    if (!oc.enabled && N > 0)
-      printf("driver_harness loop: %d keyframes in %.3f ms (%.1f us per keyframe, host-synchronous calls: UpdateView %.1f, fusion %.1f, raycast %.1f)\n",
-             N, loop_s * 1e3, loop_s * 1e6 / N, phase_us[0] / N, phase_us[1] / N, phase_us[2] / N);
+    if (!oc.enabled && N > 0) {
+      const int nt = N - (time_from > 0 && time_from < N ? time_from : 0);
+      printf("driver_harness loop: %d keyframes in %.3f ms (%.1f us per keyframe; host time inside the calls: UpdateView %.1f, fusion + window + decay %.1f, raycast %.1f; "
+             "%zu bytes in use, probe %.3f)\n",
+             nt, loop_s * 1e3, loop_s * 1e6 / nt, phase_us[0] / nt, phase_us[1] / nt, phase_us[2] / nt, used_bytes_after_loop, image_probe);
+    }
     free_pose.SetM(poses[N - 1]);
     drv.GetFloatImage(&out_float, free_pose, currentLocalMap);                // DenseSlam.h:146-153
     drv.GetImage(&out_rgba, ITMMainEngine::InfiniTAM_IMAGE_FREECAMERA_COLOUR_FROM_VOLUME, free_pose, currentLocalMap);

@@ -17,7 +17,14 @@
  *  - the engine is used from one thread (DenseSlam's main thread); it owns one HIP stream.
  *    In the default synchronous mode every call has completed (including D2H copies) when it returns,
  *    which is what the reference callers assume (DenseSlam.h:151-152,162-163).  dslam_engine_set_async
- *    lets a harness pipeline frames and synchronise explicitly.
+ *    lets a caller pipeline frames and synchronise explicitly (the ITMLib mirror in itmlib/ runs the engine this way
+ *    and synchronises where data is handed to the host).
+ *  - conditions only the device can detect (an allocation ray longer than the order key encodes: DSLAM_ERR_UNSUPPORTED;
+ *    a tile count of an ordered compaction that never arrived, after which the map state is undefined: DSLAM_ERR_HIP)
+ *    are returned by the first call that waits for the stream after the kernel in question: the call itself on a
+ *    synchronous engine; on an asynchronous one the next dslam_engine_synchronize, dslam_fence_wait, dslam_get_stats,
+ *    read-back (dslam_download_*, an image into ordinary host memory, dslam_mesh_download ...).  Told once per
+ *    occurrence; dslam_get_stats keeps reporting them for the scene they happened in until dslam_scene_reset.
  */
 #ifndef DSLAM_FUSION_H
 #define DSLAM_FUSION_H
@@ -129,6 +136,7 @@ const char *dslam_version(void);
 int dslam_engine_create(int device_index, dslam_engine **out);
 int dslam_engine_destroy(dslam_engine *e);
 int dslam_engine_set_async(dslam_engine *e, int async_mode);
+/* waits for everything enqueued so far; returns what kernels reported since the last synchronising call (above) */
 int dslam_engine_synchronize(dslam_engine *e);
 /* native hipStream_t of the engine, for callers that enqueue their own work (RCCL, torch). */
 void *dslam_engine_stream(dslam_engine *e);
@@ -253,7 +261,9 @@ int dslam_view_update_from_store(dslam_engine *e, dslam_view *v, const dslam_fra
  * frame and its old pose, so it first has to find the blocks again: a visible-list-only allocation pass at that pose (two
  * kernel launches over the depth image and the table) -- which in a re-integration batch is work every GPU repeats.  With
  * the list stored at fusion time, de-integration goes straight to the integration kernel:
- *   dslam_frame_store_enable_lists(e, fs, scene)            room for one list of num_local_blocks entries per slot
+ *   dslam_frame_store_enable_lists(e, fs, scene)            room for one list of num_local_blocks entries per slot; the
+ *                                                           lists hold entry ids of THIS scene's table size, and every
+ *                                                           call that reads one refuses a scene of another size
  *   dslam_frame_store_put_visible_list(e, fs, slot, s, r)   after ProcessFrame of that keyframe (fusion or re-fusion): the
  *                                                           render state's visible list with each entry's block position
  *   dslam_deprocess_frame_stored(e, s, v, fs, slot, M_d, ...)   the inverse update of DeProcessFrame on exactly those
@@ -281,7 +291,13 @@ int dslam_deprocess_frame_stored(dslam_engine *e, dslam_scene *s, const dslam_vi
  * use the per-keyframe calls.  On a sharded scene (dslam_scene_set_shard) every rank runs the allocation passes and
  * updates its own blocks; the exchange is dslam_shard_dirty_plan / _pack / _unpack as for the per-keyframe calls.
  * n = 0 changes nothing and allocates the call's scratch buffers (a second copy of 32 stored lists, per-block operation
- * masks): a set-up call keeps those allocations out of the first batch. */
+ * masks): a set-up call keeps those allocations out of the first batch.
+ * Errors: every argument -- slots, stored lists, table sizes, invertible new poses, the order key's range -- is checked
+ * before anything is changed, so DSLAM_ERR_INVALID / DSLAM_ERR_UNSUPPORTED leave scene, render state and store as they
+ * were.  A HIP failure in mid-batch (DSLAM_ERR_HIP) does not: allocation passes may have run whose blocks were never de-
+ * or re-integrated, i.e. the scene is UNDEFINED (neither the old nor the new map) and must be reset or restored; the
+ * render state's visible list is re-derived by its next pass, and the keyframes of the interrupted chunk lose their
+ * stored lists (dslam_frame_store_put_visible_list again after re-fusing them). */
 int dslam_reintegrate_batch(dslam_engine *e, dslam_scene *s, dslam_view *v, dslam_render_state *r, dslam_frame_store *fs,
                             int n, const int32_t *slots, const float *old_M, const float *new_M, const float intr[4],
                             float affine_a, float affine_b);
@@ -471,9 +487,15 @@ int dslam_upload_voxel_blocks(dslam_engine *e, dslam_scene *s, int first_block, 
                               const dslam_voxel *host);
 int dslam_upload_visible_ids(dslam_engine *e, dslam_render_state *r, const int32_t *ids_host, int count);
 
-/* raw device pointers (HBM layout is documented in DESIGN.md) */
+/* raw device pointers (HBM layout is documented in DESIGN.md).
+ * The hash table is READ-ONLY through this pointer: every pass that lists entries (visibility, decay, window, swapping,
+ * meshing, FindVisibleBlocks) walks a bitmap that mirrors `ptr >= 0` of the table (alloc_bits) instead of the table, so an
+ * entry written behind the engine's back exists but is never seen.  A caller that must patch or restore the table in
+ * place calls dslam_scene_table_changed afterwards (the bitmap is rebuilt from the table: the one pass that reads all of
+ * it); dslam_upload_scene_state does that by itself.  Voxel blocks may be written freely (they have no shadow). */
 void *dslam_scene_voxel_blocks_dev(dslam_scene *s);
 void *dslam_scene_hash_table_dev(dslam_scene *s);
+int dslam_scene_table_changed(dslam_engine *e, dslam_scene *s);
 void *dslam_render_state_image_dev(dslam_render_state *r, int want_float);
 
 /* ---- sharded re-integration (multi-GPU) ------------------------------------------------ */
