@@ -426,6 +426,7 @@ int dslam_scene_destroy(dslam_scene *s) {
   free_dev(s->alloc_list); free_dev(s->excess_list); free_dev(s->last_seen); free_dev(s->masks); free_dev(s->counters);
   free_dev(s->swap_state); free_dev(s->slab_ptrs_dev); free_dev(s->alloc_bits); free_dev(s->swap1_bits);
   free_dev(s->dirty); free_dev(s->dirty_list); free_dev(s->dirty_counts);
+  free_dev(s->batch_depth);
   free_dev(s->batch_born); free_dev(s->batch_opmask); free_dev(s->batch_slot_entry); free_dev(s->batch_marks); free_dev(s->batch_order); free_dev(s->batch_counters);
   if (s->batch_ops_dev) (void)hipFree(s->batch_ops_dev);
   if (s->batch_lists_dev) (void)hipFree(s->batch_lists_dev);
@@ -961,7 +962,7 @@ namespace {
 constexpr int kBatchMax = 32;   // keyframes per launch of the block kernel: two operation bits each in a 64-bit mask
 struct HostBatchOp {            // = BatchOp (integrate.hip)
   float M[16];
-  const void *raw, *rgba;
+  const void *depth, *rgba;
   int push_bit, push_frame, pad[2];
 };
 struct HostBatchList {          // = BatchListRef
@@ -983,6 +984,14 @@ static int batch_failed(dslam_scene *s, dslam_render_state *r, dslam_frame_store
 
 static int batch_scratch(dslam_engine *e, dslam_scene *s, dslam_frame_store *fs) {
   const size_t L = (size_t)s->p.num_local_blocks;
+  const size_t npix = (size_t)fs->w_d * fs->h_d;
+  if (s->batch_depth_pixels < npix) {   // (1.2 MB per 640x480 keyframe: 39 MB for the 32 of a chunk)
+    DSLAM_HIP(hipStreamSynchronize(e->stream));
+    free_dev(s->batch_depth);
+    s->batch_depth_pixels = 0;
+    DSLAM_HIP(hipMalloc(&s->batch_depth, (size_t)kBatchMax * npix * sizeof(float)));
+    s->batch_depth_pixels = npix;
+  }
   if (!s->batch_born) {
     DSLAM_HIP(hipMalloc(&s->batch_born, L * sizeof(int)));
     DSLAM_HIP(hipMalloc(&s->batch_opmask, L * sizeof(unsigned long long)));
@@ -1053,10 +1062,14 @@ int dslam_reintegrate_batch(dslam_engine *e, dslam_scene *s, dslam_view *v, dsla
     // images, not the voxels); every pass' list goes to a scratch buffer, the blocks it allocates are stamped
     s->alloc_born = s->batch_born;
     int n_pos_jobs = 0;
+    float *const view_depth = v->depth;
     for (int k = 0; k < K; k++) {
       const int slot = slots[first + k];
       const void *rgba = fs->rgba + fs->rgba_bytes * slot, *raw = fs->depth + fs->depth_bytes * slot;
       if ((rc = launch_view_convert(e, v, rgba, raw, affine_a, affine_b))) break;
+      // the pass derives the keyframe's metric depth image (as UpdateView would) -- into the batch's own image k, where
+      // both operations of the keyframe read it in the block launch
+      v->depth = s->batch_depth + (size_t)k * s->batch_depth_pixels;
       s->alloc_born_stamp = k + 1;
       // the pass writes its list straight into the scratch list of keyframe k; the last one into the render state's own
       // (what the loop of per-keyframe calls leaves there), from where it is copied
@@ -1078,12 +1091,14 @@ int dslam_reintegrate_batch(dslam_engine *e, dslam_scene *s, dslam_view *v, dsla
       HostBatchOp &d = ops[2 * k], &f = ops[2 * k + 1];
       memcpy(d.M, old_M + 16 * (size_t)(first + k), 64);
       memcpy(f.M, new_M + 16 * (size_t)(first + k), 64);
-      d.raw = f.raw = raw; d.rgba = f.rgba = rgba;
+      d.depth = f.depth = v->depth; d.rgba = f.rgba = rgba;
       d.push_bit = d.push_frame = 0; f.push_bit = bit; f.push_frame = frame;
       lists[2 * k] = {ob, ob + ids_off, ob + pos_off};
       lists[2 * k + 1] = {nb, nb + ids_off, nullptr};
     }
     s->alloc_born = nullptr;
+    v->depth = view_depth;
+    v->depth_dirty = true;   // (the view's own float image was not written: its next consumer derives it)
     if (rc) return batch_failed(s, r, fs, slots + first, K, rc);
     // phase 2: which operations touch which block, then every touched block once
     DSLAM_HIP(hipMemcpyAsync(s->batch_ops_dev, ops, 2 * (size_t)K * sizeof(HostBatchOp), hipMemcpyHostToDevice, e->stream));
@@ -1092,7 +1107,7 @@ int dslam_reintegrate_batch(dslam_engine *e, dslam_scene *s, dslam_view *v, dsla
     if ((rc = launch_batch_ops(e, s->batch_lists_dev, 2 * K, s, s->batch_born, s->batch_marks, s->batch_opmask, s->batch_slot_entry,
                                s->batch_order, s->batch_counters)))
       return batch_failed(s, r, fs, slots + first, K, rc);
-    if ((rc = launch_reintegrate_blocks(e, s, v->w_d, v->h_d, v->w_rgb, v->h_rgb, intr, affine_a, affine_b, s->batch_ops_dev,
+    if ((rc = launch_reintegrate_blocks(e, s, v->w_d, v->h_d, v->w_rgb, v->h_rgb, intr, s->batch_ops_dev,
                                         s->batch_opmask, s->batch_slot_entry, s->batch_order, s->batch_counters, 1, 2 * K)))
       return batch_failed(s, r, fs, slots + first, K, rc);
     if ((rc = launch_store_list_positions(e, s, reinterpret_cast<const HostBatchList *>(s->batch_lists_dev) + 2 * K, n_pos_jobs)))

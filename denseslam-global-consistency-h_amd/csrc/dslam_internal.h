@@ -170,6 +170,8 @@ struct dslam_scene {
   int *batch_slot_entry = nullptr, *batch_order = nullptr, *batch_counters = nullptr;   // (batch_order: 8 class lists)
   unsigned char *batch_marks = nullptr;   // [num_local_blocks][64]: operation k of the batch touches the block (zero between batches)
   void *batch_ops_dev = nullptr, *batch_lists_dev = nullptr;
+  float *batch_depth = nullptr;           // one float depth image per keyframe of a batch (written by its allocation pass, read by
+  size_t batch_depth_pixels = 0;          // both of its operations in the block launch); pixels per image it was sized for
   void *batch_staging = nullptr;          // page-locked: the operations and list references of a batch on their way to the device
   hipEvent_t batch_staging_ev = nullptr;  // ... the copies out of it have been made
   int *alloc_born = nullptr;
@@ -308,7 +310,7 @@ int launch_store_list_positions(dslam_engine *e, const dslam_scene *s, const voi
 int launch_batch_ops(dslam_engine *e, const void *lists_dev, int n_ops, const dslam_scene *s, const int *born, unsigned char *marks,
                      unsigned long long *opmask, int *slot_entry, int *cls_list, int *cls_count);
 int launch_reintegrate_blocks(dslam_engine *e, dslam_scene *s, int w_d, int h_d, int w_rgb, int h_rgb, const float *intr,
-                              float a, float b, const void *ops_dev, const unsigned long long *opmask, const int *slot_entry,
+                              const void *ops_dev, const unsigned long long *opmask, const int *slot_entry,
                               const int *cls_list, const int *cls_count, int push_ring, int n_ops);
 int alloc_step_cap(const dslam_scene *s, int W, int H, int *cap_out);
 int ensure_view_depth(dslam_engine *e, const dslam_view *v);

@@ -963,7 +963,8 @@ int launch_integrate_list(dslam_engine *e, dslam_scene *s, const dslam_view *v, 
 // Blocks differ in how many operations they take: they are ordered longest first and dealt round-robin over the waves.
 struct BatchOp {
   Mat4 M;                // world -> camera of this operation (old pose: de-integration, new pose: re-fusion)
-  const short *raw;      // the keyframe's int16 depth image (the float value is derived per read, like UpdateView does)
+  const float *depth;    // the keyframe's depth image in metres: written by the allocation pass of its re-fusion (k_mark derives
+                         // it from the int16 image exactly as UpdateView does) into the batch's scratch, one image per keyframe
   const uchar4 *rgba;
   int push_bit, push_frame;  // re-fusions: the ring bit and frame stamp ProcessFrame(isDefusion) queues the block with
   int pad[2];
@@ -977,81 +978,107 @@ struct BatchParams {
   const int *cls_list;    // [kBatchClasses][n_local]: the slots with operations, by class of their operation count
   const int *cls_count;   // [kBatchClasses]
   int n_local;
-  float a, b;             // depth = raw * a + b
-  int raw_bytes;
   int n_ops;
 };
 
-// pair_project with the depth pixels taken from the int16 image: the float value is derived as UpdateView derives it,
-// (r <= 0 || r > 32000) ? -1 : r * a + b (the conversion of k_mark / k_convert_depth: same operations, same bits).  The
-// projection only REQUESTS the dword that holds the halfword; raw_depth_finish turns it into metres when the update needs
-// it, so that the requests of several chunks are in flight together.
-struct RawProj {
-  PairProj q;        // (q.dm holds the two raw dwords until raw_depth_finish)
-  unsigned hi_half;  // bit h: voxel h's pixel is the upper halfword of its dword
+// What an operation needs of its BatchOp, in SCALAR registers.  The table sits in LDS (a scalar load per operation costs a
+// round trip of its own); what comes out of LDS is a vector register, and a buffer resource built from vector registers is
+// "divergent" to the compiler: round 3's kernel wrapped every depth / texel load of an operation in a waterfall loop
+// (v_readfirstlane x 4, two compares, an exec-mask loop around the load -- eight of them per block-operation, found in the
+// ISA), and multiplied by pose terms it re-read from LDS at every use.  Here every value is made uniform once per
+// operation (v_readfirstlane: 14 floats, two pointers), the resources are scalar, the pose terms scalar operands.
+struct OpScalars {
+  float m0, m1, m2, m4, m5, m6, m8, m9, m10, m12, m13, m14;
+  __amdgpu_buffer_rsrc_t depth_rs, rgba_rs;
 };
-
-__device__ __forceinline__ void pair_project_raw(RawProj &o, f2 pcx, f2 pcy, f2 pcz, const IntegrateParams &p,
-                                                 __amdgpu_buffer_rsrc_t raw_rs) {
-  PairProj &q = o.q;
-  const f2 fx2 = {p.fx_d, p.fx_d}, fy2 = {p.fy_d, p.fy_d}, cx2 = {p.cx_d, p.cx_d}, cy2 = {p.cy_d, p.cy_d};
-  q.pcz = pcz;
-  q.u = div_ieee2(fx2 * pcx, pcz) + cx2;
-  q.w = div_ieee2(fy2 * pcy, pcz) + cy2;
-  const float wmax = (float)(p.Wd - 2), hmax = (float)(p.Hd - 2);
-  q.act0 = (pcz.x >= kMinCamZ) & in_image(q.u.x, q.w.x, wmax, hmax);
-  q.act1 = (pcz.y >= kMinCamZ) & in_image(q.u.y, q.w.y, wmax, hmax);
-  const f2 half = {0.5f, 0.5f};
-  const f2 ur = q.u + half, wr = q.w + half;
-  // (a voxel that failed a test may produce any pixel index: its read stays inside the buffer resource or returns 0)
-  const unsigned off0 = ((unsigned)__mul24((int)wr.x, p.Wd) + (unsigned)(int)ur.x) << 1;
-  const unsigned off1 = ((unsigned)__mul24((int)wr.y, p.Wd) + (unsigned)(int)ur.y) << 1;
-  q.dm.x = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(raw_rs, off0 & ~3u, 0, 0));
-  q.dm.y = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(raw_rs, off1 & ~3u, 0, 0));
-  o.hi_half = ((off0 >> 1) & 1u) | (off1 & 2u);
+__device__ __forceinline__ float uniform_f(float v) { return __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(v))); }
+__device__ __forceinline__ const void *uniform_ptr(const void *ptr) {
+  const unsigned long long a = (unsigned long long)ptr;
+  return (const void *)(((unsigned long long)__builtin_amdgcn_readfirstlane((unsigned)(a >> 32)) << 32) |
+                        (unsigned long long)__builtin_amdgcn_readfirstlane((unsigned)a));
+}
+__device__ __forceinline__ OpScalars op_scalars(const BatchOp &op, int Wd, int Hd, int Wr, int Hr) {
+  OpScalars o;
+  o.m0 = uniform_f(op.M.m[0]); o.m1 = uniform_f(op.M.m[1]); o.m2 = uniform_f(op.M.m[2]);
+  o.m4 = uniform_f(op.M.m[4]); o.m5 = uniform_f(op.M.m[5]); o.m6 = uniform_f(op.M.m[6]);
+  o.m8 = uniform_f(op.M.m[8]); o.m9 = uniform_f(op.M.m[9]); o.m10 = uniform_f(op.M.m[10]);
+  o.m12 = uniform_f(op.M.m[12]); o.m13 = uniform_f(op.M.m[13]); o.m14 = uniform_f(op.M.m[14]);
+  o.depth_rs = image_rsrc(uniform_ptr(op.depth), Wd, Hd);
+  o.rgba_rs = image_rsrc(uniform_ptr(op.rgba), Wr, Hr);
+  return o;
 }
 
-__device__ __forceinline__ void raw_depth_finish(RawProj &o, float a, float b) {
-  const unsigned w0 = __float_as_uint(o.q.dm.x), w1 = __float_as_uint(o.q.dm.y);
-  const int r0 = (int)(short)((o.hi_half & 1u) ? (w0 >> 16) : (w0 & 0xffffu));
-  const int r1 = (int)(short)((o.hi_half & 2u) ? (w1 >> 16) : (w1 & 0xffffu));
-  o.q.dm.x = (r0 <= 0 || r0 > 32000) ? -1.0f : (float)r0 * a + b;
-  o.q.dm.y = (r1 <= 0 || r1 > 32000) ? -1.0f : (float)r1 * a + b;
+// fuse_colour_word / defuse_colour_word with the texels through an operation's own resource
+template <bool DEINT>
+__device__ __forceinline__ unsigned batch_colour_word(unsigned pack, float u, float w, __amdgpu_buffer_rsrc_t rgba_rs,
+                                                      const IntegrateParams &p, const float *inv_tab) {
+  float m[3];
+  if constexpr (DEINT) {
+    const unsigned wc = pack >> 24;
+    if (wc < 1) return pack;  // nothing was ever fused into this colour
+    bilinear_rgb_buf(rgba_rs, u, w, p.Wr, m);
+    const float oldW = (float)wc, remW = oldW - 1.0f;
+    if (remW == 0.0f) return 0u;  // colour 0, weight 0
+    const float inv_rem = inv_tab[wc - 1];
+    unsigned out = (unsigned)(unsigned char)remW << 24;
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+      const float oldC = div_exact((float)((pack >> (8 * k)) & 0xffu), 255.0f, p.inv_255);
+      const float c = div_exact(m[k], 255.0f, p.inv_255);
+      float v = div_exact(oldC * oldW - c * 1.0f, remW, inv_rem);
+      v = fmaxf(0.0f, fminf(1.0f, v));
+      out |= (unsigned)(unsigned char)(v * 255.0f) << (8 * k);
+    }
+    return out;
+  } else {
+    bilinear_rgb_buf(rgba_rs, u, w, p.Wr, m);
+    const unsigned wc = pack >> 24;
+    const float oldW = (float)wc;
+    float newW = oldW + 1.0f;
+    const float inv_new = inv_tab[wc + 1];
+    unsigned out = 0;
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+      const float oldC = div_exact((float)((pack >> (8 * k)) & 0xffu), 255.0f, p.inv_255);
+      const float c = div_exact(m[k], 255.0f, p.inv_255);
+      const float v = div_exact(oldC * oldW + c * 1.0f, newW, inv_new);
+      out |= (unsigned)(unsigned char)(v * 255.0f) << (8 * k);
+    }
+    newW = fminf(newW, (float)p.max_w);
+    return out | ((unsigned)(unsigned char)newW << 24);
+  }
 }
 
-constexpr int kBatchColQueue = 256;   // one slot per voxel of a half block
-struct BatchColQueue {   // (the colour queue of k_integrate: one per wave)
-  float u[kBatchColQueue], w[kBatchColQueue];
-  unsigned c[kBatchColQueue], r[kBatchColQueue];
-  unsigned char list[kBatchColQueue];
+// The colour queue of k_integrate, one per wave, with room for a whole block (kHalves = 2: the narrow-band voxels of BOTH
+// halves of an operation are queued and run in ONE dense pass -- two half-empty passes of ~120 instructions per block-
+// operation were a quarter of the kernel's arithmetic).  A voxel's data sits at its own place (half * 256 + chunk-voxel
+// k * 64 + lane), `list` holds the places in queue order, the result comes back in `c`.
+template <int kHalves>
+struct BatchColQueue {
+  float u[256 * kHalves], w[256 * kHalves];
+  unsigned c[256 * kHalves];
+  unsigned short list[256 * kHalves];
 };
 
-// One operation on one HALF block (the unit of work: two 16-byte chunks per lane).  Both chunks are projected and their
-// four depth pixels requested before the first update waits; the narrow-band colour updates of the half are queued in
-// LDS and run densely in one pass, as in k_integrate.  Half blocks, not blocks: the wave then needs ~90 registers instead
-// of ~140 (5 waves per SIMD instead of 3 to hide the two round trips of an operation behind each other's arithmetic)
-// and the batch has twice as many independent units to deal out.
-template <bool DEINT, bool UNIT_W>   // UNIT_W: no depth weighting -- every observation has weight 1 (the reference's configuration)
-__device__ __forceinline__ void batch_op(uint4 (&v)[2], bool (&chs)[2], int gz0, const float (&pxy)[2][3], const float *Mm,
-                                         const IntegrateParams &p, __amdgpu_buffer_rsrc_t raw_rs, float a, float b, const float *inv_tab,
-                                         BatchColQueue &Q, int lane) {
-  RawProj rq[2];
+// The depth updates of one operation on one half block (two 16-byte chunks per lane): both chunks are projected and their
+// four depth pixels requested before the first update waits; the narrow-band voxels are queued (place = qbase + ...).
+template <bool DEINT, bool UNIT_W, int kHalves>
+__device__ __forceinline__ void batch_op_half(uint4 (&v)[2], bool (&chs)[2], int gz0, const float (&pxy)[2][3], const OpScalars &os,
+                                              const IntegrateParams &p, const float *inv_tab, BatchColQueue<kHalves> &Q, int lane,
+                                              int qbase, int &q_n, unsigned &cms) {
+  PairProj pq[2];
 #pragma unroll
   for (int j = 0; j < 2; j++) {
     const float fz = (float)(gz0 + j * 2) * p.voxel_size;   // (gz0: the z of this lane's voxels in the half's first chunk)
-    // (the pose is read from LDS where it is used: six registers less across the operation)
-    const float az0 = Mm[8] * fz, az1 = Mm[9] * fz, az2 = Mm[10] * fz;
+    const float az0 = os.m8 * fz, az1 = os.m9 * fz, az2 = os.m10 * fz;
     const f2 a0 = {az0, az0}, a1 = {az1, az1}, a2 = {az2, az2};
-    const f2 t0 = {Mm[12], Mm[12]}, t1 = {Mm[13], Mm[13]}, t2 = {Mm[14], Mm[14]};
+    const f2 t0 = {os.m12, os.m12}, t1 = {os.m13, os.m13}, t2 = {os.m14, os.m14};
     const f2 px = {pxy[0][0], pxy[1][0]}, py = {pxy[0][1], pxy[1][1]}, pz = {pxy[0][2], pxy[1][2]};
-    pair_project_raw(rq[j], (px + a0) + t0, (py + a1) + t1, (pz + a2) + t2, p, raw_rs);
+    pair_project(pq[j], (px + a0) + t0, (py + a1) + t1, (pz + a2) + t2, p, os.depth_rs);
   }
-  int q_n = 0;
-  unsigned cms = 0;   // bit 2j + h: voxel h of chunk j is queued
 #pragma unroll
   for (int j = 0; j < 2; j++) {
-    raw_depth_finish(rq[j], a, b);
-    const PairProj &q = rq[j].q;
+    const PairProj &q = pq[j];
     unsigned cm;
     chs[j] |= pair_update<DEINT, UNIT_W>(v[j], q, p, inv_tab, cm);
     cms |= cm << (2 * j);
@@ -1062,36 +1089,61 @@ __device__ __forceinline__ void batch_op(uint4 (&v)[2], bool (&chs)[2], int gz0,
         const unsigned long long bm = __ballot(c);
         if (c) {
           const unsigned lo = h ? v[j].z : v[j].x, hi = h ? v[j].w : v[j].y;
-          const int own = (j * 2 + h) * 64 + lane;
+          const int own = qbase + (j * 2 + h) * 64 + lane;
           const int slot = q_n + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(bm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bm, 0u));
           Q.u[own] = h ? q.u.y : q.u.x;
           Q.w[own] = h ? q.w.y : q.w.x;
           Q.c[own] = __builtin_amdgcn_perm(hi, lo, 0x06050403u);
-          Q.list[slot] = (unsigned char)own;
+          Q.list[slot] = (unsigned short)own;
         }
         q_n += __popcll(bm);
       }
     }
   }
+}
+
+// the queued colour updates, one per lane and round; every result goes back to the place of its voxel
+template <bool DEINT, int kHalves>
+__device__ __forceinline__ void batch_colour_pass(int q_n, const OpScalars &os, const IntegrateParams &p, const float *inv_tab,
+                                                  BatchColQueue<kHalves> &Q, int lane) {
+  __builtin_amdgcn_wave_barrier();
+  for (int i = lane; i < q_n; i += 64) {
+    const int o = Q.list[i];
+    Q.c[o] = batch_colour_word<DEINT>(Q.c[o], Q.u[o], Q.w[o], os.rgba_rs, p, inv_tab);   // (read and written by the same lane)
+  }
+  __builtin_amdgcn_wave_barrier();
+}
+template <int kHalves>
+__device__ __forceinline__ void batch_colour_fetch(uint4 (&v)[2], unsigned cms, const BatchColQueue<kHalves> &Q, int qbase, int lane) {
+#pragma unroll
+  for (int j = 0; j < 2; j++)
+#pragma unroll
+    for (int h = 0; h < 2; h++)
+      if ((cms >> (2 * j + h)) & 1u) {
+        const unsigned word = Q.c[qbase + (j * 2 + h) * 64 + lane];
+        unsigned &lo = h ? v[j].z : v[j].x;
+        unsigned &hi = h ? v[j].w : v[j].y;
+        lo = __builtin_amdgcn_perm(word, lo, 0x04020100u);
+        hi = __builtin_amdgcn_perm(hi, word, 0x07030201u);
+      }
+}
+
+// one operation on the unit a wave holds (kHalves halves of a block)
+template <bool DEINT, bool UNIT_W, int kHalves>
+__device__ __forceinline__ void batch_op(uint4 (&v)[kHalves][2], bool (&chs)[kHalves][2], int gz0, const float (&pxy)[2][3],
+                                         const OpScalars &os, const IntegrateParams &p, const float *inv_tab,
+                                         BatchColQueue<kHalves> &Q, int lane) {
+  int q_n = 0;
+  unsigned cms[kHalves];
+#pragma unroll
+  for (int hf = 0; hf < kHalves; hf++) {
+    cms[hf] = 0;
+    batch_op_half<DEINT, UNIT_W, kHalves>(v[hf], chs[hf], gz0 + hf * 4, pxy, os, p, inv_tab, Q, lane, hf * 256, q_n, cms[hf]);
+  }
   if (q_n > 0) {
-    __builtin_amdgcn_wave_barrier();
-    for (int i = lane; i < q_n; i += 64) {
-      const int o = Q.list[i];
-      if constexpr (DEINT) Q.r[o] = defuse_colour_word<false>(Q.c[o], Q.u[o], Q.w[o], p, inv_tab);
-      else Q.r[o] = fuse_colour_word<false>(Q.c[o], Q.u[o], Q.w[o], p, inv_tab);
-    }
-    __builtin_amdgcn_wave_barrier();
+    batch_colour_pass<DEINT, kHalves>(q_n, os, p, inv_tab, Q, lane);
 #pragma unroll
-    for (int j = 0; j < 2; j++)
-#pragma unroll
-      for (int h = 0; h < 2; h++)
-        if ((cms >> (2 * j + h)) & 1u) {
-          const unsigned word = Q.r[(j * 2 + h) * 64 + lane];
-          unsigned &lo = h ? v[j].z : v[j].x;
-          unsigned &hi = h ? v[j].w : v[j].y;
-          lo = __builtin_amdgcn_perm(word, lo, 0x04020100u);
-          hi = __builtin_amdgcn_perm(hi, word, 0x07030201u);
-        }
+    for (int hf = 0; hf < kHalves; hf++) batch_colour_fetch<kHalves>(v[hf], cms[hf], Q, hf * 256, lane);
     __builtin_amdgcn_wave_barrier();   // (the queue is refilled by the next operation)
   }
 }
@@ -1102,14 +1154,14 @@ constexpr int kBatchWgWaves = 8;
 // which was 0.9 ms of a 1.2 ms launch and the whole launch of a rank that owns an eighth of the blocks.
 constexpr int kBatchGrid = 512;
 
-// kHalves = 2: the unit of work is a block, its halves one after the other inside every operation -- the operation's set-up
-// (pose from LDS, image resources, the block's xy terms) is paid once per block: 1.19 instead of 1.25 ms for the 120-keyframe
-// emulation map.  kHalves = 1: half a block per unit, for a rank that owns a fraction of the blocks -- the launch then ends
-// with the longest chain of operations on one unit, and a half block's is half as long (rank 0 of 8: 0.46 against 0.52 ms).
+// kHalves = 2: the unit of work is a block -- the operation's set-up (its scalars, the block's xy terms) and its colour pass
+// are paid once per block.  kHalves = 1: half a block per unit, for a rank that owns a fraction of the blocks -- the launch
+// then ends with the longest chain of operations on one unit, and a half block's is half as long (rank 0 of 8: 0.46
+// against 0.52 ms in round 3).
 template <bool UNIT_W, int kHalves>
 __global__ __launch_bounds__(kBatchWgWaves * 64) void k_reintegrate_blocks(BatchParams bp) {
   __shared__ float inv_tab[kInvTab];
-  __shared__ BatchColQueue col_q[kBatchWgWaves];
+  __shared__ BatchColQueue<kHalves> col_q[kBatchWgWaves];
   __shared__ BatchOp s_ops[64];   // the batch's operations: read per operation from LDS, not with a ~1 us scalar load each
   __shared__ int s_cum[9];        // blocks in the classes in front of class c (k_batch_assemble's lists)
   if (threadIdx.x == 0) {
@@ -1123,7 +1175,7 @@ __global__ __launch_bounds__(kBatchWgWaves * 64) void k_reintegrate_blocks(Batch
   __syncthreads();
   const IntegrateParams &p0 = bp.ip;
   const int lane = threadIdx.x & 63;
-  BatchColQueue &Q = col_q[threadIdx.x >> 6];
+  BatchColQueue<kHalves> &Q = col_q[threadIdx.x >> 6];
   const int n = __builtin_amdgcn_readfirstlane(s_cum[8]) * (2 / kHalves);
   const int vx0 = (lane & 3) * 2, vy = (lane >> 2) & 7, vz0 = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane((int)((blockIdx.x * (kBatchWgWaves * 64) + threadIdx.x) >> 6));
@@ -1180,23 +1232,16 @@ __global__ __launch_bounds__(kBatchWgWaves * 64) void k_reintegrate_blocks(Batch
     for (int part = 0; part < 2; part++) {
       for (unsigned m = part ? mhi : mlo; m; m &= m - 1) {
         const int bit = __builtin_amdgcn_readfirstlane(part * 32 + __ffs((int)m) - 1);
-        const BatchOp &op = s_ops[bit];
-        IntegrateParams p = p0;
-        p.rgba = op.rgba;
+        const OpScalars os = op_scalars(s_ops[bit], p0.Wd, p0.Hd, p0.Wr, p0.Hr);
         float pxy[2][3];
 #pragma unroll
         for (int h = 0; h < 2; h++) {
-          pxy[h][0] = op.M.m[0] * fxv[h] + op.M.m[4] * fyv;
-          pxy[h][1] = op.M.m[1] * fxv[h] + op.M.m[5] * fyv;
-          pxy[h][2] = op.M.m[2] * fxv[h] + op.M.m[6] * fyv;
+          pxy[h][0] = os.m0 * fxv[h] + os.m4 * fyv;
+          pxy[h][1] = os.m1 * fxv[h] + os.m5 * fyv;
+          pxy[h][2] = os.m2 * fxv[h] + os.m6 * fyv;
         }
-        const float *Mz = op.M.m;
-        const __amdgpu_buffer_rsrc_t raw_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<short *>(op.raw), 0, bp.raw_bytes, 0x00020000);
-#pragma unroll
-        for (int hf = 0; hf < kHalves; hf++) {
-          if (bit & 1) batch_op<false, UNIT_W>(v[hf], chs[hf], gz0 + hf * 4, pxy, Mz, p, raw_rs, bp.a, bp.b, inv_tab, Q, lane);   // re-fusion at the new pose
-          else batch_op<true, UNIT_W>(v[hf], chs[hf], gz0 + hf * 4, pxy, Mz, p, raw_rs, bp.a, bp.b, inv_tab, Q, lane);              // de-integration at the old one
-        }
+        if (bit & 1) batch_op<false, UNIT_W, kHalves>(v, chs, gz0, pxy, os, p0, inv_tab, Q, lane);   // re-fusion at the new pose
+        else batch_op<true, UNIT_W, kHalves>(v, chs, gz0, pxy, os, p0, inv_tab, Q, lane);            // de-integration at the old one
       }
     }
 #pragma unroll
@@ -1312,7 +1357,7 @@ int launch_batch_ops(dslam_engine *e, const void *lists_dev, int n_ops, const ds
 }
 
 int launch_reintegrate_blocks(dslam_engine *e, dslam_scene *s, int w_d, int h_d, int w_rgb, int h_rgb, const float *intr,
-                              float a, float b, const void *ops_dev, const unsigned long long *opmask, const int *slot_entry,
+                              const void *ops_dev, const unsigned long long *opmask, const int *slot_entry,
                               const int *cls_list, const int *cls_count, int push_ring, int n_ops) {
   BatchParams bp;
   IntegrateParams &ip = bp.ip;
@@ -1335,8 +1380,6 @@ int launch_reintegrate_blocks(dslam_engine *e, dslam_scene *s, int w_d, int h_d,
   ip.push_ring = push_ring >= 0 ? push_ring : 0;
   bp.ops = reinterpret_cast<const BatchOp *>(ops_dev);
   bp.opmask = opmask; bp.slot_entry = slot_entry; bp.cls_list = cls_list; bp.cls_count = cls_count; bp.n_local = s->p.num_local_blocks;
-  bp.a = a; bp.b = b;
-  bp.raw_bytes = (w_d * h_d * 2 + 3) & ~3;
   bp.n_ops = n_ops;
   const bool sharded = ip.num_shards > 1 || ip.shard_count >= 0;
   const dim3 grid(kBatchGrid), block(kBatchWgWaves * 64);

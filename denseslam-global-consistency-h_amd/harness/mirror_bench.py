@@ -30,7 +30,7 @@ import __graft_entry__ as ge  # noqa: E402
 
 HARNESS = os.path.join(ROOT, "denseslam-global-consistency-h_amd", "itmlib", "tests", "driver_harness")
 LINE = re.compile(r"driver_harness loop: (\d+) keyframes in ([\d.]+) ms \(([\d.]+) us per keyframe; host time inside the calls: "
-                  r"UpdateView ([\d.]+), fusion \+ window \+ decay ([\d.]+), raycast ([\d.]+); (\d+) bytes in use")
+                  r"UpdateView ([\d.]+) of which image fill ([\d.]+), fusion \+ window \+ decay ([\d.]+), raycast ([\d.]+); (\d+) bytes in use")
 
 
 def write_frames(path, pkg, wl, n):
@@ -60,8 +60,10 @@ def run_loop(frames, out, decay, window, raycast, swapping, sync, time_from):
     if not m:
         raise RuntimeError("no timing line in:\n" + res.stdout)
     return {"us_per_keyframe": float(m.group(3)), "keyframes_timed": int(m.group(1)),
-            "host_us_in_calls": {"UpdateView": float(m.group(4)), "fusion_window_decay": float(m.group(5)), "raycast": float(m.group(6))},
-            "blocks_in_use_end": int(m.group(7)) // 4096}
+            "host_us_in_calls": {"UpdateView": float(m.group(4)), "of_which_image_fill": float(m.group(5)),
+                                 "fusion_window_decay": float(m.group(6)), "raycast": float(m.group(7))},
+            "us_per_keyframe_without_image_fill": round(float(m.group(3)) - float(m.group(5)), 1),
+            "blocks_in_use_end": int(m.group(8)) // 4096}
 
 
 def measure(keyframes=120, time_from=70, repeats=2, width=640, height=480, loops=None):

@@ -43,10 +43,13 @@ class DriverHarness : public ITMMainEngine {
         online_correction_params_(oc) {}
   ~DriverHarness() { delete rgb_itm_; delete raw_depth_itm_; }
 
-  // InfiniTamDriver::UpdateView (InfiniTamDriver.cpp:280-288)
-  void UpdateView(const uint8_t *rgba, const int16_t *depth, double timestamp) {
+  // InfiniTamDriver::UpdateView (InfiniTamDriver.cpp:280-288): CvToItm x 2 (here: plain copies into the driver's own images,
+  // the cheapest stand-in for the reference's per-pixel loops), then viewBuilder->UpdateView
+  void UpdateView(const uint8_t *rgba, const int16_t *depth, double timestamp, double *fill_us = nullptr) {
+    const auto t0 = std::chrono::steady_clock::now();
     memcpy(rgb_itm_->GetData(MEMORYDEVICE_CPU), rgba, rgb_itm_->dataSize * 4);
     memcpy(raw_depth_itm_->GetData(MEMORYDEVICE_CPU), depth, raw_depth_itm_->dataSize * 2);
+    if (fill_us) *fill_us += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
     this->viewBuilder->UpdateView(&view, rgb_itm_, raw_depth_itm_, timestamp, settings->useBilateralFilter);
   }
   // the same call for a keyframe kept in the device-resident store (DenseSlam.cpp:392,421 without the upload)
@@ -271,6 +274,7 @@ int main(int argc, char **argv) {
     const int time_from = getenv("DRIVER_HARNESS_TIME_FROM") ? atoi(getenv("DRIVER_HARNESS_TIME_FROM")) : 0;
     float image_probe = 0.0f;
     double phase_us[3] = {0, 0, 0};  // UpdateView, fusion + window + decay, per-keyframe raycast
+    double fill_us = 0;              // ... of UpdateView: the copies into the driver's images (CvToItm's stand-in: the caller's own work)
     auto lap = [](std::chrono::steady_clock::time_point &t) {
       const auto now = std::chrono::steady_clock::now();
       const double us = std::chrono::duration<double, std::micro>(now - t).count();
@@ -280,12 +284,12 @@ int main(int argc, char **argv) {
     for (int i = 0; i < N && !oc.enabled; i++) {
       if (i == time_from && i > 0) {
         (void)drv.GetLocalMapUsedMemoryBytes(currentLocalMap);   // (counter read: waits for the keyframes before)
-        phase_us[0] = phase_us[1] = phase_us[2] = 0;
+        phase_us[0] = phase_us[1] = phase_us[2] = fill_us = 0;
         t_loop0 = std::chrono::steady_clock::now();
       }
       auto t = std::chrono::steady_clock::now();
       currentLocalMap->trackingState->pose_d->SetM(poses[i]);                 // SetPoseLocalMap (InfiniTamDriver.h:173-178)
-      drv.UpdateView(rgba[i].data(), depth[i].data(), (double)i);             // DenseSlam.cpp:212
+      drv.UpdateView(rgba[i].data(), depth[i].data(), (double)i, &fill_us);   // DenseSlam.cpp:212
       phase_us[0] += lap(t);
       drv.IntegrateLocalMap(currentLocalMap);                                 // DenseSlam.cpp:213
       fused++;
@@ -305,9 +309,9 @@ int main(int argc, char **argv) {
     const double loop_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_loop0).count();
     if (!oc.enabled && N > 0) {
       const int nt = N - (time_from > 0 && time_from < N ? time_from : 0);
-      printf("driver_harness loop: %d keyframes in %.3f ms (%.1f us per keyframe; host time inside the calls: UpdateView %.1f, fusion + window + decay %.1f, raycast %.1f; "
-             "%zu bytes in use, probe %.3f)\n",
-             nt, loop_s * 1e3, loop_s * 1e6 / nt, phase_us[0] / nt, phase_us[1] / nt, phase_us[2] / nt, used_bytes_after_loop, image_probe);
+      printf("driver_harness loop: %d keyframes in %.3f ms (%.1f us per keyframe; host time inside the calls: UpdateView %.1f of which image fill %.1f, "
+             "fusion + window + decay %.1f, raycast %.1f; %zu bytes in use, probe %.3f)\n",
+             nt, loop_s * 1e3, loop_s * 1e6 / nt, phase_us[0] / nt, fill_us / nt, phase_us[1] / nt, phase_us[2] / nt, used_bytes_after_loop, image_probe);
     }
     free_pose.SetM(poses[N - 1]);
     drv.GetFloatImage(&out_float, free_pose, currentLocalMap);                // DenseSlam.h:146-153
