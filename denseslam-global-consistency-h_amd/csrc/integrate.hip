@@ -994,8 +994,9 @@ struct OpScalars {
 __device__ __forceinline__ float uniform_f(float v) { return __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(v))); }
 __device__ __forceinline__ const void *uniform_ptr(const void *ptr) {
   const unsigned long long a = (unsigned long long)ptr;
-  return (const void *)(((unsigned long long)__builtin_amdgcn_readfirstlane((unsigned)(a >> 32)) << 32) |
-                        (unsigned long long)__builtin_amdgcn_readfirstlane((unsigned)a));
+  // (readfirstlane returns int: the low half must be widened as UNSIGNED, or a set bit 31 smears over the high half)
+  const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((unsigned)(a >> 32)), lo = (unsigned)__builtin_amdgcn_readfirstlane((unsigned)a);
+  return (const void *)(((unsigned long long)hi << 32) | (unsigned long long)lo);
 }
 __device__ __forceinline__ OpScalars op_scalars(const BatchOp &op, int Wd, int Hd, int Wr, int Hr) {
   OpScalars o;
