@@ -408,6 +408,8 @@ def main():
                 barrier()
                 reint.reintegrate(eng, sc, vw, rstate, reint.Batch(frames_st, old_poses, new_poses, wl.intr), timers=tm, batched=True, **kw)
                 barrier()
+                # the distinct blocks the batch loaded and its block-operations ((block, keyframe) pairs de-integrated or re-fused)
+                tm["blocks_touched"], tm["block_operations"] = eng.reintegrate_batch_stats(sc)
                 res["block_major"] = tm
                 sums.append(checksum(sc, vox))
                 store.close()
@@ -421,6 +423,7 @@ def main():
                 tot, rei, agt = max_over_ranks([tm["total_s"], tm["reintegrate_s"], tm["all_gather_s"]])
                 reint_out[form] = {"keyframes_per_s": Kre / tot, "total_ms": tot * 1e3, "compute_ms": rei * 1e3, "all_gather_ms": agt * 1e3,
                                    "gathered_bytes": tm["gathered_bytes"], "dirty_blocks": tm["dirty_blocks"],
+                                   **({"block_operations": int(tm["block_operations"]), "blocks_touched": int(tm["blocks_touched"])} if "block_operations" in tm else {}),
                                    "all_gather_GBps": (tm["gathered_bytes"] / agt / 1e9) if (use_dist and agt > 0) else None}
             reint_out["forms"] = ("reference_calls = DeProcessFrame + ProcessFrame per keyframe as DenseSlam.cpp:389-403 calls them; stored_lists / "
                                   "block_major de-integrate the blocks of the keyframe's own fusion-time list (not the reference's call sequence; "
@@ -482,11 +485,14 @@ def main():
         try:
             from dslam_amd.harness import stress
             eng.set_async(False)
-            r = stress.run(pkg, eng, n_side=64, iterations=20, W=wl.W, H=wl.H)
-            stress_out = {"workload": r["workload"], "visible_blocks": r["visible_blocks"],
-                          "achieved": r["achieved_GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                          "frac": r["achieved_GBps"] / HBM_PEAK_GBS, "avg_launch_us": r["ms_per_launch"] * 1e3,
-                          "launches": r["iterations"], "algorithmic_bytes_per_launch": r["algorithmic_bytes_per_launch"]}
+            def stress_point(as_process_frame):
+                r = stress.run(pkg, eng, n_side=64, iterations=20, W=wl.W, H=wl.H, as_process_frame=as_process_frame)
+                return {"workload": r["workload"], "visible_blocks": r["visible_blocks"],
+                        "achieved": r["achieved_GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": r["achieved_GBps"] / HBM_PEAK_GBS, "avg_launch_us": r["ms_per_launch"] * 1e3,
+                        "launches": r["iterations"], "algorithmic_bytes_per_launch": r["algorithmic_bytes_per_launch"]}
+            stress_out = stress_point(True)            # the production launch: ProcessFrame's, ring push on
+            stress_no_push = stress_point(False)       # IntegrateIntoScene's (what round 3 reported as `stress`)
         except Exception as ex:
             stress_out = {"error": repr(ex)}
 
@@ -540,6 +546,8 @@ def main():
         out["config"].update(extra)
         if stress_out is not None:
             out["roofline"]["stress"] = stress_out
+            if "error" not in stress_out:
+                out["roofline"]["stress_no_push"] = stress_no_push
         if reint_out is not None:
             out["reintegration"] = reint_out
         if not args.no_cpu_baseline and world == 1:

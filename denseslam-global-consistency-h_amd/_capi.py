@@ -336,6 +336,19 @@ class CApi:
         self._call("reintegrate_batch", self._engine, scene.ptr, view.ptr, rs.ptr, fs.ptr, C.c_int(n), _vptr(sl), _fptr(om), _fptr(nm),
                    _fptr(k), C.c_float(affine_a), C.c_float(affine_b))
 
+    def debug_set_push_job_min(self, n):
+        self._call("debug_set_push_job_min", self._engine, C.c_int(int(n)))
+
+    def reintegrate_batch_stats(self, scene):
+        """(blocks the last batch loaded, its block-operations: (block, keyframe) pairs de-integrated or re-fused) -- HIP engine"""
+        b, o = C.c_int32(0), C.c_int32(0)
+        self._call("reintegrate_batch_stats", self._engine, scene.ptr, C.byref(b), C.byref(o))
+        return b.value, o.value
+
+    def scene_table_changed(self, scene):
+        """after the hash table was written through dslam_scene_hash_table_dev: rebuild the allocation bitmap (HIP engine)"""
+        self._call("scene_table_changed", self._engine, scene.ptr)
+
     def view_update_from_store(self, view, fs, slot, affine_a=1.0 / 1000.0, affine_b=0.0, timestamp=0.0, bilateral=False):
         self._call("view_update_from_store", self._engine, view.ptr, fs.ptr, C.c_int(slot), C.c_float(affine_a),
                    C.c_float(affine_b), C.c_double(timestamp), C.c_int(int(bilateral)))

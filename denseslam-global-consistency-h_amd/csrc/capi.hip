@@ -287,6 +287,12 @@ int dslam_debug_set_render_tile_budget(dslam_engine *e, int budget) {
   return DSLAM_OK;
 }
 
+int dslam_debug_set_push_job_min(dslam_engine *e, int min_visible_blocks) {
+  DSLAM_REQUIRE(e && min_visible_blocks >= 0, "bad argument");
+  e->push_job_min = min_visible_blocks;
+  return DSLAM_OK;
+}
+
 int dslam_engine_set_async(dslam_engine *e, int async_mode) {
   DSLAM_REQUIRE(e, "null engine");
   e->async_mode = async_mode != 0;
@@ -999,7 +1005,7 @@ static int batch_scratch(dslam_engine *e, dslam_scene *s, dslam_frame_store *fs)
     DSLAM_HIP(hipMalloc(&s->batch_marks, L * 64));
     DSLAM_HIP(hipMemsetAsync(s->batch_marks, 0, L * 64, e->stream));   // (every batch leaves them zero again)
     DSLAM_HIP(hipMalloc(&s->batch_order, 8 * L * sizeof(int)));
-    DSLAM_HIP(hipMalloc(&s->batch_counters, 8 * sizeof(int)));
+    DSLAM_HIP(hipMalloc(&s->batch_counters, 16 * sizeof(int)));   // [0..8): blocks per class, [8]: block-operations
     DSLAM_HIP(hipMalloc(&s->batch_ops_dev, 2 * kBatchMax * sizeof(HostBatchOp)));
     DSLAM_HIP(hipMalloc(&s->batch_lists_dev, 3 * kBatchMax * sizeof(HostBatchList)));
     DSLAM_HIP(hipHostMalloc(&s->batch_staging, 2 * kBatchMax * sizeof(HostBatchOp) + 3 * kBatchMax * sizeof(HostBatchList), hipHostMallocDefault));
@@ -1053,7 +1059,7 @@ int dslam_reintegrate_batch(dslam_engine *e, dslam_scene *s, dslam_view *v, dsla
   for (int first = 0; first < n; first += kBatchMax) {
     const int K = (n - first) < kBatchMax ? (n - first) : kBatchMax;
     DSLAM_HIP(hipMemsetAsync(s->batch_born, 0, L * sizeof(int), e->stream));
-    DSLAM_HIP(hipMemsetAsync(s->batch_counters, 0, 8 * sizeof(int), e->stream));
+    DSLAM_HIP(hipMemsetAsync(s->batch_counters, 0, 16 * sizeof(int), e->stream));
     // (built in page-locked memory: the copies are queued behind the allocation passes and nothing waits for them here)
     DSLAM_HIP(hipEventSynchronize(s->batch_staging_ev));   // the previous batch's copies have left the buffer
     HostBatchOp *ops = reinterpret_cast<HostBatchOp *>(s->batch_staging);
@@ -1116,6 +1122,20 @@ int dslam_reintegrate_batch(dslam_engine *e, dslam_scene *s, dslam_view *v, dsla
     for (int k = 0; k < K; k++) std::swap(fs->list_ptr[slots[first + k]], fs->batch_list_ptr[k]);
   }
   return finish_call(e);
+}
+
+int dslam_reintegrate_batch_stats(dslam_engine *e, const dslam_scene *s, int32_t *blocks_out, int32_t *block_operations_out) {
+  DSLAM_REQUIRE(e && s && s->engine == e, "null argument");
+  DSLAM_REQUIRE(s->batch_counters, "no batch has run on this scene");
+  int host[16];
+  DSLAM_HIP(hipMemcpyAsync(host, s->batch_counters, sizeof(host), hipMemcpyDeviceToHost, e->stream));
+  const int rc = sync_check(e);
+  if (rc) return rc;
+  int blocks = 0;
+  for (int c = 0; c < 8; c++) blocks += host[c];
+  if (blocks_out) *blocks_out = blocks;
+  if (block_operations_out) *block_operations_out = host[8];
+  return DSLAM_OK;
 }
 
 // ---- depthPostProcessing -------------------------------------------------------------------------------------

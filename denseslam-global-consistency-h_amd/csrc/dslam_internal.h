@@ -110,6 +110,7 @@ struct dslam_engine {
   long long timer_blocks = 0;
   int *timer_counts_dev = nullptr;    // visible-block count of each timed launch (written by the kernel)
   int sm_count = 256;
+  int push_job_min = 65536;           // integrate.hip kPushJobMin; lowered only by the test of the trailing push workgroups
   int render_tile_budget = DSLAM_MAX_RENDERING_BLOCKS;  // MAX_RENDERING_BLOCKS; lowered only by the budget test
   double *icp_partials_host = nullptr;  // depth tracker: per-workgroup partial sums in mapped pinned host memory
   double *icp_partials = nullptr;       // ... and the device address of the same buffer

@@ -32,7 +32,6 @@
 #ifndef DSLAM_COLOUR_QUEUE
 #define DSLAM_COLOUR_QUEUE 1
 #endif
-
 namespace dslam {
 
 struct IntegrateParams {
@@ -58,6 +57,7 @@ struct IntegrateParams {
   unsigned long long *masks;
   int *last_seen;
   int push_words, push_ring, push_bit, push_frame;
+  int push_job_min;  // visible blocks from which on the trailing workgroups queue the list instead of the block waves (kPushJobMin)
   int *timer_slot;  // bench instrumentation: where to record this launch's visible-block count (or null)
   unsigned char *dirty;  // sharded re-integration: per slot "visited since tracking began" (null: not tracked)
   const short4 *expect_pos;  // stored keyframe list: the block each listed entry held at fusion time (null: a live list)
@@ -592,10 +592,56 @@ constexpr int kIntegrateGrid = 8192 / kWgWaves;
 // weighting -- i.e. the per-frame fusion of the reference's configuration.  Compiled without them the kernel carries
 // fewer live arguments (36 scalar registers spilled to VGPR lanes instead of 72, a shorter preamble) and can afford the
 // split update (pair_project / pair_update): 22.9 -> 21.4 us for the specialisation, -> 19.9 us with the split.
+// Queueing the frame's visible list on the ring (ProcessFrame) = one bit per visible resident block in that block's ring word,
+// and its last_seen stamp.  The words lie 64 bytes apart (one line per block), in slot order -- random with respect to the
+// order of the list.  Measured on the S-stress map (V = 262 k, 2.1 GB through the launch; profiles/experiments/
+// push_variants.sh, profiles/r04_push_variants.json): no push 451 us, the last_seen store alone 456, the ring bit as a
+// device-scope atomic from the gathering lane 550 (the product up to round 3: 0.49 of the HBM peak where the kernel without
+// push reaches 0.60), as a plain load-OR-store 522, either of them issued behind the block's stores: the same; with the
+// slots in list order the push costs nothing at all.  What costs is a quarter of a million 64-byte read-modify-writes at
+// random places of a 16 MB array in the middle of a 4.6 TB/s stream -- and, in a block wave's prologue, the wait for them.
+// So above kPushJobMin visible blocks (the voxels no longer fit the Infinity Cache) the block waves do not push: kPushWgs
+// extra workgroups at the END of the grid (they start as block workgroups retire) walk the visible list once more, four
+// entries per lane in flight -- entry (a cache hit: a block wave has just read it), ring word, OR, store -- where a lane
+// that waits holds nothing else up: 506 us = 0.53.  Below it -- every per-frame launch of a real sequence -- the gathering
+// lane's atomic stays: on the bench scene (V = 7.9 k) the trailing workgroups make the launch 0.45 us LONGER (20.0 -> 20.45 us,
+// three alternations), because there the launch ends with its last block wave and they queue behind it.  Same bits, same
+// stamps either way.
+// kPushJobMin = 65536 is dslam_engine::push_job_min (dslam_internal.h): a launch parameter, so that the parity test can lower it
+constexpr int kPushWgs = 64;
+constexpr int kPushPer = 4;   // entries per lane whose loads travel together (id -> entry -> ring word: three round trips per batch)
+__device__ __forceinline__ void push_visible_list_job(const IntegrateParams &p, int wg) {
+  if (!p.push_words) return;
+  const int nvis = p.rc->no_visible;
+  if (nvis < p.push_job_min) return;   // (the block waves push)
+  const unsigned long long bit = 1ull << (p.push_bit & 63);
+  constexpr int kStride = kPushWgs * kWgWaves * 64;
+  for (int i0 = wg * (kWgWaves * 64) + (int)threadIdx.x; i0 < nvis; i0 += kStride * kPushPer) {
+    int id[kPushPer], ptr[kPushPer];
+    unsigned long long old[kPushPer];
+#pragma unroll
+    for (int q = 0; q < kPushPer; q++) id[q] = i0 + q * kStride < nvis ? p.visible_ids[i0 + q * kStride] : -1;
+#pragma unroll
+    for (int q = 0; q < kPushPer; q++) ptr[q] = id[q] >= 0 ? load_entry(p.hash, id[q]).ptr : -1;
+#pragma unroll
+    for (int q = 0; q < kPushPer; q++)
+      old[q] = ptr[q] >= 0 ? p.masks[((size_t)ptr[q] * 2 + p.push_ring) * p.push_words + (p.push_bit >> 6)] : 0ull;
+#pragma unroll
+    for (int q = 0; q < kPushPer; q++)
+      if (ptr[q] >= 0) {   // (one lane per block and launch: no race)
+        p.masks[((size_t)ptr[q] * 2 + p.push_ring) * p.push_words + (p.push_bit >> 6)] = old[q] | bit;
+        p.last_seen[ptr[q]] = p.push_frame;
+      }
+  }
+}
+
 template <bool DEINT, bool SAME_CAM, bool PLAIN = false, bool DIAG = false>
 __global__ __launch_bounds__(kWgWaves * 64, 8) void k_integrate(IntegrateParams p) {
   static_assert(!PLAIN || (!DEINT && SAME_CAM && DSLAM_PACKED && DSLAM_COLOUR_QUEUE), "PLAIN is the queued one-camera fusion");
   static_assert(!DIAG || PLAIN, "the per-wave timeline exists for the plain fusion kernel");
+  if constexpr (PLAIN) {
+    if ((int)blockIdx.x >= kIntegrateGrid) { push_visible_list_job(p, (int)blockIdx.x - kIntegrateGrid); return; }
+  }
   __shared__ float inv_tab[kInvTab];
   [[maybe_unused]] unsigned long long diag_entry = 0, diag_cyc = 0;
   [[maybe_unused]] bool diag_first = true;  // a wave records its first block
@@ -662,7 +708,7 @@ __global__ __launch_bounds__(kWgWaves * 64, 8) void k_integrate(IntegrateParams 
       }
       if (e_ptr >= 0) {
         const int ptr = e_ptr;
-        if (p.push_words) {  // queue this block on the visible-list ring (one lane per block: no race)
+        if (p.push_words && (!PLAIN || nvis < p.push_job_min)) {  // queue this block on the visible-list ring (one lane per block: no race)
           unsigned long long *word = &p.masks[((size_t)ptr * 2 + p.push_ring) * p.push_words + (p.push_bit >> 6)];
           // (PLAIN: an atomic OR whose result nobody reads -- nothing to wait for in front of the block loads)
           if constexpr (PLAIN) __hip_atomic_fetch_or(word, 1ull << (p.push_bit & 63), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -882,6 +928,7 @@ static int launch_integrate_params(dslam_engine *e, IntegrateParams &ip, bool de
     e->ev_used += 2;
   }
   const dim3 grid(kIntegrateGrid), block(kWgWaves * 64);
+  const dim3 grid_plain(kIntegrateGrid + kPushWgs);   // (+ the workgroups that queue the visible list on the ring)
   if (deintegrate) {
     if (ip.same_cam) hipExtLaunchKernelGGL((k_integrate<true, true>), grid, block, 0, e->stream, ev0, ev1, 0, ip);
     else hipExtLaunchKernelGGL((k_integrate<true, false>), grid, block, 0, e->stream, ev0, ev1, 0, ip);
@@ -897,7 +944,7 @@ static int launch_integrate_params(dslam_engine *e, IntegrateParams &ip, bool de
       DSLAM_HIP(hipMalloc((void **)&trace_dev, kTraceBytes));
       DSLAM_HIP(hipMemsetAsync(trace_dev, 0, kTraceBytes, e->stream));
       ip.dbg_waves = trace_dev;
-      hipExtLaunchKernelGGL((k_integrate<false, true, DSLAM_PACKED && DSLAM_COLOUR_QUEUE, DSLAM_PACKED && DSLAM_COLOUR_QUEUE>), grid, block, 0, e->stream, ev0, ev1, 0, ip);
+      hipExtLaunchKernelGGL((k_integrate<false, true, DSLAM_PACKED && DSLAM_COLOUR_QUEUE, DSLAM_PACKED && DSLAM_COLOUR_QUEUE>), grid_plain, block, 0, e->stream, ev0, ev1, 0, ip);
       DSLAM_HIP(hipGetLastError());
       DSLAM_HIP(hipStreamSynchronize(e->stream));
       std::vector<unsigned long long> h(kTraceBytes / sizeof(unsigned long long));
@@ -906,7 +953,7 @@ static int launch_integrate_params(dslam_engine *e, IntegrateParams &ip, bool de
       (void)hipFree(trace_dev);
       return DSLAM_OK;
     }
-    if (plain) hipExtLaunchKernelGGL((k_integrate<false, true, DSLAM_PACKED && DSLAM_COLOUR_QUEUE>), grid, block, 0, e->stream, ev0, ev1, 0, ip);
+    if (plain) hipExtLaunchKernelGGL((k_integrate<false, true, DSLAM_PACKED && DSLAM_COLOUR_QUEUE>), grid_plain, block, 0, e->stream, ev0, ev1, 0, ip);
     else if (ip.same_cam) hipExtLaunchKernelGGL((k_integrate<false, true>), grid, block, 0, e->stream, ev0, ev1, 0, ip);
     else hipExtLaunchKernelGGL((k_integrate<false, false>), grid, block, 0, e->stream, ev0, ev1, 0, ip);
   }
@@ -922,6 +969,7 @@ int launch_integrate(dslam_engine *e, dslam_scene *s, const dslam_view *v, const
   IntegrateParams ip;
   fill_params(ip, e, s, v, r, M_d, intr_d, M_rgb, intr_rgb);
   ip.masks = s->masks; ip.last_seen = s->last_seen; ip.push_words = 0; ip.push_ring = 0; ip.push_bit = 0; ip.push_frame = 0;
+  ip.push_job_min = e->push_job_min;
   ip.spec_ids = r->n_local >= kIntegrateGrid * kWgWaves ? 1 : 0;  // (a visible list has room for every voxel-block slot)
   if (push_ring >= 0) {
     if ((rc = prepare_push_visible_list(e, s, push_ring, &ip.push_bit, &ip.push_frame))) return rc;
@@ -943,6 +991,7 @@ int launch_integrate_list(dslam_engine *e, dslam_scene *s, const dslam_view *v, 
   fill_params(ip, e, s, v, &list_view, M_d, intr_d, M_rgb, intr_rgb);
   ip.expect_pos = expect_pos;
   ip.masks = s->masks; ip.last_seen = s->last_seen; ip.push_words = 0; ip.push_ring = 0; ip.push_bit = 0; ip.push_frame = 0;
+  ip.push_job_min = e->push_job_min;
   return launch_integrate_params(e, ip, deintegrate);
 }
 
@@ -1296,7 +1345,9 @@ __global__ __launch_bounds__(256) void k_batch_assemble(uint4 *marks16, int n_sl
   // (one counter update per workgroup and class: updates of one address from all over the device serialise at ~12 ns each --
   // per wave and class they were 100 us of this launch)
   __shared__ int s_cnt[kBatchClasses], s_base[kBatchClasses];
+  __shared__ int s_ops_total;   // (diagnostics: the batch's block-operations, cls_count[kBatchClasses])
   if (threadIdx.x < kBatchClasses) s_cnt[threadIdx.x] = 0;
+  if (threadIdx.x == 0) s_ops_total = 0;
   __syncthreads();
   const int quarter = threadIdx.x & 3;
   int cls[kAsmIter], pos[kAsmIter];
@@ -1332,6 +1383,7 @@ __global__ __launch_bounds__(256) void k_batch_assemble(uint4 *marks16, int n_sl
         const int c = (64 - __popcll(mask)) >> 3;   // 0: 57..64 operations ... 7: 1..8
         cls[it0 + q] = c;
         pos[it0 + q] = atomicAdd(&s_cnt[c], 1);
+        atomicAdd(&s_ops_total, __popcll(mask));
       }
     }
   }
@@ -1340,6 +1392,7 @@ __global__ __launch_bounds__(256) void k_batch_assemble(uint4 *marks16, int n_sl
     const int c = s_cnt[threadIdx.x];
     s_base[threadIdx.x] = c ? atomicAdd(&cls_count[threadIdx.x], c) : 0;
   }
+  if (threadIdx.x == 0 && s_ops_total) atomicAdd(&cls_count[kBatchClasses], s_ops_total);
   __syncthreads();
 #pragma unroll
   for (int it = 0; it < kAsmIter; it++)

@@ -44,11 +44,15 @@ def build_lattice_state(pkg, n_side, num_buckets, num_excess):
     return table, visible, excess_list, len(free_ex) - 1
 
 
-def run(pkg, eng, n_side=64, iterations=20, W=640, H=480, slots_in_list_order=False):
+def run(pkg, eng, n_side=64, iterations=20, W=640, H=480, slots_in_list_order=False, as_process_frame=False):
     """slots_in_list_order: the r-th visible entry holds voxel-block slot r (the blocks are then visited in memory order);
-    default: slots in lattice order = random with respect to the list (hash) order -- the worse case for HBM page locality."""
+    default: slots in lattice order = random with respect to the list (hash) order -- the worse case for HBM page locality.
+    as_process_frame: the kernel as dslam_process_frame launches it -- the frame's visible list queued on the ring in the
+    same launch, as every per-frame fusion has it (the production launch); default: as dslam_integrate_into_scene launches
+    it (no ring push).  The frustum then ends in front of the 30 m depth plane, so that ProcessFrame's allocation pass marks
+    nothing on the full pool (integration has no frustum test: every voxel is still updated)."""
     n = n_side ** 3
-    params = pkg.SceneParams(voxel_size=0.01, mu=0.04, max_w=100, frustum_min=0.2, frustum_max=100.0,
+    params = pkg.SceneParams(voxel_size=0.01, mu=0.04, max_w=100, frustum_min=0.2, frustum_max=20.0 if as_process_frame else 100.0,
                              num_local_blocks=n, num_buckets=0x100000, num_excess=0x20000)
     scene = eng.create_scene(params)
     rs = eng.create_render_state(scene, W, H)
@@ -67,18 +71,22 @@ def run(pkg, eng, n_side=64, iterations=20, W=640, H=480, slots_in_list_order=Fa
     intr = np.array([100.0, 100.0, (W - 1) / 2.0, (H - 1) / 2.0], np.float32)  # wide FOV: the lattice projects inside
     # one warm-up launch, then `iterations` launches timed one by one with events attached to the dispatch packets
     # (the kernel's own start-to-end interval, what rocprofv3 reports; bench.py times the headline launch the same way)
-    eng.integrate_into_scene(scene, view, rs, M, intr)
+    call = (lambda: eng.process_frame(scene, view, rs, M, intr)) if as_process_frame else (lambda: eng.integrate_into_scene(scene, view, rs, M, intr))
+    call()
+    call()
     eng.synchronize()
     eng.kernel_timer_enable(True)
     for _ in range(iterations):
-        eng.integrate_into_scene(scene, view, rs, M, intr)
+        call()
     total_ms, launches, blocks = eng.kernel_timer_read()
     eng.kernel_timer_enable(False)
     ms, nvis = total_ms / max(1, launches), blocks // max(1, launches)
     vox = eng.download_voxel_blocks(scene, 0, 64)
     updated = float((vox["w_depth"] > 0).mean())
     alg_bytes = 8212.0 * nvis + 8.0 * W * H
-    return {"workload": f"S-stress lattice {n_side}^3" + (", slots in list order" if slots_in_list_order else ""), "visible_blocks": nvis, "ms_per_launch": ms,
+    return {"workload": f"S-stress lattice {n_side}^3" + (", slots in list order" if slots_in_list_order else "") +
+                        (", launched by ProcessFrame (visible-list ring push on)" if as_process_frame else ", launched by IntegrateIntoScene (no ring push)"),
+            "visible_blocks": nvis, "ms_per_launch": ms,
             "algorithmic_bytes_per_launch": alg_bytes, "achieved_GBps": alg_bytes / (ms * 1e-3) / 1e9,
             "frac_of_8TBps": alg_bytes / (ms * 1e-3) / 1e9 / 8000.0, "voxels_updated_frac_sample": updated,
             "iterations": iterations}
@@ -90,6 +98,7 @@ if __name__ == "__main__":
     pkg = ge.load_package()
     eng = pkg.open_engine(0)
     n_side = int(sys.argv[1]) if len(sys.argv) > 1 else 64
-    out = run(pkg, eng, n_side=n_side)
-    out["slots_in_list_order"] = run(pkg, pkg.open_engine(0), n_side=n_side, slots_in_list_order=True)
+    out = run(pkg, eng, n_side=n_side, as_process_frame=True)
+    out["no_push"] = run(pkg, pkg.open_engine(0), n_side=n_side)
+    out["slots_in_list_order"] = run(pkg, pkg.open_engine(0), n_side=n_side, slots_in_list_order=True, as_process_frame=True)
     print(json.dumps(out))

@@ -169,6 +169,11 @@ int dslam_selftest_division(dslam_engine *e, long long samples, long long *misma
  * Upstream drops, in visible-list order, every block whose tiles would reach the budget; real scenes never get
  * there (it takes > 262144 tiles), so the parity test of that rule lowers the budget instead. */
 int dslam_debug_set_render_tile_budget(dslam_engine *e, int budget);
+/* Test hook: ProcessFrame queues the frame's visible list on the ring either from the fusion kernel's block waves or -- from
+ * this many visible blocks on (default 65536: maps whose visible voxels no longer fit the Infinity Cache) -- from extra
+ * workgroups at the end of the same launch (csrc/integrate.hip, kPushJobMin).  Same bits either way; the parity test of the
+ * second form lowers the threshold instead of building a quarter-million-block scene for the oracle. */
+int dslam_debug_set_push_job_min(dslam_engine *e, int min_visible_blocks);
 
 /* ---- scene ------------------------------------------------------------------------------------- */
 /* new ITMScene(sceneParams, useSwapping, memoryType) + ResetScene.  ext_voxel_blocks_dev may be NULL
@@ -301,6 +306,10 @@ int dslam_deprocess_frame_stored(dslam_engine *e, dslam_scene *s, const dslam_vi
 int dslam_reintegrate_batch(dslam_engine *e, dslam_scene *s, dslam_view *v, dslam_render_state *r, dslam_frame_store *fs,
                             int n, const int32_t *slots, const float *old_M, const float *new_M, const float intr[4],
                             float affine_a, float affine_b);
+
+/* what the last dslam_reintegrate_batch (its last chunk of <= 32 keyframes) worked on: the distinct voxel blocks it loaded, and
+ * its block-operations -- (block, keyframe) pairs de-integrated or re-fused, the unit the block kernel's cost is quoted in */
+int dslam_reintegrate_batch_stats(dslam_engine *e, const dslam_scene *s, int32_t *blocks_out, int32_t *block_operations_out);
 
 /* DenseSlam::depthPostProcessing's pixel loop (DenseSlam.cpp:488-529): blanks (sets to 0) every pixel of the
  * current keyframe's depth whose reprojection into the previous keyframe disagrees with that keyframe's depth by

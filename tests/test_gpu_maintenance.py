@@ -77,6 +77,21 @@ def test_slide_window(pkg, synth, gpu, oracle):
     assert st["fusion_fifo_len"] == 3 and st["slid_block_count"] > 0
 
 
+def test_ring_push_by_trailing_workgroups(pkg, synth, gpu, oracle):
+    """From 65536 visible blocks on, ProcessFrame's fusion kernel queues the visible list on the ring from extra workgroups
+    at the end of its grid instead of from its block waves (integrate.hip, kPushJobMin).  The threshold is lowered to 0 here,
+    so that every frame of a window + decay sequence takes that path: rings (through what the window releases), last_seen
+    and the map must be the oracle's after every frame."""
+    wl = synth.s_tiny()
+    p = util.small_params(pkg, wl)
+    gpu.debug_set_push_job_min(0)
+    try:
+        objs, last = _run_pair(gpu, oracle, pkg, wl, p, 14, decay=(1, 2, True), slide=4)
+    finally:
+        gpu.debug_set_push_job_min(65536)
+    assert last["gpu"]["stats"]["slid_block_count"] > 0
+
+
 def test_slide_window_and_decay_together(pkg, synth, gpu, oracle):
     wl = synth.s_tiny()
     p = util.small_params(pkg, wl)
