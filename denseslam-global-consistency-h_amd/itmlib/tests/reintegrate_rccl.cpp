@@ -1,7 +1,7 @@
 // reintegrate_rccl.cpp -- the sharded global re-integration of INTEGRATION.md section 5 as a native program: one process
 // per GPU, the C ABI of include/dslam_fusion.h, RCCL (ncclAllGather) for the one exchange (BASELINE configs[4]).
 //
-//   RANK=r WORLD_SIZE=n DSLAM_NCCL_ID_FILE=/shared/path  reintegrate_rccl frames.bin out.bin [K]
+//   RANK=r WORLD_SIZE=n DSLAM_NCCL_ID_FILE=/shared/path  reintegrate_rccl frames.bin out.bin [K] [--batched]
 //
 // Every rank fuses the same N keyframes (frames.bin has driver_harness's layout), then the last K keyframes (default 4)
 // get a pose correction (keyframe j of the batch: camera-frame translation (0.01 (j+1), 0, 0.02) m): each is
@@ -10,8 +10,13 @@
 // by the rank that owns their slot ((slot / 64) % world); one all-gather of the used slot range makes the replicas
 // whole again.  With WORLD_SIZE=1 the exchange is a single-rank all-gather: same code path, checked against the
 // unsharded result by tests/test_gpu_itmlib_shim.py.  Rank 0 creates the ncclUniqueId and shares it through the file.
-// out.bin: int32 lastFreeBlockId, int32 noVisible, uint64 fnv1a(hash table), uint64 fnv1a(voxel blocks), double ms of
-// the re-integration, double ms of the all-gather, uint64 bytes gathered per rank.
+// --batched: the keyframes sit in a device-resident keyframe store with the visible lists of their fusion, and the whole
+// correction is ONE dslam_reintegrate_batch call per rank (block-major: the allocation passes first, then every touched
+// voxel block loaded once); de-integration then visits each keyframe's own stored list.
+// Every rank checks the result: the checksums of the hash table and of the voxel blocks are reduced over the ranks with
+// ncclAllReduce (min and max); a rank whose replica differs makes every rank exit with status 3.
+// out.bin (rank 0): int32 lastFreeBlockId, int32 noVisible, uint64 fnv1a(hash table), uint64 fnv1a(voxel blocks), double ms
+// of the re-integration, double ms of the all-gather, uint64 bytes gathered per rank, int32 replicas equal (1 / 0).
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 #include <unistd.h>
@@ -48,7 +53,9 @@ int main(int argc, char **argv) {
   int32_t hdr[3];
   if (fread(hdr, 4, 3, f) != 3) return 2;
   const int W = hdr[0], H = hdr[1], N = hdr[2];
-  const int K = argc > 3 ? atoi(argv[3]) : (N < 4 ? N : 4);
+  const int K = argc > 3 && argv[3][0] != '-' ? atoi(argv[3]) : (N < 4 ? N : 4);
+  bool batched = false;
+  for (int a = 3; a < argc; a++) batched = batched || strcmp(argv[a], "--batched") == 0;
   std::vector<std::vector<uint8_t>> rgba(N, std::vector<uint8_t>((size_t)W * H * 4));
   std::vector<std::vector<int16_t>> depth(N, std::vector<int16_t>((size_t)W * H));
   std::vector<std::vector<float>> poses(N, std::vector<float>(16));
@@ -96,25 +103,40 @@ int main(int argc, char **argv) {
   CHECK_DSLAM(dslam_scene_create(eng, &p, nullptr, &scene));
   CHECK_DSLAM(dslam_render_state_create(eng, scene, W, H, &rs));
   CHECK_DSLAM(dslam_view_create(eng, W, H, W, H, &view));
+  dslam_frame_store *store = nullptr;   // (--batched) mfusionFrameDataBase's images + the visible lists of the fusions
+  if (batched) {
+    CHECK_DSLAM(dslam_frame_store_create(eng, W, H, W, H, N, &store));
+    CHECK_DSLAM(dslam_frame_store_enable_lists(eng, store, scene));
+  }
   for (int i = 0; i < N; i++) {  // the live fusion every replica has done
     CHECK_DSLAM(dslam_view_update(eng, view, rgba[i].data(), depth[i].data(), 1e-3f, 0.0f, (double)i, 0));
+    if (batched) CHECK_DSLAM(dslam_frame_store_put_view(eng, store, i, view));
     CHECK_DSLAM(dslam_process_frame(eng, scene, view, rs, poses[i].data(), intr, nullptr, nullptr, 0, 0));
+    if (batched) CHECK_DSLAM(dslam_frame_store_put_visible_list(eng, store, i, scene, rs));
   }
+  if (batched) CHECK_DSLAM(dslam_reintegrate_batch(eng, scene, view, rs, store, 0, nullptr, nullptr, nullptr, intr, 1e-3f, 0.0f));  // (set-up call)
 
   // ---- the corrected batch, sharded --------------------------------------------------------------------------------
   const int chunk = 64;  // voxel-block slots per ownership chunk (256 KiB)
   const auto t0 = std::chrono::steady_clock::now();
   CHECK_DSLAM(dslam_scene_track_dirty(eng, scene, 1));  // from here on the kernels note every block they visit
   CHECK_DSLAM(dslam_scene_set_shard(scene, rank, world, chunk));
+  std::vector<int32_t> slots(K);
+  std::vector<float> old_M((size_t)K * 16), new_M((size_t)K * 16);
   for (int j = 0; j < K; j++) {
     const int i = N - K + j;
     std::vector<float> corrected = poses[i];  // column-major world -> camera; a camera-frame translation adds to column 3
     corrected[12] += 0.01f * (float)(j + 1);
     corrected[14] += 0.02f;
+    slots[j] = i;
+    memcpy(&old_M[(size_t)j * 16], poses[i].data(), 64);
+    memcpy(&new_M[(size_t)j * 16], corrected.data(), 64);
+    if (batched) continue;
     CHECK_DSLAM(dslam_view_update(eng, view, rgba[i].data(), depth[i].data(), 1e-3f, 0.0f, (double)i, 0));
     CHECK_DSLAM(dslam_deprocess_frame(eng, scene, view, rs, poses[i].data(), intr, nullptr, nullptr));
     CHECK_DSLAM(dslam_process_frame(eng, scene, view, rs, corrected.data(), intr, nullptr, nullptr, 0, /*isDefusion*/ 1));
   }
+  if (batched) CHECK_DSLAM(dslam_reintegrate_batch(eng, scene, view, rs, store, K, slots.data(), old_M.data(), new_M.data(), intr, 1e-3f, 0.0f));
   dslam_stats st;
   CHECK_DSLAM(dslam_get_stats(eng, scene, rs, &st));  // synchronises; identical on every rank
   const auto t1 = std::chrono::steady_clock::now();
@@ -148,6 +170,27 @@ int main(int argc, char **argv) {
   CHECK_DSLAM(dslam_download_voxel_blocks(eng, scene, 0, p.num_local_blocks, vox.data()));
   const double ms_reint = std::chrono::duration<double, std::milli>(t1 - t0).count();
   const double ms_gather = std::chrono::duration<double, std::milli>(t2 - t1).count();
+  // every rank's replica must be the same map: min and max of the checksums over the ranks
+  int32_t replicas_equal = 1;
+  {
+    const uint64_t mine[2] = {fnv1a(hash.data(), hash.size() * sizeof(dslam_hash_entry)), fnv1a(vox.data(), vox.size() * sizeof(dslam_voxel))};
+    uint64_t *dev = nullptr, lo[2], hi[2];
+    CHECK_HIP(hipMalloc(&dev, 4 * sizeof(uint64_t)));
+    CHECK_HIP(hipMemcpy(dev, mine, sizeof(mine), hipMemcpyHostToDevice));
+    hipStream_t stream = static_cast<hipStream_t>(dslam_engine_stream(eng));
+    CHECK_NCCL(ncclAllReduce(dev, dev + 2, 2, ncclUint64, ncclMin, comm, stream));
+    CHECK_HIP(hipStreamSynchronize(stream));
+    CHECK_HIP(hipMemcpy(lo, dev + 2, sizeof(lo), hipMemcpyDeviceToHost));
+    CHECK_NCCL(ncclAllReduce(dev, dev + 2, 2, ncclUint64, ncclMax, comm, stream));
+    CHECK_HIP(hipStreamSynchronize(stream));
+    CHECK_HIP(hipMemcpy(hi, dev + 2, sizeof(hi), hipMemcpyDeviceToHost));
+    CHECK_HIP(hipFree(dev));
+    if (lo[0] != hi[0] || lo[1] != hi[1]) {
+      replicas_equal = 0;
+      fprintf(stderr, "rank %d: replicas differ after the exchange (hash table %s, voxel blocks %s; mine %016llx %016llx)\n", rank,
+              lo[0] == hi[0] ? "equal" : "DIFFERENT", lo[1] == hi[1] ? "equal" : "DIFFERENT", (unsigned long long)mine[0], (unsigned long long)mine[1]);
+    }
+  }
   if (rank == 0) {
     FILE *o = fopen(argv[2], "wb");
     if (!o) { perror("out"); return 2; }
@@ -155,14 +198,16 @@ int main(int argc, char **argv) {
     const uint64_t sums[2] = {fnv1a(hash.data(), hash.size() * sizeof(dslam_hash_entry)), fnv1a(vox.data(), vox.size() * sizeof(dslam_voxel))};
     const uint64_t g = gathered;
     fwrite(head, 4, 2, o); fwrite(sums, 8, 2, o); fwrite(&ms_reint, 8, 1, o); fwrite(&ms_gather, 8, 1, o); fwrite(&g, 8, 1, o);
+    fwrite(&replicas_equal, 4, 1, o);
     fclose(o);
-    printf("reintegrate_rccl ok: world %d, %d keyframes re-integrated in %.3f ms, all-gather of %zu bytes per rank in %.3f ms\n",
-           world, K, ms_reint, gathered, ms_gather);
+    printf("reintegrate_rccl %s: world %d, %d keyframes re-integrated%s in %.3f ms, all-gather of %zu bytes per rank in %.3f ms\n",
+           replicas_equal ? "ok" : "FAILED (replicas differ)", world, K, batched ? " (one dslam_reintegrate_batch call)" : "", ms_reint, gathered, ms_gather);
   }
+  if (store) dslam_frame_store_destroy(store);
   dslam_view_destroy(view);
   dslam_render_state_destroy(rs);
   dslam_scene_destroy(scene);
   dslam_engine_destroy(eng);
   ncclCommDestroy(comm);
-  return 0;
+  return replicas_equal ? 0 : 3;
 }

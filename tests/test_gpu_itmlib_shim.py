@@ -130,7 +130,8 @@ def test_rccl_program_is_built():
 
 
 @pytest.mark.gpu
-def test_native_rccl_reintegration_single_rank_matches_unsharded_oracle(pkg, synth, oracle, tmp_path):
+@pytest.mark.parametrize("batched", [False, True])
+def test_native_rccl_reintegration_single_rank_matches_unsharded_oracle(pkg, synth, oracle, tmp_path, batched):
     """INTEGRATION.md section 5 as a compiled program (C ABI + RCCL): fuse, then de-integrate / re-integrate the last
     keyframes at corrected poses with the voxel blocks sharded by slot, one ncclAllGather.  With one rank the exchange is
     a single-rank all-gather through exactly the multi-rank code path (pack -> ncclAllGather -> unpack); the map must
@@ -149,28 +150,47 @@ def test_native_rccl_reintegration_single_rank_matches_unsharded_oracle(pkg, syn
         f.write(struct.pack("<4f", p.voxel_size, p.mu, p.frustum_min, p.frustum_max))
         f.write(struct.pack("<4i", p.max_w, p.num_local_blocks, p.num_buckets, p.num_excess))
     env = dict(os.environ, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
-    res = subprocess.run([RCCL_PROG, str(fin), str(fout), str(K)], capture_output=True, text=True, timeout=300, env=env)
+    # --batched: the keyframes in a device-resident store with their fusion-time lists, the correction as ONE
+    # dslam_reintegrate_batch call; either way every rank compares checksums over the ranks and exits 3 on a mismatch
+    res = subprocess.run([RCCL_PROG, str(fin), str(fout), str(K)] + (["--batched"] if batched else []), capture_output=True, text=True,
+                         timeout=300, env=env)
     assert res.returncode == 0, res.stdout + res.stderr
+    assert ("one dslam_reintegrate_batch call" in res.stdout) == batched
     raw = open(fout, "rb").read()
     last_free, no_vis = struct.unpack_from("<2i", raw, 0)
     h_hash, h_vox = struct.unpack_from("<2Q", raw, 8)
     ms_reint, ms_gather = struct.unpack_from("<2d", raw, 24)
     (gathered,) = struct.unpack_from("<Q", raw, 40)
+    assert struct.unpack_from("<i", raw, 48)[0] == 1, "the program's own cross-rank check"
 
     s = oracle.create_scene(p)
     rs = oracle.create_render_state(s, wl.W, wl.H)
     v = oracle.create_view(wl.W, wl.H)
+    store = oracle.create_frame_store(wl.W, wl.H, n_frames) if batched else None
+    if batched:
+        oracle.frame_store_enable_lists(store, s)
     for i, (rgba, mm, M) in enumerate(frames):
         oracle.view_update(v, rgba, mm, timestamp=float(i))
+        if batched:
+            oracle.frame_store_put_view(store, i, v)
         oracle.process_frame(s, v, rs, M, wl.intr)
+        if batched:
+            oracle.frame_store_put_visible_list(store, i, s, rs)
+    corrected = []
     for j in range(K):
         rgba, mm, M = frames[n_frames - K + j]
         Mc = np.array(M, np.float32)
         Mc[0, 3] += np.float32(0.01) * np.float32(j + 1)  # row-major here; the program adds to column 3 of the ABI layout
         Mc[2, 3] += np.float32(0.02)
+        corrected.append(Mc)
+        if batched:
+            continue
         oracle.view_update(v, rgba, mm, timestamp=float(n_frames - K + j))
         oracle.deprocess_frame(s, v, rs, M, wl.intr)
         oracle.process_frame(s, v, rs, Mc, wl.intr, is_defusion=True)
+    if batched:
+        ids = list(range(n_frames - K, n_frames))
+        oracle.reintegrate_batch(s, v, rs, store, ids, [frames[i][2] for i in ids], corrected, wl.intr)
     st = oracle.stats(s, rs)
     assert last_free == st["last_free_block_id"] and no_vis == st["no_visible_entries"]
     assert h_hash == fnv1a(oracle.download_hash_table(s).tobytes())
