@@ -543,8 +543,6 @@ static int render_state_allocate(dslam_engine *e, dslam_render_state *r) {
   DSLAM_HIP(hipMemsetAsync(r->raycast, 0, npix * sizeof(float4), e->stream));
   DSLAM_HIP(hipMemsetAsync(r->image_rgba, 0, npix * sizeof(uchar4), e->stream));
   DSLAM_HIP(hipMemsetAsync(r->image_float, 0, npix * sizeof(float), e->stream));
-  const int rc_march = march_lists_allocate(e, r);
-  if (rc_march) return rc_march;
   DSLAM_HIP(hipStreamSynchronize(e->stream));
   return DSLAM_OK;
 }
@@ -569,7 +567,6 @@ int dslam_render_state_destroy(dslam_render_state *r) {
   free_dev(r->visible_ids); free_dev(r->visible_type); free_dev(r->vis_bits); free_dev(r->range); free_dev(r->raycast);
   free_dev(r->image_rgba); free_dev(r->image_float); free_dev(r->icp_points); free_dev(r->icp_normals);
   free_dev(r->raycast_image);
-  free_dev(r->march_vis); free_dev(r->march_shadow); free_dev(r->march_lists); free_dev(r->march_cnt);
   free_dev(r->proj_boxes); free_dev(r->proj_z); free_dev(r->proj_req); free_dev(r->proj_wg_tiles); free_dev(r->counters);
   delete r;
   return DSLAM_OK;
@@ -1395,7 +1392,7 @@ static int get_image_on_device(dslam_engine *e, const dslam_scene *s, dslam_rend
   r->memo_valid = false;
   r->types_follow_list = false;  // FindVisibleBlocks replaces this render state's list
   if ((rc = launch_find_visible_and_depths(e, s, r, M, intr))) return rc;
-  if ((rc = launch_render(e, s, r, M, intr, type, false, direct_out, true))) return rc;   // (march tables from this view's lists)
+  if ((rc = launch_render(e, s, r, M, intr, type, false, direct_out))) return rc;
   r->memo_valid = true; r->memo_scene = s; r->memo_version = s->version; r->memo_budget = e->render_tile_budget;
   memcpy(r->memo_M, M, sizeof(r->memo_M));
   memcpy(r->memo_intr, intr, sizeof(r->memo_intr));

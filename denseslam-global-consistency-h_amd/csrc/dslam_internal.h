@@ -197,11 +197,6 @@ struct dslam_render_state {
   int *proj_req = nullptr;      // per visible block: render tiles required (0 = invalid projection)
   int *proj_wg_tiles = nullptr; // render tiles requested per workgroup of the projection pass (summed by the next kernel)
   dslam::RenderCounters *counters = nullptr;  // device
-  // per-cell block tables of the ray march (raycast.hip): GetImage's lists; two alternating sets of counters
-  uint4 *march_vis = nullptr, *march_shadow = nullptr, *march_lists = nullptr;
-  int *march_cnt = nullptr;
-  int march_cnt_stride = 0, march_set = 0;
-  bool march_valid = false;   // the lists are those of the range image / visible list this render state holds now
   // entriesVisibleType carries a generation bit (0x80): an allocation pass writes its marks with the pass' bit, so a
   // non-zero byte with the OTHER bit is "visible in the previous pass" (upstream's re-arming of the previous visible
   // list as type 3) without a pass over that list.  The C ABI hands out the plain types (bit masked off).
@@ -328,13 +323,12 @@ int launch_count_visible(dslam_engine *e, const dslam_scene *s, const dslam_rend
                          int *out);
 int launch_expected_depths(dslam_engine *e, const dslam_scene *s, dslam_render_state *r, const float *M,
                            const float *intr);
-int march_lists_allocate(dslam_engine *e, dslam_render_state *r);
 int launch_find_visible_and_depths(dslam_engine *e, const dslam_scene *s, dslam_render_state *r, const float *M,
                                    const float *intr);
 int launch_track_camera(dslam_engine *e, const dslam_view *v, dslam_render_state *r, const float *scenePose, float *pose_M,
                         const float *intr, const dslam_tracker_params *tp, dslam_tracker_result *res);
 int launch_render(dslam_engine *e, const dslam_scene *s, dslam_render_state *r, const float *M, const float *intr,
-                  int type, bool reuse_raycast = false, void *image_out_override = nullptr, bool march_lists = false);
+                  int type, bool reuse_raycast = false, void *image_out_override = nullptr);
 int launch_icp_maps(dslam_engine *e, const dslam_scene *s, dslam_render_state *r, const float *M, const float *intr);
 int launch_mesh_scene(dslam_engine *e, const dslam_scene *s, int max_triangles, int with_colour, int *out_num);
 int launch_decay(dslam_engine *e, dslam_scene *s, dslam_render_state *r, int max_weight, int min_age, int force_all,

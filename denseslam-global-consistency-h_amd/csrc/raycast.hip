@@ -26,118 +26,7 @@ struct FrustumParams {
   Mat4 M;
   float fx, fy, cx, cy, voxel_size;
   int W, H;
-  // inward unit normals of the four side planes of the view pyramid, opened by one pixel on every side (bounding-sphere
-  // rejection in front of the 8-corner test, see sphere_outside)
-  float nl[3], nr[3], nt[3], nb[3];
 };
-
-// ---------------------------------------------------------------------------------------------------------
-// Per-cell block tables for the ray march (round 4)
-// ---------------------------------------------------------------------------------------------------------
-// Every march step looks its voxel block up: a 16-byte probe of the 19 MB hash table (Infinity-Cache latency, ~1000 cycles)
-// on the critical path of a wave whose launch lasts as long as its longest chain of such steps.  Every variant of rounds
-// 1-3 kept that probe.  Here GetImage hands each 8x8-pixel cell -- one k_render workgroup -- the COMPLETE set
-// of allocated blocks its rays can touch, and the workgroup builds an open-addressed table in LDS from it before it
-// marches: a lookup, hit or MISS, is then an LDS probe, and only the tap loads go to memory.
-//   exactness  a miss in the table must be a true miss.  A ray of pixel (x, y) asks for the blocks of ROUND(p) and of
-//              floor(p) .. floor(p) + 1 at points p ON its ray: block B is asked for only if p lies within [8 B - 1, 8 B + 8]
-//              voxels on every axis.  So the "march box" of an allocated block is the pixel bounding box of that EXPANDED cube
-//              (its 8 corners projected; exact for a cube in front of the camera, whose image is the hull of its corners;
-//              one pixel of slack), and a cell's table holds every allocated block whose march box contains the cell --
-//              visible by upstream's 8-corner rule or not: the selection over alloc_bits sees every allocated entry, and
-//              those that fail the rule but whose march box meets the screen come along as "shadow" entries.  A cube that
-//              straddles the camera plane has no such box: it goes to every cell unless its bounding sphere misses the
-//              view pyramid.  Whatever cannot be held (a list or a table that overflows) sends that cell's workgroup
-//              back to the global probe -- the result is the same either way, bit for bit.
-//   lists      (block position, slot, march box) per visible-list rank + the shadow entries -> k_fill_range_tiles, which
-//              already visits every visible block per 16x16-cell tile, drops them into lists per 8x8-cell SUB-tile
-//              (one LDS count + one global atomic per workgroup and sub-tile) -> k_render scans its sub-tile's list.
-constexpr int kSubTile = 8;          // cells per side of a list tile
-constexpr int kSubTileCap = 2048;    // entries per list (a longer list: that sub-tile's cells use the global probe)
-constexpr int kShadowCap = 16384;
-constexpr int kMarchSlots = 512;     // LDS table slots of a cell (8 KiB per single-wave workgroup: every workgroup of a 640x480 launch is still resident at once -- with 16 KiB they are not, and the launch lasts 82 us instead of 72); at most kMarchMax are filled
-constexpr int kMarchMax = 160;       // ... so that a probe sequence -- every lane of the wave waits for the longest one -- is one or two slots long
-constexpr float kMarchZEps = 0.02f;  // rays start at kVeryClose = 0.05 m of camera depth
-struct MarchLists {
-  uint4 *vis;      // [n_local]: entry of visible-list rank r
-  uint4 *shadow;   // [kShadowCap]
-  int *cnt;        // this GetImage's counters: [0] shadow entries, [1] flags (1: shadow list overflowed), [2 + st] list lengths
-  int *cnt_next;   // the other set: zeroed by this GetImage's range pass for the next one
-  uint4 *lists;    // [n_sub][kSubTileCap]
-  int cw, ch, stx, n_sub;
-  int mode;        // diagnostics (DSLAM_MARCH_LDS): 1 = on, 2 = build the tables but probe the hash table all the same
-};
-// entry: x = pos0 | pos1 << 16 (the hash entry's first word), y = pos2 | x0 << 16 | y0 << 24, z = voxel-block slot,
-//        w = x1 | y1 << 8 | code << 16 (0: no ray can touch it, 1: box, 2: every cell)
-
-__device__ __forceinline__ bool sphere_outside(const HashEntry &e, const FrustumParams &fp) {
-  // bounding sphere of the expanded cube [8 B - 1.0625, 8 B + 8.0625] voxels (radius with 5 % to spare)
-  const float vs = fp.voxel_size;
-  Vec4 c = {((float)e.pos[0] * 8.0f + 3.5f) * vs, ((float)e.pos[1] * 8.0f + 3.5f) * vs, ((float)e.pos[2] * 8.0f + 3.5f) * vs, 1.0f};
-  c = mul(fp.M, c);
-  const float R = 0.8660254f * 9.125f * 1.05f * vs;
-  if (c.z + R < 0.0f) return true;   // (upstream's visibility rule takes corners with z >= 1e-10)
-  if (fp.nl[0] * c.x + fp.nl[1] * c.y + fp.nl[2] * c.z < -R) return true;
-  if (fp.nr[0] * c.x + fp.nr[1] * c.y + fp.nr[2] * c.z < -R) return true;
-  if (fp.nt[0] * c.x + fp.nt[1] * c.y + fp.nt[2] * c.z < -R) return true;
-  if (fp.nb[0] * c.x + fp.nb[1] * c.y + fp.nb[2] * c.z < -R) return true;
-  return false;   // (NaN compares false: kept)
-}
-
-// march box of an allocated block (cells); returns the code of the entry encoding above
-__device__ __forceinline__ int march_box(const HashEntry &e, const FrustumParams &fp, int cw, int ch, int &x0, int &y0, int &x1, int &y1) {
-  const float vs = fp.voxel_size;
-  const float lo = -1.0625f * vs, hi = 8.0625f * vs;
-  const float ox = (float)e.pos[0] * 8.0f * vs, oy = (float)e.pos[1] * 8.0f * vs, oz = (float)e.pos[2] * 8.0f * vs;
-  float umin = 3.0e6f, umax = -3.0e6f, wmin = 3.0e6f, wmax = -3.0e6f;
-  int behind = 0;
-#pragma unroll
-  for (int k = 0; k < 8; k++) {
-    Vec4 q = {ox + ((k & 1) ? hi : lo), oy + ((k & 2) ? hi : lo), oz + ((k & 4) ? hi : lo), 1.0f};
-    q = mul(fp.M, q);
-    if (!(q.z >= kMarchZEps)) { behind++; continue; }
-    const float u = fp.fx * q.x / q.z + fp.cx, w = fp.fy * q.y / q.z + fp.cy;
-    umin = fminf(umin, u); umax = fmaxf(umax, u); wmin = fminf(wmin, w); wmax = fmaxf(wmax, w);
-  }
-  if (behind == 8) return 0;   // wholly in front of where rays start
-  x0 = 0; y0 = 0; x1 = cw - 1; y1 = ch - 1;
-  if (behind) return 2;        // straddles the camera plane (the sphere test has let it through): every cell
-  if (!(umin <= umax) || !(wmin <= wmax)) return 2;   // (NaN: no claim)
-  // one pixel of slack; clamped as floats so that the conversions cannot overflow
-  const float fx0 = floorf((fmaxf(umin, -16.0f) - 1.0f) * 0.125f), fx1 = floorf((fminf(umax, 1.0e6f) + 1.0f) * 0.125f);
-  const float fy0 = floorf((fmaxf(wmin, -16.0f) - 1.0f) * 0.125f), fy1 = floorf((fminf(wmax, 1.0e6f) + 1.0f) * 0.125f);
-  if (fx1 < 0.0f || fy1 < 0.0f || fx0 > (float)(cw - 1) || fy0 > (float)(ch - 1)) return 0;
-  x0 = fx0 < 0.0f ? 0 : (int)fx0; y0 = fy0 < 0.0f ? 0 : (int)fy0;
-  x1 = fx1 > (float)(cw - 1) ? cw - 1 : (int)fx1; y1 = fy1 > (float)(ch - 1) ? ch - 1 : (int)fy1;
-  return 1;
-}
-
-// The same box for a block whose 8 corners (NOT expanded) were projected anyway (ProjectSingleBlock): their extent in CELLS
-// (u / 8) plus a margin.  A point P of the expanded cube is Q + d with Q in the cube and |d| <= D = 1.0625 sqrt(3) voxels;
-// with every corner at depth >= zmin > D + kMarchZEps:  |u(P) - u(Q)| <= f D (1 + |x / z|) / (zmin - D), and |x / z| of a
-// point of the cube is at most max |u - c| / f over its corners.  Corners nearer than that: the full computation.
-__device__ __forceinline__ int march_box_from_extent(const HashEntry &e, const FrustumParams &fp, float umin8, float umax8, float wmin8, float wmax8,
-                                                     float zmin_all, int cw, int ch, int &x0, int &y0, int &x1, int &y1) {
-  const float D = 1.0625f * 1.7320508f * fp.voxel_size;
-  if (!(zmin_all >= D + 2.0f * kMarchZEps)) return march_box(e, fp, cw, ch, x0, y0, x1, y1);
-  const float umin = umin8 * 8.0f, umax = umax8 * 8.0f, wmin = wmin8 * 8.0f, wmax = wmax8 * 8.0f;
-  const float k = D / (zmin_all - D);
-  const float mu = k * (fp.fx + fmaxf(fabsf(umin - fp.cx), fabsf(umax - fp.cx))) * 1.02f + 1.0f;
-  const float mw = k * (fp.fy + fmaxf(fabsf(wmin - fp.cy), fabsf(wmax - fp.cy))) * 1.02f + 1.0f;
-  if (!(mu < 1.0e6f) || !(mw < 1.0e6f) || !(umin <= umax) || !(wmin <= wmax)) return march_box(e, fp, cw, ch, x0, y0, x1, y1);
-  const float fx0 = floorf((fmaxf(umin, -1.0e6f) - mu) * 0.125f), fx1 = floorf((fminf(umax, 1.0e6f) + mu) * 0.125f);
-  const float fy0 = floorf((fmaxf(wmin, -1.0e6f) - mw) * 0.125f), fy1 = floorf((fminf(wmax, 1.0e6f) + mw) * 0.125f);
-  if (fx1 < 0.0f || fy1 < 0.0f || fx0 > (float)(cw - 1) || fy0 > (float)(ch - 1)) return 0;
-  x0 = fx0 < 0.0f ? 0 : (int)fx0; y0 = fy0 < 0.0f ? 0 : (int)fy0;
-  x1 = fx1 > (float)(cw - 1) ? cw - 1 : (int)fx1; y1 = fy1 > (float)(ch - 1) ? ch - 1 : (int)fy1;
-  return 1;
-}
-
-__device__ __forceinline__ uint4 march_entry(const HashEntry &e, int code, int x0, int y0, int x1, int y1) {
-  return make_uint4(((unsigned)e.pos[0] & 0xffffu) | ((unsigned)e.pos[1] << 16),
-                    ((unsigned)e.pos[2] & 0xffffu) | ((unsigned)x0 << 16) | ((unsigned)y0 << 24), (unsigned)e.ptr,
-                    (unsigned)x1 | ((unsigned)y1 << 8) | ((unsigned)code << 16));
-}
 
 // ---------------------------------------------------------------------------------------------------------
 // CountVisibleBlocks
@@ -177,16 +66,10 @@ struct ProjParams {
 
 // ProjectSingleBlock: bbox (in 1/8-resolution cells) and z-range of one block; returns the number of 16x16 render
 // tiles it needs (0 = nothing to render)
-// extent of the 8 projected corners in pixels and the smallest corner depth (the march box of a block in front of the camera
-// is this extent plus a margin, see march_box_from_extent)
-struct CornerExtent { float umin, umax, wmin, wmax, zmin_all; };
-
-template <bool EXTENT = false>
-__device__ __forceinline__ int project_single_block(const HashEntry &e, const ProjParams &p, int4 &box, float2 &zr, CornerExtent *ext = nullptr) {
+__device__ __forceinline__ int project_single_block(const HashEntry &e, const ProjParams &p, int4 &box, float2 &zr) {
   if (e.ptr < 0) return 0;
   int ulx = p.W / 8, uly = p.H / 8, lrx = -1, lry = -1;
   float zmin = kFarAway, zmax = kVeryClose;
-  if constexpr (EXTENT) { ext->umin = 3.0e6f; ext->umax = -3.0e6f; ext->wmin = 3.0e6f; ext->wmax = -3.0e6f; ext->zmin_all = 3.0e6f; }
 #pragma unroll
   for (int corner = 0; corner < 8; corner++) {
     short tx = e.pos[0], ty = e.pos[1], tz = e.pos[2];
@@ -197,14 +80,9 @@ __device__ __forceinline__ int project_single_block(const HashEntry &e, const Pr
     q.z = (float)tz * (float)kBlock * p.voxel_size;
     q.w = 1.0f;
     q = mul(p.M, q);
-    if constexpr (EXTENT) ext->zmin_all = fminf(ext->zmin_all, q.z);
     if (q.z < 1e-6f) continue;
     const float px = (p.fx * q.x / q.z + p.cx) / 8.0f;
     const float py = (p.fy * q.y / q.z + p.cy) / 8.0f;
-    if constexpr (EXTENT) {
-      ext->umin = fminf(ext->umin, px); ext->umax = fmaxf(ext->umax, px);
-      ext->wmin = fminf(ext->wmin, py); ext->wmax = fmaxf(ext->wmax, py);
-    }
     if ((float)ulx > floorf(px)) ulx = (int)floorf(px);
     if ((float)lrx < ceilf(px)) lrx = (int)ceilf(px);
     if ((float)uly > floorf(py)) uly = (int)floorf(py);
@@ -238,7 +116,6 @@ struct SelFrustum {
   int *req_out;
   float2 *range;
   int npix;
-  MarchLists ml;   // (ml.vis == nullptr: no lists)
   __device__ void prologue() const {
     if (PROJECT)   // (independent job) reset the range image to (FAR_AWAY, VERY_CLOSE)
       for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < npix; i += gridDim.x * blockDim.x) range[i] = make_float2(kFarAway, kVeryClose);
@@ -247,46 +124,24 @@ struct SelFrustum {
   __device__ HashEntry load(int t) const { return load_entry(hash, t); }
   __device__ bool test(int, const HashEntry &e) const {
     if (e.ptr < 0) return false;
-    // A block whose bounding sphere lies outside the view pyramid has no corner in the image: most allocated blocks of a long
-    // run are dismissed by one matrix product instead of eight projections.
-    if (sphere_outside(e, fp)) return false;
     bool vis, vis_enl;
     check_block_vis<false>(vis, vis_enl, e.pos[0], e.pos[1], e.pos[2], fp.M, fp.fx, fp.fy, fp.cx, fp.cy, fp.voxel_size, fp.W, fp.H);
-    if (PROJECT && !vis && ml.vis) {
-      // not visible by the 8-corner rule, yet rays may pass through it (a block over an image border): a shadow entry
-      int x0, y0, x1, y1;
-      const int code = march_box(e, fp, ml.cw, ml.ch, x0, y0, x1, y1);
-      if (code) {
-        const int k = atomicAdd(&ml.cnt[0], 1);   // (a few dozen per image)
-        if (k < kShadowCap) ml.shadow[k] = march_entry(e, code, x0, y0, x1, y1);
-        else atomicOr(&ml.cnt[1], 1);
-      }
-    }
     return vis;
   }
-  struct Staged { int4 box; float2 zr; int req; uint4 mb; };
+  struct Staged { int4 box; float2 zr; int req; };
   __device__ Staged stage(int, const HashEntry &e) const {
     Staged s;
     s.req = 0;
     if (!PROJECT) return s;
     ProjParams pp;
     pp.M = fp.M; pp.fx = fp.fx; pp.fy = fp.fy; pp.cx = fp.cx; pp.cy = fp.cy; pp.voxel_size = fp.voxel_size; pp.W = fp.W; pp.H = fp.H;
-    if (ml.vis) {
-      CornerExtent ext;
-      s.req = project_single_block<true>(e, pp, s.box, s.zr, &ext);
-      int x0, y0, x1, y1;
-      const int code = march_box_from_extent(e, fp, ext.umin, ext.umax, ext.wmin, ext.wmax, ext.zmin_all, ml.cw, ml.ch, x0, y0, x1, y1);
-      s.mb = march_entry(e, code, x0, y0, x1, y1);
-    } else {
-      s.req = project_single_block(e, pp, s.box, s.zr);
-    }
+    s.req = project_single_block(e, pp, s.box, s.zr);
     return s;
   }
   __device__ int emit(int, int r, bool listed, const Staged &s) const {
     if (!PROJECT || !listed) return 0;
     if (s.req) { boxes[r] = s.box; zr_out[r] = s.zr; }
     req_out[r] = s.req;
-    if (ml.vis) ml.vis[r] = s.mb;
     return s.req;
   }
   __device__ void finish(int) const {}
@@ -297,43 +152,7 @@ static FrustumParams make_frustum_params(const dslam_scene *s, const dslam_rende
   memcpy(fp.M.m, M, 64);
   fp.fx = intr[0]; fp.fy = intr[1]; fp.cx = intr[2]; fp.cy = intr[3]; fp.voxel_size = s->p.voxel_size;
   fp.W = r->w; fp.H = r->h;
-  // side planes through the camera centre and the image borders at pixel -1 and W (H): x >= al z, x <= ar z, y >= at z, y <= ab z
-  const float al = (-1.0f - fp.cx) / fp.fx, ar = ((float)fp.W - fp.cx) / fp.fx;
-  const float at = (-1.0f - fp.cy) / fp.fy, ab = ((float)fp.H - fp.cy) / fp.fy;
-  auto unit = [](float *n, float x, float y, float z) { const float k = 1.0f / sqrtf(x * x + y * y + z * z); n[0] = x * k; n[1] = y * k; n[2] = z * k; };
-  unit(fp.nl, 1.0f, 0.0f, -al); unit(fp.nr, -1.0f, 0.0f, ar); unit(fp.nt, 0.0f, 1.0f, -at); unit(fp.nb, 0.0f, -1.0f, ab);
   return fp;
-}
-
-// the lists of this GetImage (null pointers if the render state has none: image wider than 2040 pixels, or switched off)
-static MarchLists make_march_lists(dslam_render_state *r, bool advance) {
-  MarchLists ml;
-  memset(&ml, 0, sizeof(ml));
-  if (!r->march_vis) return ml;
-  if (advance) r->march_set ^= 1;
-  ml.cw = (r->w + 7) / 8; ml.ch = (r->h + 7) / 8;
-  ml.stx = (ml.cw + kSubTile - 1) / kSubTile;
-  ml.n_sub = ml.stx * ((ml.ch + kSubTile - 1) / kSubTile);
-  ml.vis = r->march_vis; ml.shadow = r->march_shadow; ml.lists = r->march_lists;
-  ml.cnt = r->march_cnt + (size_t)r->march_set * r->march_cnt_stride;
-  ml.cnt_next = r->march_cnt + (size_t)(r->march_set ^ 1) * r->march_cnt_stride;
-  static const int mode = getenv("DSLAM_MARCH_LDS") ? atoi(getenv("DSLAM_MARCH_LDS")) : 1;
-  ml.mode = mode;
-  return ml;
-}
-
-int march_lists_allocate(dslam_engine *e, dslam_render_state *r) {
-  static const bool off = getenv("DSLAM_MARCH_LDS") && atoi(getenv("DSLAM_MARCH_LDS")) == 0;
-  const int cw = (r->w + 7) / 8, ch = (r->h + 7) / 8;
-  if (off || cw > 255 || ch > 255) return DSLAM_OK;   // (cell coordinates are packed in bytes)
-  const int n_sub = ((cw + kSubTile - 1) / kSubTile) * ((ch + kSubTile - 1) / kSubTile);
-  r->march_cnt_stride = (2 + n_sub + 15) & ~15;
-  DSLAM_HIP(hipMalloc(&r->march_vis, (size_t)r->n_local * sizeof(uint4)));
-  DSLAM_HIP(hipMalloc(&r->march_shadow, (size_t)kShadowCap * sizeof(uint4)));
-  DSLAM_HIP(hipMalloc(&r->march_lists, (size_t)n_sub * kSubTileCap * sizeof(uint4)));
-  DSLAM_HIP(hipMalloc(&r->march_cnt, (size_t)2 * r->march_cnt_stride * sizeof(int)));
-  DSLAM_HIP(hipMemsetAsync(r->march_cnt, 0, (size_t)2 * r->march_cnt_stride * sizeof(int), e->stream));
-  return DSLAM_OK;
 }
 
 int launch_find_visible(dslam_engine *e, const dslam_scene *s, dslam_render_state *r, const float *M,
@@ -342,9 +161,7 @@ int launch_find_visible(dslam_engine *e, const dslam_scene *s, dslam_render_stat
   DSLAM_REQUIRE(r->n_entries == N, "render state was created for a different scene size");
   int rc = ensure_scratch(e, N, s->p.num_local_blocks);
   if (rc) return rc;
-  SelFrustum<false> sel{s->hash, make_frustum_params(s, r, M, intr), nullptr, nullptr, nullptr, nullptr, 0, make_march_lists(r, false)};
-  sel.ml.vis = nullptr;
-  r->march_valid = false;
+  SelFrustum<false> sel{s->hash, make_frustum_params(s, r, M, intr), nullptr, nullptr, nullptr, nullptr, 0};
   launch_bits_select(e, s->alloc_bits, N, sel, r->visible_ids, r->n_local, &r->counters->no_visible, s->counters);
   DSLAM_HIP(hipGetLastError());
   return DSLAM_OK;
@@ -396,12 +213,9 @@ __global__ __launch_bounds__(256) void k_fill_range_tiles(const RenderCounters *
                                                           const float2 *__restrict__ zr, const int *__restrict__ req,
                                                           float2 *range, int W, int tiles_x,
                                                           const int *__restrict__ wg_tiles, int n_wg_tiles, int budget,
-                                                          int capacity, MarchLists ml) {
+                                                          int capacity) {
   __shared__ int s_min[kRangeTile * kRangeTile], s_max[kRangeTile * kRangeTile];
   __shared__ int red[4];
-  // (independent job) the counters of the NEXT GetImage's lists are zeroed here: nobody touches that set during this one
-  if (ml.vis && blockIdx.x == 0 && blockIdx.y == 0)
-    for (int i = threadIdx.x; i < 2 + ml.n_sub; i += 256) ml.cnt_next[i] = 0;
   // The visible count, the per-workgroup tile totals and this lane's first list entry are all fetched before anything
   // waits: four dependent round trips become one (the entry is read speculatively -- the index is inside the
   // buffers whatever the count turns out to be).
@@ -415,11 +229,7 @@ __global__ __launch_bounds__(256) void k_fill_range_tiles(const RenderCounters *
   // the projection pass' per-workgroup counts) exceeds it does the order matter.  That case (> 262144 tiles) is
   // replayed below, by every workgroup for itself.
   const bool over_budget = block_sum_strided(wg_tiles, n_wg_tiles, 1, red) >= budget;
-  // the lists of the march tables take the visible entries and, behind them, the shadow entries of the selection
-  int ns = ml.vis ? __builtin_amdgcn_readfirstlane(ml.cnt[0]) : 0;
-  ns = ns < kShadowCap ? ns : kShadowCap;
-  const int n_list = ml.vis ? n + ns : 0;
-  if ((int)(blockIdx.y * 256) >= n && (int)(blockIdx.y * 256) >= n_list && !over_budget) return;
+  if ((int)(blockIdx.y * 256) >= n && !over_budget) return;
   const int tx0 = (blockIdx.x % tiles_x) * kRangeTile, ty0 = (blockIdx.x / tiles_x) * kRangeTile;
   const int far_i = __float_as_int(kFarAway), close_i = __float_as_int(kVeryClose);
   s_min[threadIdx.x] = far_i;
@@ -519,48 +329,6 @@ __global__ __launch_bounds__(256) void k_fill_range_tiles(const RenderCounters *
       }
     }
   }
-  if (ml.vis) {
-    if (over_budget) {   // (the tile budget drops blocks in list order: no lists, the march probes the table)
-      if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) atomicOr(&ml.cnt[1], 2);
-    } else {
-      // every entry whose march box meets this 16x16-cell tile goes to the lists of the 8x8-cell sub-tiles it meets: counted
-      // and staged in LDS, one global atomic per workgroup, round and sub-tile
-      __shared__ int s_qn[4], s_qbase[4];
-      __shared__ uint4 s_q[4][256];
-      for (int ib = blockIdx.y * 256; ib < n_list; ib += gridDim.y * 256) {   // (uniform trip count: barriers inside)
-        if (threadIdx.x < 4) s_qn[threadIdx.x] = 0;
-        __syncthreads();
-        const int i = ib + threadIdx.x;
-        if (i < n_list) {
-          const uint4 m = i < n ? ml.vis[i] : ml.shadow[i - n];
-          if ((m.w >> 16) & 3u) {
-            const int bx0 = (int)((m.y >> 16) & 0xffu), by0 = (int)(m.y >> 24), bx1 = (int)(m.w & 0xffu), by1 = (int)((m.w >> 8) & 0xffu);
-#pragma unroll
-            for (int q = 0; q < 4; q++) {
-              const int qx0 = tx0 + (q & 1) * kSubTile, qy0 = ty0 + (q >> 1) * kSubTile;
-              if (bx0 <= qx0 + kSubTile - 1 && bx1 >= qx0 && by0 <= qy0 + kSubTile - 1 && by1 >= qy0 && qx0 < ml.cw && qy0 < ml.ch)
-                s_q[q][atomicAdd(&s_qn[q], 1)] = m;
-            }
-          }
-        }
-        __syncthreads();
-        if (threadIdx.x < 4 && s_qn[threadIdx.x]) {
-          const int st = (ty0 / kSubTile + (threadIdx.x >> 1)) * ml.stx + tx0 / kSubTile + (threadIdx.x & 1);
-          s_qbase[threadIdx.x] = atomicAdd(&ml.cnt[2 + st], s_qn[threadIdx.x]);
-        }
-        __syncthreads();
-#pragma unroll
-        for (int q = 0; q < 4; q++) {
-          const int k = (int)threadIdx.x;
-          if (k < s_qn[q] && s_qbase[q] + k < kSubTileCap) {   // (a list that runs over keeps its true length: k_render sees it)
-            const int st = (ty0 / kSubTile + (q >> 1)) * ml.stx + tx0 / kSubTile + (q & 1);
-            ml.lists[(size_t)st * kSubTileCap + s_qbase[q] + k] = s_q[q][k];
-          }
-        }
-        __syncthreads();   // (the staging arrays are refilled by the next round)
-      }
-    }
-  }
   __syncthreads();
   const int mn = s_min[threadIdx.x], mx = s_max[threadIdx.x];
   if (mn != far_i || mx != close_i) {
@@ -577,13 +345,13 @@ __global__ __launch_bounds__(256) void k_fill_range_tiles(const RenderCounters *
 
 constexpr int kProjectGrid = 512;
 
-static int launch_fill_range(dslam_engine *e, dslam_render_state *r, int n_wg_tiles, const MarchLists &ml) {
+static int launch_fill_range(dslam_engine *e, dslam_render_state *r, int n_wg_tiles) {
   // corner = the tiles covering ceil(W/8) x ceil(H/8) cells (clamped to the image); chunks sized for the pool
   const int cw = (r->w + 7) / 8, ch = (r->h + 7) / 8;
   const int tiles_x = (cw + kRangeTile - 1) / kRangeTile, tiles_y = (ch + kRangeTile - 1) / kRangeTile;
   hipLaunchKernelGGL(k_fill_range_tiles, dim3(tiles_x * tiles_y, kRangeSlices), dim3(256), 0, e->stream, r->counters,
                      r->proj_boxes, r->proj_z, r->proj_req, r->range, r->w, tiles_x, r->proj_wg_tiles, n_wg_tiles,
-                     e->render_tile_budget, r->n_local, ml);
+                     e->render_tile_budget, r->n_local);
   DSLAM_HIP(hipGetLastError());
   return DSLAM_OK;
 }
@@ -601,10 +369,7 @@ int launch_expected_depths(dslam_engine *e, const dslam_scene *s, dslam_render_s
   const ProjParams pp = make_proj_params(s, r, M, intr);
   hipLaunchKernelGGL(k_project_blocks, dim3(kProjectGrid), dim3(256), 0, e->stream, r->visible_ids, r->counters, s->hash,
                      pp, r->proj_boxes, r->proj_z, r->proj_req, r->range, r->w * r->h, r->proj_wg_tiles);
-  MarchLists none;
-  memset(&none, 0, sizeof(none));
-  r->march_valid = false;   // (the tracking path lists visible blocks only: its march probes the table)
-  return launch_fill_range(e, r, kProjectGrid, none);
+  return launch_fill_range(e, r, kProjectGrid);
 }
 
 // FindVisibleBlocks + CreateExpectedDepths for the same pose (ITMMainEngine::GetImage's FREECAMERA path): three launches
@@ -615,11 +380,9 @@ int launch_find_visible_and_depths(dslam_engine *e, const dslam_scene *s, dslam_
   DSLAM_REQUIRE(r->n_entries == N, "render state was created for a different scene size");
   int rc = ensure_scratch(e, N, s->p.num_local_blocks);
   if (rc) return rc;
-  const MarchLists ml = make_march_lists(r, true);
-  SelFrustum<true> sel{s->hash, make_frustum_params(s, r, M, intr), r->proj_boxes, r->proj_z, r->proj_req, r->range, r->w * r->h, ml};
+  SelFrustum<true> sel{s->hash, make_frustum_params(s, r, M, intr), r->proj_boxes, r->proj_z, r->proj_req, r->range, r->w * r->h};
   launch_bits_select(e, s->alloc_bits, N, sel, r->visible_ids, r->n_local, &r->counters->no_visible, s->counters, r->proj_wg_tiles);
-  r->march_valid = ml.vis != nullptr;
-  return launch_fill_range(e, r, select_tiles(N), ml);
+  return launch_fill_range(e, r, select_tiles(N));
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -742,83 +505,6 @@ __device__ __forceinline__ void resolve_cell_blocks(const VolumeRef &vol, const 
   }
 }
 
-// ---- the same two lookups in a cell's LDS table (k_render builds it; "Per-cell block tables" at the top of this file) ------
-// slot: x = pos0 | pos1 << 16, y = pos2, z = voxel index of the block's first voxel, w = 1 if occupied; linear probing, never
-// more than half full, so a probe sequence always ends at an empty slot
-// slot of a block position: the table's multipliers, folded so that the low bits depend on all of the product's bits (with
-// the plain low bits neighbouring blocks fall into runs of slots, and linear probing turns runs into long walks)
-__device__ __forceinline__ unsigned march_slot(int bx, int by, int bz) {
-  unsigned h = ((unsigned)bx * 73856093u) ^ ((unsigned)by * 19349669u) ^ ((unsigned)bz * 83492791u);
-  h ^= h >> 15;
-  h *= 0x2c1b3c6du;
-  h ^= h >> 12;
-  return h & (unsigned)(kMarchSlots - 1);
-}
-
-__device__ __forceinline__ int lookup_block_lds(const uint4 *tab, int bx, int by, int bz, IndexCache &c) {
-  if (bx == c.bx && by == c.by && bz == c.bz) return c.block_ptr;
-  // (a block coordinate outside the short range can never be stored, so it never matches)
-  if (bx != (short)bx || by != (short)by || bz != (short)bz) return -1;
-  const unsigned kx = ((unsigned)bx & 0xffffu) | ((unsigned)by << 16), kz = (unsigned)bz & 0xffffu;
-  unsigned h = march_slot(bx, by, bz);
-  while (true) {
-    const uint4 e = tab[h];
-    if (e.w == 0u) return -1;
-    if (e.x == kx && e.y == kz) {
-      c.bx = bx; c.by = by; c.bz = bz;
-      c.block_ptr = (int)e.z;
-      return c.block_ptr;
-    }
-    h = (h + 1u) & (unsigned)(kMarchSlots - 1);
-  }
-}
-
-// resolve_cell_blocks on the table: the eight first probes issued together, collisions followed together
-__device__ __forceinline__ void resolve_cell_blocks_lds(const uint4 *tab, const int bxa[2], const int bya[2], const int bza[2], int base[8]) {
-  const unsigned hx[2] = {(unsigned)bxa[0] * 73856093u, (unsigned)bxa[1] * 73856093u};
-  const unsigned hy[2] = {(unsigned)bya[0] * 19349669u, (unsigned)bya[1] * 19349669u};
-  const unsigned hz[2] = {(unsigned)bza[0] * 83492791u, (unsigned)bza[1] * 83492791u};
-  const unsigned tx[2] = {(unsigned)bxa[0] & 0xffffu, (unsigned)bxa[1] & 0xffffu};
-  const unsigned ty[2] = {(unsigned)bya[0] << 16, (unsigned)bya[1] << 16};
-  const unsigned tz[2] = {(unsigned)bza[0] & 0xffffu, (unsigned)bza[1] & 0xffffu};
-  const bool okx[2] = {bxa[0] == (short)bxa[0], bxa[1] == (short)bxa[1]};
-  const bool oky[2] = {bya[0] == (short)bya[0], bya[1] == (short)bya[1]};
-  const bool okz[2] = {bza[0] == (short)bza[0], bza[1] == (short)bza[1]};
-  unsigned h[8];
-  uint4 e[8];
-#pragma unroll
-  for (int k = 0; k < 8; k++) {
-    unsigned v = hx[k & 1] ^ hy[(k >> 1) & 1] ^ hz[k >> 2];   // (= march_slot)
-    v ^= v >> 15; v *= 0x2c1b3c6du; v ^= v >> 12;
-    h[k] = v & (unsigned)(kMarchSlots - 1);
-    e[k] = tab[h[k]];
-  }
-  unsigned pending = 0;
-#pragma unroll
-  for (int k = 0; k < 8; k++) {
-    const bool ok = okx[k & 1] && oky[(k >> 1) & 1] && okz[k >> 2];
-    const bool match = ok && e[k].w != 0u && e[k].x == (tx[k & 1] | ty[(k >> 1) & 1]) && e[k].y == tz[k >> 2];
-    base[k] = match ? (int)e[k].z : -1;
-    if (ok && !match && e[k].w != 0u) pending |= 1u << k;
-  }
-  while (pending) {
-#pragma unroll
-    for (int k = 0; k < 8; k++) {
-      h[k] = (pending & (1u << k)) ? ((h[k] + 1u) & (unsigned)(kMarchSlots - 1)) : h[k];
-      e[k] = tab[h[k]];
-    }
-    unsigned still = 0;
-#pragma unroll
-    for (int k = 0; k < 8; k++) {
-      const bool pk = (pending & (1u << k)) != 0;
-      const bool match = e[k].w != 0u && e[k].x == (tx[k & 1] | ty[(k >> 1) & 1]) && e[k].y == tz[k >> 2];
-      base[k] = (pk && match) ? (int)e[k].z : base[k];
-      still |= (pk && !match && e[k].w != 0u) ? (1u << k) : 0u;
-    }
-    pending = still;
-  }
-}
-
 // The 8 taps of a trilinear read.  Tap k = (dx, dy, dz) = (k & 1, (k >> 1) & 1, k >> 2) relative to (x, y, z).  The
 // kernel is bound by the NUMBER of scattered load instructions (measured: prefetching or speculative variants that
 // add loads are slower), so the <= 8 (usually 1 or 2) distinct voxel blocks are resolved with as few probes as
@@ -870,12 +556,10 @@ __device__ __forceinline__ float trilinear_sdf(const uint2 t[8], float cx, float
 
 // The 8 taps (low voxel words) of the trilinear cell at (x0, y0, z0) in two load round trips: every block of the
 // cell resolved together, then the 8 taps together; a tap whose block is not allocated reads the empty voxel.
-// (tab: the cell's LDS table, or null: the blocks are looked up in the hash table)
-__device__ __forceinline__ void gather_taps_batched(const VolumeRef &vol, int x0, int y0, int z0, unsigned raw[8], const uint4 *tab = nullptr) {
+__device__ __forceinline__ void gather_taps_batched(const VolumeRef &vol, int x0, int y0, int z0, unsigned raw[8]) {
   const int bxa[2] = {x0 >> 3, (x0 + 1) >> 3}, bya[2] = {y0 >> 3, (y0 + 1) >> 3}, bza[2] = {z0 >> 3, (z0 + 1) >> 3};
   int base[8];
-  if (tab) resolve_cell_blocks_lds(tab, bxa, bya, bza, base);
-  else resolve_cell_blocks(vol, bxa, bya, bza, base);
+  resolve_cell_blocks(vol, bxa, bya, bza, base);
   const unsigned lx[2] = {(unsigned)x0 & 7u, (unsigned)(x0 + 1) & 7u};
   const unsigned ly[2] = {((unsigned)y0 & 7u) << 3, ((unsigned)(y0 + 1) & 7u) << 3};
   const unsigned lz[2] = {((unsigned)z0 & 7u) << 6, ((unsigned)(z0 + 1) & 7u) << 6};
@@ -898,10 +582,10 @@ __device__ __forceinline__ float trilinear_raw(const unsigned raw[8], float cx, 
 }
 
 // readFromSDF_float_interpolated; same values as read_sdf_interp, two round trips instead of up to nine
-__device__ __forceinline__ float read_sdf_interp_batched(const VolumeRef &vol, const Vec3 &pt, const uint4 *tab = nullptr) {
+__device__ __forceinline__ float read_sdf_interp_batched(const VolumeRef &vol, const Vec3 &pt) {
   const float fx = floorf(pt.x), fy = floorf(pt.y), fz = floorf(pt.z);
   unsigned raw[8];
-  gather_taps_batched(vol, (int)fx, (int)fy, (int)fz, raw, tab);
+  gather_taps_batched(vol, (int)fx, (int)fy, (int)fz, raw);
   return trilinear_raw(raw, pt.x - fx, pt.y - fy, pt.z - fz);
 }
 
@@ -1003,7 +687,6 @@ struct RenderParams {
   unsigned long long *dbg_waves;  // diagnostics only (env DSLAM_DBG_WAVETIME=<file>): per wave {cycles, max iterations, straddling iterations, their cycles, setup cycles, refinement cycles}
   int dbg_flags;  // diagnostics only (env DSLAM_DBG_FLAGS: 8 = 16x16 workgroups)
   float split_len;  // > 0: tiles with a longer depth range (voxels) are marched by two wavefronts; the grid is (W/8, 2 H/8)
-  MarchLists ml;    // per-cell block tables (ml.vis == nullptr: off -- the march probes the hash table)
 };
 
 constexpr float kSplitLen = 175.0f;  // voxels of depth range above which a tile is marched by two wavefronts (150-200 measure the same)
@@ -1014,7 +697,7 @@ struct MarchDiag { int iters, wave_iters, slow_iters; unsigned long long slow_cy
 
 template <bool DIAG>
 __device__ __forceinline__ bool cast_ray(Vec4 &out, int x, int y, const RenderParams &p, const float2 minmax,
-                                         MarchDiag &diag, const uint4 *tab) {
+                                         MarchDiag &diag) {
   const unsigned long long t_enter = DIAG ? __builtin_amdgcn_s_memtime() : 0ull;
   Vec4 pc;
   Vec3 ps, pe, dir, res;
@@ -1075,7 +758,7 @@ __device__ __forceinline__ bool cast_ray(Vec4 &out, int x, int y, const RenderPa
     // step (bitmap, prefetch, speculation, resolving the whole cell every step) all measured slower.
     const int vx = iround(res.x), vy = iround(res.y), vz = iround(res.z);
     const int bx = vx >> 3, by = vy >> 3, bz = vz >> 3;
-    const int base = tab ? lookup_block_lds(tab, bx, by, bz, cache) : lookup_block(p.vol, bx, by, bz, cache);
+    const int base = lookup_block(p.vol, bx, by, bz, cache);
     if (base < 0) {
       sdf = 1.0f;  // empty voxel: 32767 / 32767
       step = (float)kBlock;
@@ -1107,7 +790,7 @@ __device__ __forceinline__ bool cast_ray(Vec4 &out, int x, int y, const RenderPa
                             (z0 >> 3) == bz && ((z0 + 1) >> 3) == bz;
         if (!all_in) {  // the cell straddles blocks: fetch it properly
           if (DIAG) s_slow_flag = 1;
-          gather_taps_batched(p.vol, x0, y0, z0, raw, tab);
+          gather_taps_batched(p.vol, x0, y0, z0, raw);
         }
         sdf = trilinear_raw(raw, res.x - f0x, res.y - f0y, res.z - f0z);
       }
@@ -1123,7 +806,7 @@ __device__ __forceinline__ bool cast_ray(Vec4 &out, int x, int y, const RenderPa
   if (sdf <= 0.0f) {
     step = sdf * step_scale;
     res.x += step * dir.x; res.y += step * dir.y; res.z += step * dir.z;
-    sdf = read_sdf_interp_batched(p.vol, res, tab);
+    sdf = read_sdf_interp_batched(p.vol, res);
     step = sdf * step_scale;
     res.x += step * dir.x; res.y += step * dir.y; res.z += step * dir.z;
     pt_found = true;
@@ -1140,7 +823,7 @@ __device__ __forceinline__ bool cast_ray(Vec4 &out, int x, int y, const RenderPa
 // hides its load round trips).  SHADE = true adds the normal / colour modes.
 // REUSE = true: raycastResult already holds this very view's march (GetImage memo) -- shade only.
 template <int WAVES, bool SHADE, bool DIAG = false, bool REUSE = false>
-__global__ __launch_bounds__(WAVES * 64, 4) void k_render(RenderParams p) {
+__global__ __launch_bounds__(WAVES * 64, 5) void k_render(RenderParams p) {
   // one wavefront = one workgroup = an 8x8 pixel tile = exactly one cell of the 1/8-resolution range image.
   // Single-wave workgroups let the dispatcher backfill a SIMD the moment a short tile finishes (ray lengths vary
   // by 10x between tiles), instead of holding 4 waves until the slowest of a 16x16 tile is done.
@@ -1149,8 +832,6 @@ __global__ __launch_bounds__(WAVES * 64, 4) void k_render(RenderParams p) {
   // rays of one image region then pile up on one XCD; the march is bound by its longest dependent-load chain)
   const int x = (WAVES == 4) ? blockIdx.x * 16 + (wave & 1) * 8 + (lane & 7) : blockIdx.x * 8 + (lane & 7);
   int y = (WAVES == 4) ? blockIdx.y * 16 + (wave >> 1) * 8 + (lane >> 3) : blockIdx.y * 8 + (lane >> 3);
-  [[maybe_unused]] bool lanes_off = false;   // (split tile: the other half's lanes -- they still help to build the table)
-  int cell_y = blockIdx.y;
   if (WAVES == 1 && p.split_len > 0.0f) {
     // The launch ends when its longest wavefront ends, and a step of a wavefront costs the union of what its rays do
     // (measured: the first 32 steps of the longest tile, all 64 rays alive, take twice as long as its last 36).  So a
@@ -1161,45 +842,9 @@ __global__ __launch_bounds__(WAVES * 64, 4) void k_render(RenderParams p) {
     const int ty = blockIdx.y >> 1, sub = blockIdx.y & 1;
     const float2 mm = p.range[(int)blockIdx.x + ty * p.W];
     const bool split = (mm.y - mm.x) * p.one_over_vs > p.split_len;
-    if (!split && sub != 0) return;
-    lanes_off = split && lane >= 32;
+    if (split ? (lane >= 32) : (sub != 0)) return;
     y = ty * 8 + (split ? sub * 4 : 0) + (lane >> 3);
-    cell_y = ty;
   }
-  // ---- this cell's block table ("Per-cell block tables" at the top of this file) ------------------------------------------
-  __shared__ uint4 s_tab[(WAVES == 1 && !REUSE) ? kMarchSlots : 1];
-  const uint4 *tab = nullptr;
-  if constexpr (WAVES == 1 && !REUSE) {
-    if (p.ml.vis) {   // (uniform)
-      const int st = (cell_y / kSubTile) * p.ml.stx + (int)blockIdx.x / kSubTile;
-      const int n_l = __builtin_amdgcn_readfirstlane(p.ml.cnt[2 + st]);
-      const int flags = __builtin_amdgcn_readfirstlane(p.ml.cnt[1]);
-      if (flags == 0 && n_l <= kSubTileCap) {
-#pragma unroll
-        for (int i = 0; i < kMarchSlots / 64; i++) s_tab[lane + i * 64] = make_uint4(0u, 0u, 0u, 0u);
-        __builtin_amdgcn_wave_barrier();
-        const uint4 *list = p.ml.lists + (size_t)st * kSubTileCap;
-        int held = 0;
-        const unsigned cxu = blockIdx.x, cyu = (unsigned)cell_y;
-        for (int j0 = 0; j0 < n_l && held <= kMarchMax; j0 += 64) {   // (uniform)
-          const int j = j0 + lane;
-          uint4 m = make_uint4(0u, 0u, 0u, 0u);
-          if (j < n_l) m = list[j];
-          const bool in = j < n_l && ((m.y >> 16) & 0xffu) <= cxu && (m.w & 0xffu) >= cxu && (m.y >> 24) <= cyu && ((m.w >> 8) & 0xffu) >= cyu;
-          held += __popcll(__ballot(in));
-          if (in && held <= kMarchMax) {
-            const int bx = (int)(short)(m.x & 0xffffu), by = (int)(short)(m.x >> 16), bz = (int)(short)(m.y & 0xffffu);
-            unsigned h = march_slot(bx, by, bz);
-            while (atomicCAS(&s_tab[h].w, 0u, 1u) != 0u) h = (h + 1u) & (unsigned)(kMarchSlots - 1);
-            s_tab[h].x = m.x; s_tab[h].y = m.y & 0xffffu; s_tab[h].z = m.z * (unsigned)kBlock3;
-          }
-        }
-        __builtin_amdgcn_wave_barrier();
-        if (held <= kMarchMax && p.ml.mode != 2) tab = s_tab;   // (a fuller cell: the global probe)
-      }
-    }
-  }
-  if (lanes_off) return;
   if (x >= p.W || y >= p.H) return;
   const int loc = x + y * p.W;
   const int loc2 = (int)floorf((float)x / 8.0f) + (int)floorf((float)y / 8.0f) * p.W;
@@ -1210,7 +855,7 @@ __global__ __launch_bounds__(WAVES * 64, 4) void k_render(RenderParams p) {
     const float4 q = p.raycast[loc];
     pr.x = q.x; pr.y = q.y; pr.z = q.z; pr.w = q.w;
   } else {
-    cast_ray<DIAG>(pr, x, y, p, p.range[loc2], diag, tab);
+    cast_ray<DIAG>(pr, x, y, p, p.range[loc2], diag);
   }
   if (DIAG) {  // diagnostic instantiation (DSLAM_DBG_WAVETIME): per-wave cycles and march length
     const unsigned long long dt = __builtin_amdgcn_s_memtime() - t_start;
@@ -1272,7 +917,7 @@ __global__ __launch_bounds__(WAVES * 64, 4) void k_render(RenderParams p) {
 }
 
 static int fill_render_params(RenderParams &rp, const dslam_scene *s, dslam_render_state *r, const float *M,
-                              const float *intr, int type, bool march_lists) {
+                              const float *intr, int type) {
   rp.vol.hash = s->hash; rp.vol.voxels = s->voxels; rp.vol.mask = (unsigned)(s->p.num_buckets - 1);
   rp.vol.num_buckets = s->p.num_buckets;
   memcpy(rp.M.m, M, 64);
@@ -1285,9 +930,6 @@ static int fill_render_params(RenderParams &rp, const dslam_scene *s, dslam_rend
   rp.type = type;
   static const int dbg_flags = getenv("DSLAM_DBG_FLAGS") ? atoi(getenv("DSLAM_DBG_FLAGS")) : 0;
   rp.dbg_flags = dbg_flags; rp.dbg_waves = nullptr; rp.split_len = 0.0f;
-  memset(&rp.ml, 0, sizeof(rp.ml));
-  // (the lists launch_find_visible_and_depths has just left for this very view and map: GetImage's march only)
-  if (march_lists && r->march_valid) rp.ml = make_march_lists(r, false);
   return DSLAM_OK;
 }
 
@@ -1299,9 +941,9 @@ static dim3 march_grid(RenderParams &rp, const dslam_render_state *r, bool split
 }
 
 int launch_render(dslam_engine *e, const dslam_scene *s, dslam_render_state *r, const float *M, const float *intr,
-                  int type, bool reuse_raycast, void *image_out_override, bool march_lists) {
+                  int type, bool reuse_raycast, void *image_out_override) {
   RenderParams rp;
-  int rc = fill_render_params(rp, s, r, M, intr, type, march_lists && !reuse_raycast);
+  int rc = fill_render_params(rp, s, r, M, intr, type);
   if (rc) return rc;
   if (image_out_override) {  // a page-locked caller image: the kernel stores the pixels there itself (over PCIe)
     if (type == DSLAM_IMAGE_DEPTH) rp.out_float = static_cast<float *>(image_out_override);
@@ -1400,7 +1042,7 @@ int launch_icp_maps(dslam_engine *e, const dslam_scene *s, dslam_render_state *r
     DSLAM_HIP(hipMalloc(&r->raycast_image, (size_t)r->w * r->h * sizeof(uchar4)));
   }
   RenderParams rp;
-  int rc = fill_render_params(rp, s, r, M, intr, -1, false);
+  int rc = fill_render_params(rp, s, r, M, intr, -1);
   if (rc) return rc;
   const dim3 grid((r->w + 15) / 16, (r->h + 15) / 16);
   hipLaunchKernelGGL((k_render<1, false>), march_grid(rp, r, true), dim3(64), 0, e->stream, rp);
