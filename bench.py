@@ -479,6 +479,23 @@ def main():
                 extra[key] = repr(ex)
         eng.set_async(False)
 
+    # ---- the same step through the drop-in: the C++ ITMLib mirror driven by the native driver harness (rank 0, N = 1 only)
+    mirror_out = None
+    if rank == 0 and world == 1 and not args.no_extra_rates:
+        try:
+            from dslam_amd.harness import mirror_bench
+            eng.synchronize()
+            m = mirror_bench.measure(keyframes=80, time_from=30, repeats=1, width=wl.W, height=wl.H, loops=["plain_raycast"], modes=("deferred",))
+            row = m["plain_raycast"]["deferred"]
+            mirror_out = {"fps": 1e6 / row["us_per_keyframe"], "us_per_keyframe": row["us_per_keyframe"],
+                          "us_per_keyframe_without_image_fill": row["us_per_keyframe_without_image_fill"],
+                          "host_us_in_calls": row["host_us_in_calls"],
+                          "what": "UpdateView + IntegrateLocalMap + GetImage(FREECAMERA_DEPTH, read back) per keyframe through the C++ ITMLib mirror "
+                                  "(itmlib/tests/driver_harness: the reference driver's calls, frames copied into the driver's own images, "
+                                  "every call returning as the reference expects), 50 S-street keyframes"}
+        except Exception as ex:
+            mirror_out = {"error": repr(ex)}
+
     # ---- S-stress: the integrate kernel with every block of a 1 GiB pool visible (rank 0, N = 1 only)
     stress_out = None
     if rank == 0 and world == 1 and not args.no_stress:
@@ -544,6 +561,9 @@ def main():
                          "algorithmic_bytes_per_launch": alg_bytes / max(1, launches)},
         }
         out["config"].update(extra)
+        if mirror_out is not None:
+            out["config"]["dropin_mirror_fps"] = mirror_out.get("fps")
+            out["config"]["dropin_mirror"] = mirror_out
         if stress_out is not None:
             out["roofline"]["stress"] = stress_out
             if "error" not in stress_out:

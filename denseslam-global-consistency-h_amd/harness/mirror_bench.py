@@ -5,6 +5,7 @@ reference issues it, the raycast image read through GetData as ItmDepthToCv does
 
 Loops (120 S-street keyframes at 640x480, timed over the last 50, i.e. with the window full; SURVEY 8d's parameters):
     plain            UpdateView + IntegrateLocalMap
+    plain_raycast    ... + one free-camera depth raycast read back per keyframe: bench.py's step through the mirror
     decay            ... + Decay(3, 30, forceAll)                                   (DenseSlam.cpp:227-232)
     decay_window     ... + SlideWindow(50)                                          (DenseSlam.cpp:215-225)
     *_raycast        ... + one free-camera depth raycast read back per keyframe     (SaveRaycastDepth, DenseSlam.cpp:573-603)
@@ -66,7 +67,7 @@ def run_loop(frames, out, decay, window, raycast, swapping, sync, time_from):
             "blocks_in_use_end": int(m.group(8)) // 4096}
 
 
-def measure(keyframes=120, time_from=70, repeats=2, width=640, height=480, loops=None):
+def measure(keyframes=120, time_from=70, repeats=2, width=640, height=480, loops=None, modes=("deferred", "synchronous")):
     pkg = ge.load_package()
     from dslam_amd.harness import synth
     wl = synth.s_street(width, height)
@@ -77,6 +78,7 @@ def measure(keyframes=120, time_from=70, repeats=2, width=640, height=480, loops
                      "synchronous": "DSLAM_MIRROR_SYNC=1: every call waits (the round-3 mirror without the per-call counter read-back)"}}
     table = {
         "plain": dict(decay=0, window=-1, raycast=0, swapping=0),
+        "plain_raycast": dict(decay=0, window=-1, raycast=1, swapping=0),   # the bench's step: UpdateView + IntegrateLocalMap + GetImage
         "decay": dict(decay=1, window=-1, raycast=0, swapping=0),
         "decay_raycast": dict(decay=1, window=-1, raycast=1, swapping=0),
         "decay_window": dict(decay=1, window=50, raycast=0, swapping=0),
@@ -92,6 +94,8 @@ def measure(keyframes=120, time_from=70, repeats=2, width=640, height=480, loops
                 continue
             row = {}
             for mode, sync in (("deferred", 0), ("synchronous", 1)):
+                if mode not in modes:
+                    continue
                 runs = [run_loop(frames, fout, sync=sync, time_from=time_from, **kw) for _ in range(repeats)]
                 row[mode] = min(runs, key=lambda r: r["us_per_keyframe"])
             out[name] = row

@@ -4,6 +4,9 @@ export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 cd $R
 mkdir -p gpurun_out
+# two parts (a gpurun call lasts 20 minutes at most):  bash profiles/collect_profiles.sh 1   then   bash profiles/collect_profiles.sh 2
+PART=${1:-all}
+if [ "$PART" = 1 ] || [ "$PART" = all ]; then
 python bench.py > gpurun_out/final_bench.json 2> gpurun_out/final_bench.err; echo bench rc=$?
 BENCH_FAST="--steps 100 --warmup 10 --no-cpu-baseline --no-stress --no-extra-rates --reint 0"
 cd /tmp
@@ -23,6 +26,8 @@ python denseslam-global-consistency-h_amd/harness/stress.py 64 > gpurun_out/fina
 python profiles/experiments/pipeline_breakdown.py 100 > gpurun_out/final_pipeline.json 2>/dev/null; cat gpurun_out/final_pipeline.json
 python denseslam-global-consistency-h_amd/harness/side_bench.py 50 > gpurun_out/final_side_bench.json 2>gpurun_out/final_side_bench.err; tail -c 300 gpurun_out/final_side_bench.json
 python denseslam-global-consistency-h_amd/harness/quality.py 40 > gpurun_out/final_quality.json 2>gpurun_out/final_quality.err; tail -c 300 gpurun_out/final_quality.json
+fi
+if [ "$PART" = 2 ] || [ "$PART" = all ]; then
 python denseslam-global-consistency-h_amd/harness/maint_bench.py > gpurun_out/final_maintenance.json 2>gpurun_out/final_maintenance.err; tail -c 400 gpurun_out/final_maintenance.json
 # the same script under the kernel trace: per-kernel split of the maintenance path (S-stress calls + keyframe loops, BASELINE configs[2])
 (cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/final_maint_stats -- python3 $R/denseslam-global-consistency-h_amd/harness/maint_bench.py > /dev/null 2> $R/gpurun_out/final_maint_stats.err); echo maint_stats rc=$?
@@ -31,5 +36,12 @@ python denseslam-global-consistency-h_amd/harness/maint_bench.py > gpurun_out/fi
 # instruction / wave-time counters of the block-major batch launch (one pass of SQ counters; TCC counters are NOT mixed into it:
 # a pass with FETCH_SIZE + WRITE_SIZE + SQ_INSTS_VMEM_* went silent for 7 minutes on this pool)
 (cd /tmp && rocprofv3 --pmc SQ_INSTS_VALU SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_SALU --kernel-trace --output-format csv -d $R/gpurun_out/final_reint_sq -- python3 $R/bench.py --steps 100 --warmup 10 --no-cpu-baseline --no-stress --no-extra-rates --mode device > $R/gpurun_out/final_reint_sq.log 2>&1); echo reint_sq rc=$?
+# HBM traffic of the block-major batch launch: FETCH_SIZE and WRITE_SIZE in two SEPARATE single-counter passes (round 4; the mixed TCC + SQ
+# set of round 3 went silent)
+(cd /tmp && rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $R/gpurun_out/final_reint_fetch -- python3 $R/bench.py --steps 100 --warmup 10 --no-cpu-baseline --no-stress --no-extra-rates --mode device > $R/gpurun_out/final_reint_fetch.log 2>&1); echo reint_fetch rc=$?
+(cd /tmp && rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $R/gpurun_out/final_reint_write -- python3 $R/bench.py --steps 100 --warmup 10 --no-cpu-baseline --no-stress --no-extra-rates --mode device > $R/gpurun_out/final_reint_write.log 2>&1); echo reint_write rc=$?
+# the drop-in: keyframe loops through the C++ ITMLib mirror (deferred completion vs every call waiting)
+python denseslam-global-consistency-h_amd/harness/mirror_bench.py > gpurun_out/final_mirror.json 2> gpurun_out/final_mirror.err; tail -c 300 gpurun_out/final_mirror.json
 python denseslam-global-consistency-h_amd/harness/memory_sensitivity.py 1500 > gpurun_out/final_memory_sensitivity.json 2> gpurun_out/final_memory_sensitivity.err; echo sensitivity rc=$?
 python denseslam-global-consistency-h_amd/harness/shard_emulation.py 120 32 > gpurun_out/final_shard_emulation.json 2>/dev/null; tail -c 300 gpurun_out/final_shard_emulation.json
+fi

@@ -67,7 +67,8 @@ def main():
         shutil.copy(dev, os.path.join(HERE, f"{tag}_bench_device_steps100_kernel_stats.csv"))
     for src, dst in (("final_stress.json", "stress_integrate"), ("final_pipeline.json", "pipeline_breakdown"),
                      ("final_side_bench.json", "side_bench"), ("final_maintenance.json", "maintenance"),
-                     ("final_quality.json", "quality"), ("final_shard_emulation.json", "shard_emulation")):
+                     ("final_quality.json", "quality"), ("final_shard_emulation.json", "shard_emulation"),
+                     ("final_mirror.json", "mirror_bench"), ("push_variants.json", "push_variants")):
         copy_json(src, f"{tag}_{dst}.json")
 
     # HBM traffic of k_integrate from the two PMC passes (MI355X_MICROARCH.md, "HBM / rocprofv3"): counters are in KiB;
@@ -211,6 +212,40 @@ def main():
                                  "frac_of_wave_time_with_a_valu_instruction_active": round(m["SQ_ACTIVE_INST_VALU"] / wc, 3),
                                  "frac_issuing": round(m["SQ_ACTIVE_INST_ANY"] / wc, 3), "frac_stalled_at_issue": round(m["SQ_WAIT_INST_ANY"] / wc, 3),
                                  "frac_parked_on_waitcnt_or_barrier": round(m["SQ_WAIT_ANY"] / wc, 3)}
+        # HBM-side traffic of the same launches (two separate single-counter passes) and the batch's own counts
+        rf = newest("final_reint_fetch/*/*counter_collection.csv", required=False)
+        rw = newest("final_reint_write/*/*counter_collection.csv", required=False)
+        ri = (bench.get("reintegration") or {}).get("block_major", {})
+        if rf and rw:
+            def per_kernel(path, name):
+                acc, disp = collections.defaultdict(float), collections.defaultdict(set)
+                for r in csv.DictReader(open(path)):
+                    k = r["Kernel_Name"].split("(")[0]
+                    if r["Counter_Name"] == name and ("k_reintegrate_blocks" in k or "k_batch_" in k):
+                        acc[k] += float(r["Counter_Value"]); disp[k].add(r["Dispatch_Id"])
+                return {k: v / len(disp[k]) for k, v in acc.items()}
+            fe, wr = per_kernel(rf, "FETCH_SIZE"), per_kernel(rw, "WRITE_SIZE")
+            for k in out["kernels"]:
+                if k in fe and k in wr:
+                    out["kernels"][k].update({"FETCH_SIZE_KiB": fe[k], "WRITE_SIZE_KiB": wr[k]})
+            out["traffic_command"] = "the same bench command under rocprofv3 --pmc FETCH_SIZE and, separately, --pmc WRITE_SIZE (one counter per pass)"
+            blk = [k for k in out["kernels"] if "k_reintegrate_blocks" in k]
+            if blk and ri.get("blocks_touched"):
+                kb = out["kernels"][blk[0]]
+                nb, nops = ri["blocks_touched"], ri["block_operations"]
+                alg = nb * 8192.0
+                # FETCH_SIZE halves wide (16 B per lane) reads on gfx950 (MI355X_MICROARCH.md): the block loads are wide, the image
+                # gathers are dwords -- both bounds are given
+                lo = (kb["FETCH_SIZE_KiB"] + kb["WRITE_SIZE_KiB"]) * 1024.0
+                hi = (2.0 * kb["FETCH_SIZE_KiB"] + kb["WRITE_SIZE_KiB"]) * 1024.0
+                kb.update({"blocks_touched": nb, "block_operations": nops, "valu_instructions_per_block_operation": kb["valu_instructions"] / nops,
+                           "algorithmic_bytes_blocks_once": alg, "algorithmic_bytes_of_the_per_keyframe_loop": nops * 8212.0,
+                           "traffic_bytes_lower_bound": lo, "traffic_bytes_if_every_read_were_wide": hi,
+                           "write_bytes_per_touched_block": kb["WRITE_SIZE_KiB"] * 1024.0 / nb, "fetch_bytes_per_touched_block_lower_bound": kb["FETCH_SIZE_KiB"] * 1024.0 / nb,
+                           "note": "writes = the changed 16-byte chunks of every touched block, once (<= 4 KiB per block); fetches = the 4 KiB of every block "
+                                   "once PLUS the depth / colour gathers of every operation: 32 keyframes' images (78 MB) are in flight at once "
+                                   "and miss the 4 MiB L2s, where a per-keyframe launch gathers from ONE 2.4 MB image pair -- the L2-miss traffic of "
+                                   "the gathers (served by the Infinity Cache) is what FETCH_SIZE shows above the blocks' own 4 KiB"})
         json.dump(out, open(os.path.join(HERE, f"{tag}_reintegration_pmc.json"), "w"), indent=1)
     ms_src = os.path.join(OUT, "final_memory_sensitivity.json")
     if os.path.exists(ms_src) and os.path.getsize(ms_src) > 2:
