@@ -94,22 +94,30 @@ def reintegrate(api, scene, view, rs, batch, rank=0, world=1, chunk_blocks=64, a
 
 
 def make_torch_all_gather(api, scene, dist, engine_sync):
-    """pack -> all_gather_into_tensor -> unpack on torch CUDA tensors (HIP engine; backend nccl = RCCL).  The engine's
-    kernels run on its own stream, torch's collective on torch's: each side is drained before the other reads."""
+    """pack -> all_gather_into_tensor -> unpack on torch CUDA tensors (HIP engine; backend nccl = RCCL), ordered by the
+    ENGINE'S stream alone: torch is told to treat that stream as its current one for the collective (ExternalStream), so the
+    collective waits for the pack kernel and the unpack kernel for the collective through stream order -- as the native
+    program does (itmlib/tests/reintegrate_rccl.cpp: ncclAllGather on dslam_engine_stream).  Up to round 3 the two sides
+    were drained on the host three times per exchange.  One wait at the end (the caller reads timers / the map next)."""
     import torch
 
+    ext = None
+
     def run(counts):
+        nonlocal ext
         world, rank = dist.get_world_size(), dist.get_rank()
         cap = max(1, max(counts))
         dev = torch.device("cuda", torch.cuda.current_device())
-        send = torch.empty((cap, BLOCK_BYTES), dtype=torch.uint8, device=dev)
-        recv = torch.empty((world, cap, BLOCK_BYTES), dtype=torch.uint8, device=dev)
-        api.shard_dirty_pack(scene, rank, send.data_ptr(), cap)
+        if ext is None:
+            ext = torch.cuda.ExternalStream(api.stream(), device=dev)
+        with torch.cuda.stream(ext):   # (allocations and the collective are stream-ordered on the engine's stream)
+            send = torch.empty((cap, BLOCK_BYTES), dtype=torch.uint8, device=dev)
+            recv = torch.empty((world, cap, BLOCK_BYTES), dtype=torch.uint8, device=dev)
+            api.shard_dirty_pack(scene, rank, send.data_ptr(), cap)
+            dist.all_gather_into_tensor(recv.view(-1), send.view(-1))
+            api.shard_dirty_unpack(scene, rank, recv.data_ptr(), cap)
         engine_sync()
-        dist.all_gather_into_tensor(recv.view(-1), send.view(-1))
-        torch.cuda.synchronize()
-        api.shard_dirty_unpack(scene, rank, recv.data_ptr(), cap)
-        engine_sync()
+        del send, recv
     return run
 
 
