@@ -68,8 +68,17 @@ def main():
     for src, dst in (("final_stress.json", "stress_integrate"), ("final_pipeline.json", "pipeline_breakdown"),
                      ("final_side_bench.json", "side_bench"), ("final_maintenance.json", "maintenance"),
                      ("final_quality.json", "quality"), ("final_shard_emulation.json", "shard_emulation"),
-                     ("final_mirror.json", "mirror_bench"), ("push_variants.json", "push_variants")):
+                     ("final_mirror.json", "mirror_bench")):
         copy_json(src, f"{tag}_{dst}.json")
+    pv = os.path.join(OUT, "push_variants.json")   # (profiles/experiments/push_variants.sh: an indented JSON list)
+    if os.path.exists(pv):
+        rows = json.load(open(pv))
+        json.dump({"what": "k_integrate<false,true,true> on the S-stress map (V = 262144), kernel time by packet-attached events, per build "
+                           "of integrate.hip with -DDSLAM_PUSH_VARIANT (an experiment macro of round 4, since removed): 0 = the round-3 product "
+                           "(ring bit as a device-scope atomic from the gathering lane + last_seen store), 1 = no push, 2 = ring bit only, "
+                           "3 = last_seen only, 4 = load-OR-store instead of the atomic, 5 / 6 = 0 / 4 behind the group's block stores; "
+                           "process_frame_us = launched by ProcessFrame (push on), integrate_into_scene_us = no push in any variant",
+                   "runs": rows}, open(os.path.join(HERE, f"{tag}_push_variants.json"), "w"), indent=1)
 
     # HBM traffic of k_integrate from the two PMC passes (MI355X_MICROARCH.md, "HBM / rocprofv3"): counters are in KiB;
     # on gfx950 FETCH_SIZE counts wide (16 B per lane) streaming reads at half their size -> doubled; WRITE_SIZE is exact.
