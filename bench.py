@@ -520,7 +520,7 @@ def main():
         avg_ms = int_ms / max(1, launches)
         achieved = (alg_bytes / max(1, launches)) / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
         traffic, traffic_source = None, None
-        for tag in ("r03", "r02", "r01"):  # PMC passes are separate rocprofv3 runs of this same command (profiles/)
+        for tag in ("r04", "r03", "r02", "r01"):  # PMC passes are separate rocprofv3 runs of this same command (profiles/)
             pmc_path = os.path.join(ROOT, "profiles", f"{tag}_integrate_pmc.json")
             if os.path.exists(pmc_path):
                 traffic = json.load(open(pmc_path))["traffic_bytes_per_visible_block"] * blocks / max(1, launches)
