@@ -336,6 +336,9 @@ class CApi:
         self._call("reintegrate_batch", self._engine, scene.ptr, view.ptr, rs.ptr, fs.ptr, C.c_int(n), _vptr(sl), _fptr(om), _fptr(nm),
                    _fptr(k), C.c_float(affine_a), C.c_float(affine_b))
 
+    def debug_inject_device_error(self, scene, bits):
+        self._call("debug_inject_device_error", self._engine, scene.ptr, C.c_int(int(bits)))
+
     def debug_set_push_job_min(self, n):
         self._call("debug_set_push_job_min", self._engine, C.c_int(int(n)))
 

@@ -57,6 +57,14 @@ __global__ __launch_bounds__(256) void k_reset_tables(HashEntry *hash, int n_ent
   }
 }
 
+// test hook (dslam_debug_inject_device_error): a kernel that reports exactly what a failing pass would
+__global__ void k_inject_error(SceneCounters *cnt, int bits) { report_error(cnt, bits); }
+int launch_inject_error(dslam_engine *e, dslam_scene *s, int bits) {
+  hipLaunchKernelGGL(k_inject_error, dim3(1), dim3(1), 0, e->stream, s->counters, bits);
+  DSLAM_HIP(hipGetLastError());
+  return DSLAM_OK;
+}
+
 int launch_scene_reset(dslam_engine *e, dslam_scene *s) {
   const size_t n16 = (size_t)s->p.num_local_blocks * kBlock3 / 2;
   const unsigned fill_wgs = (unsigned)((n16 + 256 * kFillUnroll - 1) / (256 * kFillUnroll));

@@ -293,6 +293,13 @@ int dslam_debug_set_push_job_min(dslam_engine *e, int min_visible_blocks) {
   return DSLAM_OK;
 }
 
+int dslam_debug_inject_device_error(dslam_engine *e, dslam_scene *s, int bits) {
+  DSLAM_REQUIRE(e && s && s->engine == e && (bits == 1 || bits == 2 || bits == 3), "bad argument");
+  int rc = launch_inject_error(e, s, bits);
+  if (rc) return rc;
+  return finish_call(e);
+}
+
 int dslam_engine_set_async(dslam_engine *e, int async_mode) {
   DSLAM_REQUIRE(e, "null engine");
   e->async_mode = async_mode != 0;

@@ -285,6 +285,7 @@ inline void dbg_sync(dslam_engine *e, const char *what) {
 }
 // kernels' host launchers (one translation unit per subsystem)
 int launch_scene_reset(dslam_engine *e, dslam_scene *s);
+int launch_inject_error(dslam_engine *e, dslam_scene *s, int bits);
 int launch_build_alloc_bits(dslam_engine *e, dslam_scene *s);  // alloc_bits from an uploaded table
 int launch_view_convert(dslam_engine *e, dslam_view *v, const void *rgba_dev, const void *depth_dev, float a, float b);
 int launch_bgr_to_rgba(dslam_engine *e, const void *bgr_dev, uchar4 *rgba_dev, int npix);

@@ -174,6 +174,12 @@ int dslam_debug_set_render_tile_budget(dslam_engine *e, int budget);
  * workgroups at the end of the same launch (csrc/integrate.hip, kPushJobMin).  Same bits either way; the parity test of the
  * second form lowers the threshold instead of building a quarter-million-block scene for the oracle. */
 int dslam_debug_set_push_job_min(dslam_engine *e, int min_visible_blocks);
+/* Test hook: a one-thread kernel reports the given device-side error bits for the scene (1: allocation ray longer than the
+ * order key encodes, 2: a tile count never arrived) exactly as a failing pass would (report_error, csrc/dslam_device.h), so
+ * that the way such an error reaches the caller can be tested: returned by this very call on a synchronous engine, by the
+ * next call that waits for the stream on an asynchronous one -- once --, and by dslam_get_stats of that scene until it is
+ * reset. */
+int dslam_debug_inject_device_error(dslam_engine *e, dslam_scene *s, int bits);
 
 /* ---- scene ------------------------------------------------------------------------------------- */
 /* new ITMScene(sceneParams, useSwapping, memoryType) + ResetScene.  ext_voxel_blocks_dev may be NULL

@@ -192,3 +192,38 @@ def test_stored_list_deintegration_equals_the_reference_call_on_an_unchanged_map
         assert gpu.stats(scene, rs)["no_visible_entries"] > 50
     assert np.array_equal(states[0][0], states[1][0]), "hash table"
     assert np.array_equal(states[0][1], states[1][1]), "voxels"
+
+
+@pytest.mark.parametrize("bits,what", [(1, "order key"), (2, "tile count")])
+def test_device_side_errors_reach_the_caller(pkg, synth, gpu, bits, what):
+    """Two conditions only a kernel can detect (an allocation ray longer than the order key encodes; a tile count of an
+    ordered compaction that never arrived).  A one-thread kernel reports them exactly as a failing pass would
+    (dslam_debug_inject_device_error -> report_error).  Synchronous engine: the call itself fails.  Asynchronous engine
+    (what the ITMLib mirror runs): the call returns, the NEXT call that waits for the stream fails -- once --, further waits
+    are clean, and dslam_get_stats keeps reporting the scene's own sticky flags until the scene is reset
+    (include/dslam_fusion.h, conventions)."""
+    wl = synth.s_tiny()
+    p = util.small_params(pkg, wl)
+    scene = gpu.create_scene(p)
+    other = gpu.create_scene(p)
+    rs = gpu.create_render_state(scene, wl.W, wl.H)
+    with pytest.raises(pkg.DslamError, match=what):
+        gpu.debug_inject_device_error(scene, bits)        # synchronous: told by the call that caused it
+    gpu.synchronize()                                      # ... and told once
+    gpu.set_async(True)
+    try:
+        gpu.debug_inject_device_error(scene, bits)        # enqueued, returns
+        with pytest.raises(pkg.DslamError, match=what):
+            gpu.synchronize()                              # the first waiting call hears of it
+        gpu.synchronize()
+        gpu.download_hash_table(other)                     # (a read-back is a waiting call too: nothing left to tell)
+        gpu.debug_inject_device_error(scene, bits)
+        with pytest.raises(pkg.DslamError, match=what):
+            gpu.download_hash_table(other)                 # whichever scene the waiting call is about: the word is the engine's
+    finally:
+        gpu.set_async(False)
+    with pytest.raises(pkg.DslamError, match=what):
+        gpu.stats(scene, rs)                               # sticky for the scene it happened in
+    assert gpu.stats(other)["num_allocated_blocks"] == p.num_local_blocks   # ... and only there
+    gpu.reset_scene(scene)
+    assert gpu.stats(scene, rs)["last_free_block_id"] == p.num_local_blocks - 1
