@@ -86,6 +86,11 @@ def _trial(pkg, synth, gpu, oracle, seed, use_store=None, extras=True, more_ops=
     async_mode = bool(extras and ops_v >= 2 and rng_store.random() < 0.33) and is_hip
     if async_mode:
         gpu.set_async(True)
+    # (round 4) one trial in five queues its visible lists on the ring from the fusion kernel's trailing workgroups -- the
+    # path maps with 65536+ visible blocks take (own random stream: the trials of earlier hunts stay what they were)
+    push_job = bool(is_hip and gpu.has("debug_set_push_job_min") and np.random.default_rng(seed + 99119911).random() < 0.2)
+    if push_job:
+        gpu.debug_set_push_job_min(0)
     log = []
     try:
         fused = []
@@ -262,6 +267,8 @@ def _trial(pkg, synth, gpu, oracle, seed, use_store=None, extras=True, more_ops=
     finally:
         if async_mode:
             gpu.set_async(False)
+        if push_job:
+            gpu.debug_set_push_job_min(65536)
         for api, *_ in objs.values():
             api.set_fusion_weight_params()
     return log
