@@ -85,10 +85,10 @@ int sync_check(dslam_engine *e) {
   return device_errors(e);
 }
 int device_errors(dslam_engine *e) {
-  volatile int *h = e->err_host;
-  const int flags = h ? *h : 0;
+  int *h = e->err_host;
+  if (!h || __atomic_load_n(h, __ATOMIC_RELAXED) == 0) return DSLAM_OK;
+  const int flags = __atomic_exchange_n(h, 0, __ATOMIC_RELAXED);   // (taken in one step: a report that lands now is the next call's)
   if (flags == 0) return DSLAM_OK;
-  *h = 0;
   if (flags & 2) {
     set_last_error("a tile count of an ordered compaction never arrived (device made no progress?): the map state is undefined");
     return DSLAM_ERR_HIP;
