@@ -1028,6 +1028,7 @@ struct BatchParams {
   const int *cls_count;   // [kBatchClasses]
   int n_local;
   int n_ops;
+  int grid_waves;   // waves of the launch (units are dealt round-robin over them)
 };
 
 // What an operation needs of its BatchOp, in SCALAR registers.  The table sits in LDS (a scalar load per operation costs a
@@ -1229,7 +1230,7 @@ __global__ __launch_bounds__(kBatchWgWaves * 64) void k_reintegrate_blocks(Batch
   const int n = __builtin_amdgcn_readfirstlane(s_cum[8]) * (2 / kHalves);
   const int vx0 = (lane & 3) * 2, vy = (lane >> 2) & 7, vz0 = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane((int)((blockIdx.x * (kBatchWgWaves * 64) + threadIdx.x) >> 6));
-  for (int i = wave; i < n; i += kBatchGrid * kBatchWgWaves) {
+  for (int i = wave; i < n; i += bp.grid_waves) {
     const int bi = kHalves == 2 ? i : (i >> 1);
     int cls = 0;
 #pragma unroll
@@ -1436,7 +1437,9 @@ int launch_reintegrate_blocks(dslam_engine *e, dslam_scene *s, int w_d, int h_d,
   bp.opmask = opmask; bp.slot_entry = slot_entry; bp.cls_list = cls_list; bp.cls_count = cls_count; bp.n_local = s->p.num_local_blocks;
   bp.n_ops = n_ops;
   const bool sharded = ip.num_shards > 1 || ip.shard_count >= 0;
-  const dim3 grid(kBatchGrid), block(kBatchWgWaves * 64);
+  static const int grid_wgs = getenv("DSLAM_BATCH_GRID") ? atoi(getenv("DSLAM_BATCH_GRID")) : kBatchGrid;   // (experiments: occupancy of the block launch)
+  bp.grid_waves = grid_wgs * kBatchWgWaves;
+  const dim3 grid(grid_wgs), block(kBatchWgWaves * 64);
   if (ip.depth_weighting) {
     if (sharded) hipLaunchKernelGGL((k_reintegrate_blocks<false, 1>), grid, block, 0, e->stream, bp);
     else hipLaunchKernelGGL((k_reintegrate_blocks<false, 2>), grid, block, 0, e->stream, bp);
