@@ -1199,7 +1199,17 @@ __device__ __forceinline__ void batch_op(uint4 (&v)[kHalves][2], bool (&chs)[kHa
   }
 }
 
-constexpr int kBatchWgWaves = 8;
+// (-DDSLAM_BATCH_WAVES / -DDSLAM_BATCH_MIN_WAVES / -DDSLAM_BATCH_UNSHARDED_HALVES: occupancy experiments of round 4)
+#ifndef DSLAM_BATCH_WAVES
+#define DSLAM_BATCH_WAVES 8
+#endif
+#ifndef DSLAM_BATCH_MIN_WAVES
+#define DSLAM_BATCH_MIN_WAVES 1
+#endif
+#ifndef DSLAM_BATCH_UNSHARDED_HALVES
+#define DSLAM_BATCH_UNSHARDED_HALVES 2
+#endif
+constexpr int kBatchWgWaves = DSLAM_BATCH_WAVES;
 // 4096 waves = what is resident at once (4 per SIMD at this register count).  Units are dealt round-robin over the list
 // ordered longest first -- NOT fetched from a device counter: ~77 k fetches from one address serialise at ~12 ns each,
 // which was 0.9 ms of a 1.2 ms launch and the whole launch of a rank that owns an eighth of the blocks.
@@ -1210,7 +1220,7 @@ constexpr int kBatchGrid = 512;
 // then ends with the longest chain of operations on one unit, and a half block's is half as long (rank 0 of 8: 0.46
 // against 0.52 ms in round 3).
 template <bool UNIT_W, int kHalves>
-__global__ __launch_bounds__(kBatchWgWaves * 64) void k_reintegrate_blocks(BatchParams bp) {
+__global__ __launch_bounds__(kBatchWgWaves * 64, DSLAM_BATCH_MIN_WAVES) void k_reintegrate_blocks(BatchParams bp) {
   __shared__ float inv_tab[kInvTab];
   __shared__ BatchColQueue<kHalves> col_q[kBatchWgWaves];
   __shared__ BatchOp s_ops[64];   // the batch's operations: read per operation from LDS, not with a ~1 us scalar load each
@@ -1442,10 +1452,10 @@ int launch_reintegrate_blocks(dslam_engine *e, dslam_scene *s, int w_d, int h_d,
   const dim3 grid(grid_wgs), block(kBatchWgWaves * 64);
   if (ip.depth_weighting) {
     if (sharded) hipLaunchKernelGGL((k_reintegrate_blocks<false, 1>), grid, block, 0, e->stream, bp);
-    else hipLaunchKernelGGL((k_reintegrate_blocks<false, 2>), grid, block, 0, e->stream, bp);
+    else hipLaunchKernelGGL((k_reintegrate_blocks<false, DSLAM_BATCH_UNSHARDED_HALVES>), grid, block, 0, e->stream, bp);
   } else {
     if (sharded) hipLaunchKernelGGL((k_reintegrate_blocks<true, 1>), grid, block, 0, e->stream, bp);
-    else hipLaunchKernelGGL((k_reintegrate_blocks<true, 2>), grid, block, 0, e->stream, bp);
+    else hipLaunchKernelGGL((k_reintegrate_blocks<true, DSLAM_BATCH_UNSHARDED_HALVES>), grid, block, 0, e->stream, bp);
   }
   DSLAM_HIP(hipGetLastError());
   return DSLAM_OK;
