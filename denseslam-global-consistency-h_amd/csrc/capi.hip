@@ -642,13 +642,36 @@ static int finish_view_update(dslam_engine *e, dslam_view *v, const void *rgba_d
 // engine remembers the ranges, so an upload from one of them can skip the staging copy.
 static std::mutex g_pinned_mu;
 static std::vector<std::pair<const char *, size_t>> g_pinned_ranges;
+// Buffers of up to kArenaMax bytes are carved out of page-locked arenas one behind the other (256-byte granules), so that
+// images a caller allocates in a row -- InfiniTamDriver's rgb_itm_ and raw_depth_itm_ (InfiniTamDriver.h:103-104), the bench's
+// frame ring -- are CONTIGUOUS in host memory: dslam_view_update then moves a frame with one copy instead of two (one DMA
+// start-up less per frame: what the pipelined upload path already did for callers that laid their frames out that way by
+// hand).  An arena goes back to the runtime when its last buffer is freed.
+namespace {
+constexpr size_t kArenaMax = 8u << 20, kArenaBytes = 32u << 20;
+struct PinnedArena { char *base; size_t used; int live; };
+std::vector<PinnedArena> g_arenas;
+}  // namespace
 
 int dslam_host_alloc(size_t bytes, void **out) {
   DSLAM_REQUIRE(out, "null argument");
-  void *p = nullptr;
-  DSLAM_HIP(hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault));
-  memset(p, 0, bytes);
+  const size_t need = ((bytes ? bytes : 1) + 255) & ~(size_t)255;
   std::lock_guard<std::mutex> lock(g_pinned_mu);
+  void *p = nullptr;
+  if (need <= kArenaMax) {
+    if (g_arenas.empty() || g_arenas.back().used + need > kArenaBytes) {
+      void *base = nullptr;
+      DSLAM_HIP(hipHostMalloc(&base, kArenaBytes, hipHostMallocDefault));
+      g_arenas.push_back({static_cast<char *>(base), 0, 0});
+    }
+    PinnedArena &a = g_arenas.back();
+    p = a.base + a.used;
+    a.used += need;
+    a.live++;
+  } else {
+    DSLAM_HIP(hipHostMalloc(&p, need, hipHostMallocDefault));
+  }
+  memset(p, 0, bytes);
   g_pinned_ranges.emplace_back(static_cast<const char *>(p), bytes ? bytes : 1);
   *out = p;
   return DSLAM_OK;
@@ -656,12 +679,22 @@ int dslam_host_alloc(size_t bytes, void **out) {
 
 int dslam_host_free(void *p) {
   if (!p) return DSLAM_OK;
-  {
-    std::lock_guard<std::mutex> lock(g_pinned_mu);
-    size_t i = 0;
-    while (i < g_pinned_ranges.size() && g_pinned_ranges[i].first != p) i++;
-    DSLAM_REQUIRE(i < g_pinned_ranges.size(), "dslam_host_free: pointer was not returned by dslam_host_alloc");
-    g_pinned_ranges.erase(g_pinned_ranges.begin() + i);
+  std::lock_guard<std::mutex> lock(g_pinned_mu);
+  size_t i = 0;
+  while (i < g_pinned_ranges.size() && g_pinned_ranges[i].first != p) i++;
+  DSLAM_REQUIRE(i < g_pinned_ranges.size(), "dslam_host_free: pointer was not returned by dslam_host_alloc");
+  g_pinned_ranges.erase(g_pinned_ranges.begin() + i);
+  for (size_t k = 0; k < g_arenas.size(); k++) {
+    PinnedArena &a = g_arenas[k];
+    if (static_cast<char *>(p) >= a.base && static_cast<char *>(p) < a.base + kArenaBytes) {
+      if (--a.live == 0) {   // (the arena that is being filled is kept while it has room: its next buffer may come at once)
+        if (k + 1 == g_arenas.size() && a.used < kArenaBytes) { a.used = 0; return DSLAM_OK; }
+        char *base = a.base;
+        g_arenas.erase(g_arenas.begin() + k);
+        DSLAM_HIP(hipHostFree(base));
+      }
+      return DSLAM_OK;
+    }
   }
   DSLAM_HIP(hipHostFree(p));
   return DSLAM_OK;
