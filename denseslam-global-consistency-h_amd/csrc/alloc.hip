@@ -36,7 +36,7 @@ __global__ __launch_bounds__(256) void k_fill_voxels(uint4 *__restrict__ v, size
 #pragma unroll
   for (int u = 0; u < kFillUnroll; u++) {
     const size_t i = base + (size_t)u * 256;
-    if (i < n16) v[i] = empty2;
+    if (i < n16) v[i] = empty2;   // (plain stores: the non-temporal policy is 1.5 % slower here, 198-201 -> 203-204 us per GiB)
   }
 }
 
@@ -383,6 +383,7 @@ struct SweepParams {
   unsigned *swap1_bits;
   SceneCounters *cnt;
   RenderCounters *rc;
+  int *vis_hint;    // page-locked copy of rc->no_visible for the host (dslam_render_state::vis_hint); may be null
   int *visible_ids;
   int capacity;
   const unsigned *q1, *q2, *mark, *retest;   // this pass
@@ -802,6 +803,7 @@ __global__ __launch_bounds__(256) void k_alloc_sweep(SweepParams p) {
     if (last && threadIdx.x == 0) {
       const int n = vis_first + vis_tot;
       p.rc->no_visible = n < p.capacity ? n : p.capacity;
+      if (p.vis_hint) __hip_atomic_store(p.vis_hint, n < p.capacity ? n : p.capacity, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
       if (p.do_commit) {
         const int vr_all = all1 + (all2 < avail_ex ? all2 : avail_ex);
         const int succ_vba = vr_all < avail_vba ? vr_all : avail_vba;   // every success takes exactly one voxel-block slot
@@ -976,6 +978,7 @@ int launch_allocate(dslam_engine *e, dslam_scene *s, const dslam_view *v, dslam_
   sp.vis_type = r->visible_type; sp.swap_state = s->swap_state; sp.swap1_bits = s->swap1_bits;
   sp.cnt = s->counters; sp.capacity = r->n_local;
   sp.rc = count_out ? reinterpret_cast<RenderCounters *>(count_out) : r->counters;
+  sp.vis_hint = count_out ? nullptr : r->vis_hint;
   sp.visible_ids = list_out ? list_out : r->visible_ids;
   sp.q1 = mp.q1; sp.q2 = mp.q2; sp.mark = mp.mark; sp.retest = e->bits_retest;
   sp.oq1 = e->bits_q1[oth]; sp.oq2 = e->bits_q2[oth]; sp.omark = e->bits_mark[oth];

@@ -531,6 +531,8 @@ int dslam_shard_dirty_unpack(dslam_engine *e, dslam_scene *s, int skip_shard, co
 static int render_state_allocate(dslam_engine *e, dslam_render_state *r) {
   const size_t npix = (size_t)r->w * r->h;
   DSLAM_HIP(hipMalloc(&r->visible_ids, (size_t)r->n_local * sizeof(int)));
+  DSLAM_HIP(hipHostMalloc((void **)&r->vis_hint, 64, hipHostMallocDefault));
+  *r->vis_hint = 0;
   DSLAM_HIP(hipMalloc(&r->visible_type, r->n_entries));
   const size_t vis_bits_bytes = (size_t)bit_tiles(r->n_entries) * kBitTileWords * sizeof(unsigned);
   DSLAM_HIP(hipMalloc(&r->vis_bits, vis_bits_bytes));
@@ -575,6 +577,7 @@ int dslam_render_state_destroy(dslam_render_state *r) {
   free_dev(r->image_rgba); free_dev(r->image_float); free_dev(r->icp_points); free_dev(r->icp_normals);
   free_dev(r->raycast_image);
   free_dev(r->proj_boxes); free_dev(r->proj_z); free_dev(r->proj_req); free_dev(r->proj_wg_tiles); free_dev(r->counters);
+  if (r->vis_hint) (void)hipHostFree(r->vis_hint);
   delete r;
   return DSLAM_OK;
 }
@@ -1679,6 +1682,7 @@ int dslam_upload_visible_ids(dslam_engine *e, dslam_render_state *r, const int32
   rc = d2h(e, rcn, r->counters, sizeof(RenderCounters));
   if (rc) return rc;
   rcn->no_visible = count;
+  __atomic_store_n(r->vis_hint, count, __ATOMIC_RELAXED);
   return h2d(e, r->counters, rcn, sizeof(RenderCounters));
 }
 

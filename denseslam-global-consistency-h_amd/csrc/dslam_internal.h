@@ -110,7 +110,10 @@ struct dslam_engine {
   long long timer_blocks = 0;
   int *timer_counts_dev = nullptr;    // visible-block count of each timed launch (written by the kernel)
   int sm_count = 256;
-  int push_job_min = 65536;           // integrate.hip kPushJobMin; lowered only by the test of the trailing push workgroups
+  // visible blocks from which on a fusion launch counts as larger than the Infinity Cache (65536 x 4 KiB = 256 MiB): trailing
+  // push workgroups (integrate.hip kPushJobMin, decided on the device) and streaming cache policy (decided by the host from
+  // dslam_render_state::vis_hint).  Lowered only by the parity test of those paths.
+  int push_job_min = 65536;
   int render_tile_budget = DSLAM_MAX_RENDERING_BLOCKS;  // MAX_RENDERING_BLOCKS; lowered only by the budget test
   double *icp_partials_host = nullptr;  // depth tracker: per-workgroup partial sums in mapped pinned host memory
   double *icp_partials = nullptr;       // ... and the device address of the same buffer
@@ -197,6 +200,11 @@ struct dslam_render_state {
   int *proj_req = nullptr;      // per visible block: render tiles required (0 = invalid projection)
   int *proj_wg_tiles = nullptr; // render tiles requested per workgroup of the projection pass (summed by the next kernel)
   dslam::RenderCounters *counters = nullptr;  // device
+  // One page-locked word: the length of the visible list as the last allocation pass that RAN left it (k_alloc_sweep writes
+  // it next to the device counter; an uploaded list sets it).  The host looks at it -- without waiting for anything, so on an
+  // asynchronous engine it is a frame or two old -- to choose the fusion kernel's cache policy (launch_integrate): a hint,
+  // both policies compute the same bytes.
+  int *vis_hint = nullptr;
   // entriesVisibleType carries a generation bit (0x80): an allocation pass writes its marks with the pass' bit, so a
   // non-zero byte with the OTHER bit is "visible in the previous pass" (upstream's re-arming of the previous visible
   // list as type 3) without a pass over that list.  The C ABI hands out the plain types (bit masked off).

@@ -125,7 +125,7 @@ __global__ __launch_bounds__(256) void k_decay_blocks(const int *__restrict__ ca
       uint4 *blk = voxels16 + (size_t)ptr * (kBlock3 / 2);
       uint4 v[4];
 #pragma unroll
-      for (int j = 0; j < 4; j++) v[j] = blk[j * 64 + lane];
+      for (int j = 0; j < 4; j++) v[j] = load_nt(blk + j * 64 + lane);
       bool measured = false;
 #pragma unroll
       for (int j = 0; j < 4; j++) {
@@ -134,7 +134,7 @@ __global__ __launch_bounds__(256) void k_decay_blocks(const int *__restrict__ ca
         if (w0 > 0 && (int)w0 <= max_weight) { v[j].x = kEmptyVoxelLo; v[j].y = kEmptyVoxelHi; ch = true; }
         if (w1 > 0 && (int)w1 <= max_weight) { v[j].z = kEmptyVoxelLo; v[j].w = kEmptyVoxelHi; ch = true; }
         measured |= (((v[j].x >> 16) & 0xffu) > 0) || (((v[j].z >> 16) & 0xffu) > 0);
-        if (ch) blk[j * 64 + lane] = v[j];
+        if (ch) store_nt(blk + j * 64 + lane, v[j]);
       }
       const bool any = __ballot(measured) != 0ull;
       if (!any && mark_empty && lane == 0) {
@@ -221,7 +221,7 @@ __global__ __launch_bounds__(256) void k_release_and_leaders(const int *__restri
         if (ptr < 0) continue;
         uint4 *blk = voxels16 + (size_t)ptr * (kBlock3 / 2);
 #pragma unroll
-        for (int j = 0; j < 4; j++) blk[j * 64 + lane] = empty2;
+        for (int j = 0; j < 4; j++) store_nt(blk + j * 64 + lane, empty2);
         if (lane < 2 * words) masks[(size_t)ptr * 2 * words + lane] = 0ull;
       }
     }

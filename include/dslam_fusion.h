@@ -171,8 +171,10 @@ int dslam_selftest_division(dslam_engine *e, long long samples, long long *misma
 int dslam_debug_set_render_tile_budget(dslam_engine *e, int budget);
 /* Test hook: ProcessFrame queues the frame's visible list on the ring either from the fusion kernel's block waves or -- from
  * this many visible blocks on (default 65536: maps whose visible voxels no longer fit the Infinity Cache) -- from extra
- * workgroups at the end of the same launch (csrc/integrate.hip, kPushJobMin).  Same bits either way; the parity test of the
- * second form lowers the threshold instead of building a quarter-million-block scene for the oracle. */
+ * workgroups at the end of the same launch (csrc/integrate.hip, kPushJobMin).  From the same size on the fusion and
+ * de-integration launches over a render state's list read and write their voxel blocks with the non-temporal cache policy
+ * (chosen by the host from the visible count the last allocation pass reported).  Same bits either way; the parity test of
+ * the second forms lowers the threshold instead of building a quarter-million-block scene for the oracle. */
 int dslam_debug_set_push_job_min(dslam_engine *e, int min_visible_blocks);
 /* Test hook: a one-thread kernel reports the given device-side error bits for the scene (1: allocation ray longer than the
  * order key encodes, 2: a tile count never arrived) exactly as a failing pass would (report_error, csrc/dslam_device.h), so
