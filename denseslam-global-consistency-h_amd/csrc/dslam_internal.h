@@ -200,10 +200,10 @@ struct dslam_render_state {
   int *proj_req = nullptr;      // per visible block: render tiles required (0 = invalid projection)
   int *proj_wg_tiles = nullptr; // render tiles requested per workgroup of the projection pass (summed by the next kernel)
   dslam::RenderCounters *counters = nullptr;  // device
-  // One page-locked word: the length of the visible list as the last allocation pass that RAN left it (k_alloc_sweep writes
-  // it next to the device counter; an uploaded list sets it).  The host looks at it -- without waiting for anything, so on an
-  // asynchronous engine it is a frame or two old -- to choose the fusion kernel's cache policy (launch_integrate): a hint,
-  // both policies compute the same bytes.
+  // One page-locked word: the length of the visible list as an allocation pass that RAN left it -- k_alloc_sweep rewrites it
+  // whenever the answer to "at least push_job_min blocks?" would change, an uploaded list sets it.  The
+  // host looks at it -- without waiting for anything, so on an asynchronous engine it is a frame or two late -- to choose the
+  // fusion kernel's cache policy (launch_integrate): a hint, both policies compute the same bytes.
   int *vis_hint = nullptr;
   // entriesVisibleType carries a generation bit (0x80): an allocation pass writes its marks with the pass' bit, so a
   // non-zero byte with the OTHER bit is "visible in the previous pass" (upstream's re-arming of the previous visible

@@ -734,14 +734,22 @@ __global__ __launch_bounds__(kWgWaves * 64, 8) void k_integrate(IntegrateParams 
         if (p.push_words && (!PLAIN || nvis < p.push_job_min)) {  // queue this block on the visible-list ring (one lane per block: no race)
           unsigned long long *word = &p.masks[((size_t)ptr * 2 + p.push_ring) * p.push_words + (p.push_bit >> 6)];
           // (PLAIN: an atomic OR whose result nobody reads -- nothing to wait for in front of the block loads)
-          if constexpr (PLAIN) __hip_atomic_fetch_or(word, 1ull << (p.push_bit & 63), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          else *word |= 1ull << (p.push_bit & 63);
+          int bit = p.push_bit & 63;
+          // (STREAM: the shift stays here -- hoisted out of the loops, the 64-bit mask is the one value the streaming variants
+          // have no register for, and they would be the only kernels of the library with scratch memory)
+          if constexpr (STREAM) asm volatile("" : "+v"(bit));
+          if constexpr (PLAIN) __hip_atomic_fetch_or(word, 1ull << bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          else *word |= 1ull << bit;
           p.last_seen[ptr] = p.push_frame;
         }
         if constexpr (!PLAIN) {
           // (before the shard test: every rank of a sharded batch ends up with the same set of marks)
           if (p.dirty) p.dirty[ptr] = 1;
-          if (p.num_shards > 1 && ((ptr / p.chunk_blocks) % p.num_shards) != p.shard) e_ptr = -3;
+          if (p.num_shards > 1) {
+            int cb = p.chunk_blocks, ns = p.num_shards;
+            if constexpr (STREAM) asm volatile("" : "+s"(cb), "+s"(ns));   // (the divisions' reciprocals stay here: see the ring push above)
+            if (((ptr / cb) % ns) != p.shard) e_ptr = -3;
+          }
           if (p.shard_count >= 0 && (ptr < p.shard_first || ptr >= p.shard_first + p.shard_count)) e_ptr = -3;
         }
       }
@@ -773,7 +781,8 @@ __global__ __launch_bounds__(kWgWaves * 64, 8) void k_integrate(IntegrateParams 
       for (int half = 0; half < 2; half++) {
       uint4 v[2];
       if constexpr (stream) {
-        vox_load2(v[0], v[1], blk + (half * 2) * 64 + lane, blk + (half * 2 + 1) * 64 + lane);
+        v[0] = load_nt(blk + (half * 2) * 64 + lane);
+        v[1] = load_nt(blk + (half * 2 + 1) * 64 + lane);
       } else {
         v[0] = blk[(half * 2) * 64 + lane];
         v[1] = blk[(half * 2 + 1) * 64 + lane];
@@ -897,7 +906,7 @@ __global__ __launch_bounds__(kWgWaves * 64, 8) void k_integrate(IntegrateParams 
 #pragma unroll
       for (int jj = 0; jj < 2; jj++)
         if (chs[jj]) {
-          if constexpr (stream) vox_store(blk + (half * 2 + jj) * 64 + lane, v[jj]);
+          if constexpr (stream) store_nt(blk + (half * 2 + jj) * 64 + lane, v[jj]);
           else blk[(half * 2 + jj) * 64 + lane] = v[jj];
         }
       DSLAM_STAMP(7 + half * 4);
