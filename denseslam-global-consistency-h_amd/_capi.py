@@ -168,6 +168,12 @@ class CApi:
     def set_async(self, flag):
         self._call("engine_set_async", self._engine, C.c_int(int(flag)))
 
+    def device_numa_node(self, device=0):
+        """NUMA node of the host the device hangs off (-1: unknown) -- HIP engine"""
+        node = C.c_int(-1)
+        self._call("device_numa_node", C.c_int(int(device)), C.byref(node))
+        return node.value
+
     def selftest_division(self, samples):
         out = C.c_longlong(-1)
         self._call("selftest_division", self._engine, C.c_longlong(samples), C.byref(out))
@@ -341,6 +347,11 @@ class CApi:
 
     def debug_set_push_job_min(self, n):
         self._call("debug_set_push_job_min", self._engine, C.c_int(int(n)))
+
+    def debug_stream_launches(self):
+        n = C.c_longlong(0)
+        self._call("debug_stream_launches", self._engine, C.byref(n))
+        return n.value
 
     def reintegrate_batch_stats(self, scene):
         """(blocks the last batch loaded, its block-operations: (block, keyframe) pairs de-integrated or re-fused) -- HIP engine"""

@@ -2,6 +2,7 @@
 // composition of kernels into the ITMLib engine calls (ITMDenseMapper::ProcessFrame, ITMMainEngine::GetImage ...).
 // No arithmetic of the hot path lives here; there is no CPU fallback: without a HIP device the engine cannot be
 // created and every entry point fails.
+#include <cctype>
 #include <atomic>
 #include <cstdio>
 #include <cstdlib>
@@ -217,6 +218,28 @@ static int engine_allocate(dslam_engine *e) {
   return DSLAM_OK;
 }
 
+int dslam_device_numa_node(int device_index, int *node_out) {
+  if (!node_out) return DSLAM_ERR_INVALID;
+  *node_out = -1;
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) {
+    set_last_error("no HIP device: libdslam_fusion has no CPU path");
+    return DSLAM_ERR_NO_DEVICE;
+  }
+  DSLAM_REQUIRE(device_index >= 0 && device_index < n, "device index out of range");
+  char bus[64] = {0};
+  DSLAM_HIP(hipDeviceGetPCIBusId(bus, (int)sizeof(bus) - 1, device_index));
+  for (char *c = bus; *c; c++) *c = (char)tolower(*c);
+  char path[160];
+  snprintf(path, sizeof(path), "/sys/bus/pci/devices/%s/numa_node", bus);
+  if (FILE *f = fopen(path, "r")) {
+    int node = -1;
+    if (fscanf(f, "%d", &node) == 1) *node_out = node;
+    fclose(f);
+  }
+  return DSLAM_OK;   // (-1: the platform does not say)
+}
+
 int dslam_engine_create(int device_index, dslam_engine **out) {
   if (!out) return DSLAM_ERR_INVALID;
   *out = nullptr;
@@ -290,6 +313,12 @@ int dslam_debug_set_render_tile_budget(dslam_engine *e, int budget) {
 int dslam_debug_set_push_job_min(dslam_engine *e, int min_visible_blocks) {
   DSLAM_REQUIRE(e && min_visible_blocks >= 0, "bad argument");
   e->push_job_min = min_visible_blocks;
+  return DSLAM_OK;
+}
+
+int dslam_debug_stream_launches(dslam_engine *e, long long *count_out) {
+  DSLAM_REQUIRE(e && count_out, "bad argument");
+  *count_out = e->stream_launches;
   return DSLAM_OK;
 }
 

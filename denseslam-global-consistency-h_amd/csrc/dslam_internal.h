@@ -114,6 +114,7 @@ struct dslam_engine {
   // push workgroups (integrate.hip kPushJobMin, decided on the device) and streaming cache policy (decided by the host from
   // dslam_render_state::vis_hint).  Lowered only by the parity test of those paths.
   int push_job_min = 65536;
+  long long stream_launches = 0;      // fusion / de-integration launches that took the streaming instantiation (test hook)
   int render_tile_budget = DSLAM_MAX_RENDERING_BLOCKS;  // MAX_RENDERING_BLOCKS; lowered only by the budget test
   double *icp_partials_host = nullptr;  // depth tracker: per-workgroup partial sums in mapped pinned host memory
   double *icp_partials = nullptr;       // ... and the device address of the same buffer

@@ -970,6 +970,8 @@ static int launch_integrate_params(dslam_engine *e, IntegrateParams &ip, bool de
   const dim3 grid(kIntegrateGrid), block(kWgWaves * 64);
   const dim3 grid_plain(kIntegrateGrid + kPushWgs);   // (+ the workgroups that queue the visible list on the ring)
   if (deintegrate) {
+    // (streaming instantiations exist for the one-camera de-integration and the plain one-camera fusion)
+    if (ip.same_cam && stream) e->stream_launches++;
     if (ip.same_cam && stream) hipExtLaunchKernelGGL((k_integrate<true, true, false, false, true>), grid, block, 0, e->stream, ev0, ev1, 0, ip);
     else if (ip.same_cam) hipExtLaunchKernelGGL((k_integrate<true, true>), grid, block, 0, e->stream, ev0, ev1, 0, ip);
     else hipExtLaunchKernelGGL((k_integrate<true, false>), grid, block, 0, e->stream, ev0, ev1, 0, ip);
@@ -994,6 +996,7 @@ static int launch_integrate_params(dslam_engine *e, IntegrateParams &ip, bool de
       (void)hipFree(trace_dev);
       return DSLAM_OK;
     }
+    if (plain && stream) e->stream_launches++;
     if (plain && stream) hipExtLaunchKernelGGL((k_integrate<false, true, DSLAM_PACKED && DSLAM_COLOUR_QUEUE, false, true>), grid_plain, block, 0, e->stream, ev0, ev1, 0, ip);
     else if (plain) hipExtLaunchKernelGGL((k_integrate<false, true, DSLAM_PACKED && DSLAM_COLOUR_QUEUE>), grid_plain, block, 0, e->stream, ev0, ev1, 0, ip);
     else if (ip.same_cam) hipExtLaunchKernelGGL((k_integrate<false, true>), grid, block, 0, e->stream, ev0, ev1, 0, ip);

@@ -134,6 +134,11 @@ const char *dslam_version(void);
 /* ITMSceneReconstructionEngineFactory / ITMVisualisationEngineFactory / ITMSwappingEngineFactory for
  * the HIP device type (ITMMainEngine ctor, InfiniTamDriver.h:102). */
 int dslam_engine_create(int device_index, dslam_engine **out);
+/* The NUMA node of the host the device hangs off (-1 if the platform does not say; read from sysfs by PCI bus id).  A caller
+ * that fills page-locked images every frame (CvToItm, InfiniTamDriver.cpp:17-75) should run on that node: the 1.8 MB fill of a
+ * 640x480 frame takes ~60 us there and ~160 us from the other socket of a two-socket host.  May be
+ * called before any engine exists. */
+int dslam_device_numa_node(int device_index, int *node_out);
 int dslam_engine_destroy(dslam_engine *e);
 int dslam_engine_set_async(dslam_engine *e, int async_mode);
 /* waits for everything enqueued so far; returns what kernels reported since the last synchronising call (above) */
@@ -176,6 +181,8 @@ int dslam_debug_set_render_tile_budget(dslam_engine *e, int budget);
  * (chosen by the host from the visible count the last allocation pass reported).  Same bits either way; the parity test of
  * the second forms lowers the threshold instead of building a quarter-million-block scene for the oracle. */
 int dslam_debug_set_push_job_min(dslam_engine *e, int min_visible_blocks);
+/* Test hook: how many fusion / de-integration launches of this engine took the streaming (non-temporal) instantiation. */
+int dslam_debug_stream_launches(dslam_engine *e, long long *count_out);
 /* Test hook: a one-thread kernel reports the given device-side error bits for the scene (1: allocation ray longer than the
  * order key encodes, 2: a tile count never arrived) exactly as a failing pass would (report_error, csrc/dslam_device.h), so
  * that the way such an error reaches the caller can be tested: returned by this very call on a synchronous engine, by the

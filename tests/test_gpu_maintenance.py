@@ -92,6 +92,35 @@ def test_ring_push_by_trailing_workgroups(pkg, synth, gpu, oracle):
     assert last["gpu"]["stats"]["slid_block_count"] > 0
 
 
+def test_streaming_instantiations_of_fusion_and_deintegration(pkg, synth, gpu, oracle):
+    """Launches over at least push_job_min visible blocks run the STREAM instantiations of k_integrate (non-temporal loads and
+    stores of the voxel blocks, chosen by the host from the visible count the allocation sweep reported;
+    integrate.hip vox_load2).  With the threshold at 0 every fusion AND de-integration of an online-correction sequence takes
+    them: same map as the oracle after every frame."""
+    wl = synth.s_tiny()
+    p = util.small_params(pkg, wl)
+
+    def extra(i, api, s, rs, v):
+        if i >= 3:
+            j = i - 3
+            rgba, mm, M_old = wl.frame(j)
+            M_new = synth.world_to_camera(wl.pose(j) @ synth.pose_matrix(synth.look_rotation(0.01, 0.0), [0.01, 0.0, 0.005]))
+            api.view_update(v, rgba, mm, timestamp=float(j))
+            api.deprocess_frame(s, v, rs, M_old, wl.intr)
+            api.process_frame(s, v, rs, M_new, wl.intr, is_defusion=True)
+
+    before = gpu.debug_stream_launches()
+    gpu.debug_set_push_job_min(0)
+    try:
+        _run_pair(gpu, oracle, pkg, wl, p, 8, slide=4, extra=extra)
+    finally:
+        gpu.debug_set_push_job_min(65536)
+    assert gpu.debug_stream_launches() - before == 8 + 2 * 5   # every fusion, de-integration and re-fusion
+    # ... and an ordinary sequence never takes them
+    _run_pair(gpu, oracle, pkg, wl, p, 3)
+    assert gpu.debug_stream_launches() - before == 8 + 2 * 5
+
+
 def test_slide_window_and_decay_together(pkg, synth, gpu, oracle):
     wl = synth.s_tiny()
     p = util.small_params(pkg, wl)
