@@ -121,6 +121,29 @@ def make_torch_all_gather(api, scene, dist, engine_sync):
     return run
 
 
+def make_staged_all_gather(api, scene, dist, engine_sync):
+    """HIP engine, collective over HOST memory (backend gloo): pack on the device, stage through the host, unpack on the
+    device.  Not a production path -- it is how several ranks that SHARE one GPU (the one-GPU box: RCCL refuses two ranks on
+    one device) run the sharded kernels and the exchange across real process boundaries (tests/test_gpu_multirank.py)."""
+    import torch
+
+    def run(counts):
+        world, rank = dist.get_world_size(), dist.get_rank()
+        cap = max(1, max(counts))
+        dev = torch.device("cuda", torch.cuda.current_device())
+        send = torch.zeros((cap, BLOCK_BYTES), dtype=torch.uint8, device=dev)
+        torch.cuda.synchronize()
+        api.shard_dirty_pack(scene, rank, send.data_ptr(), cap)
+        engine_sync()
+        recv_h = torch.empty((world, cap, BLOCK_BYTES), dtype=torch.uint8)
+        dist.all_gather_into_tensor(recv_h.view(-1), send.cpu().view(-1))
+        recv = recv_h.to(dev)
+        torch.cuda.synchronize()
+        api.shard_dirty_unpack(scene, rank, recv.data_ptr(), cap)
+        engine_sync()
+    return run
+
+
 def make_numpy_all_gather(api, scene, dist):
     """The same on host buffers, for engines whose voxel blocks live in host memory (the CPU oracle under gloo)."""
     import torch

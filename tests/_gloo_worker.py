@@ -1,4 +1,6 @@
-"""Worker for tests/test_multigpu_gloo.py: one rank of the sharded re-integration on the CPU oracle over gloo."""
+"""Worker for tests/test_multigpu_gloo.py: one rank of the sharded re-integration on the CPU oracle over gloo -- and for
+tests/test_gpu_multirank.py: the same with the HIP engine, every rank a process of its own on the ONE GPU of the box (engine
+"hip": sharded kernels + pack / unpack on the device, the collective staged through the host)."""
 import os
 import sys
 
@@ -43,7 +45,7 @@ def make_batch(pkg, synth, reint, wl, first, n):
     return reint.Batch(frames, old, new, wl.intr)
 
 
-def main(rank, world, port, out_path, maintenance, batched=False):
+def main(rank, world, port, out_path, maintenance, batched=False, engine="oracle"):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     import torch
@@ -54,7 +56,13 @@ def main(rank, world, port, out_path, maintenance, batched=False):
     from dslam_amd.harness import reintegrate as reint
     from dslam_amd.harness import synth
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    api = ge.load_oracle().open_oracle(pkg.CApi)
+    if engine == "hip":
+        torch.cuda.set_device(0)
+        api = pkg.open_engine(0)
+        gather = lambda sc: reint.make_staged_all_gather(api, sc, dist, api.synchronize)
+    else:
+        api = ge.load_oracle().open_oracle(pkg.CApi)
+        gather = lambda sc: reint.make_numpy_all_gather(api, sc, dist)
     wl = synth.s_tiny()
     chunk = 16
     params = util.small_params(pkg, wl, num_local_blocks=0x800, num_buckets=0x1000, num_excess=0x400)
@@ -68,7 +76,7 @@ def main(rank, world, port, out_path, maintenance, batched=False):
         batch = reint.Batch([("store", stores[0], j) for j in range(first, first + count)], batch.old_poses, batch.new_poses, batch.intr)
     timers = {}
     counts = reint.reintegrate(api, s, v, rs, batch, rank=rank, world=world, chunk_blocks=chunk,
-                               all_gather=reint.make_numpy_all_gather(api, s, dist), timers=timers, batched=batched)
+                               all_gather=gather(s), timers=timers, batched=batched)
     snap = util.snapshot(api, s, rs)
     ok = True
     msg = ""
@@ -113,4 +121,4 @@ def main(rank, world, port, out_path, maintenance, batched=False):
 
 if __name__ == "__main__":
     main(int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]), sys.argv[4], int(sys.argv[5]) != 0,
-         len(sys.argv) > 6 and int(sys.argv[6]) != 0)
+         len(sys.argv) > 6 and int(sys.argv[6]) != 0, sys.argv[7] if len(sys.argv) > 7 else "oracle")
