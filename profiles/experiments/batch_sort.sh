@@ -1,6 +1,7 @@
 #!/bin/bash
 # Round 4: what spatial (Morton) order of the block-major batch's class lists would buy the image gathers -- lists sorted on the
 # HOST (DSLAM_BATCH_SORT=1; 2 = plain slot order as the control), the block launch timed by rocprofv3.   run on the GPU box.
+# Needs the experimental build: git apply profiles/experiments/batch_sort.patch && make -C denseslam-global-consistency-h_amd/csrc
 export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 cd /tmp
