@@ -227,3 +227,32 @@ def test_device_side_errors_reach_the_caller(pkg, synth, gpu, bits, what):
     assert gpu.stats(other)["num_allocated_blocks"] == p.num_local_blocks   # ... and only there
     gpu.reset_scene(scene)
     assert gpu.stats(scene, rs)["last_free_block_id"] == p.num_local_blocks - 1
+
+
+def test_device_numa_node_and_page_locked_arenas(pkg, gpu):
+    """dslam_device_numa_node answers from sysfs (-1 where the platform does not say), rejects a device that does not exist;
+    dslam_host_alloc hands out page-locked buffers back to back (one arena), so that a frame's two images go up as one copy,
+    and frees cleanly."""
+    import os
+    node = gpu.device_numa_node(0)
+    assert node >= -1
+    if node >= 0:
+        assert os.path.isdir(f"/sys/devices/system/node/node{node}")
+    with pytest.raises(pkg.DslamError):
+        gpu.device_numa_node(4096)
+    for attempt in range(2):   # (a pair may straddle the end of an arena other tests have filled: the next pair cannot)
+        a = gpu.host_alloc((480, 640, 4), np.uint8)
+        b = gpu.host_alloc((480, 640), np.int16)
+        if b.ctypes.data == a.ctypes.data + ((a.nbytes + 255) & ~255) or attempt == 1:
+            break
+    assert b.ctypes.data == a.ctypes.data + ((a.nbytes + 255) & ~255)   # the next 256-byte boundary behind `a`
+    a[...] = 7
+    b[...] = -3
+    assert int(a.sum()) == 7 * a.size and int(b.sum()) == -3 * b.size
+    big = gpu.host_alloc((16 << 20,), np.uint8)   # larger than an arena piece: an allocation of its own
+    assert not (a.ctypes.data <= big.ctypes.data < a.ctypes.data + (32 << 20))
+    for x in (a, b, big):
+        gpu.host_free(x)
+    c = gpu.host_alloc((480, 640, 4), np.uint8)   # (freed space is handed out again or returned to the system: either way usable)
+    assert int(c.sum()) == 0
+    gpu.host_free(c)
