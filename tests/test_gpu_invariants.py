@@ -12,6 +12,8 @@ brought back and checked:
   * the visible list is strictly ascending, names resident entries only, and an entry has a type byte exactly if it is listed;
   * the counters of dslam_get_stats agree with what the arrays say.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -75,7 +77,10 @@ def check_map(api, scene, rs, p, label):
     listed = np.zeros(nb + ne, dtype=bool)
     listed[ids] = True
     assert np.array_equal(types != 0, listed), f"{label}: type bytes and list disagree"
-    assert st["alloc_failures"] == 0
+    # a request only ever fails on an empty pool (a swapping scene keeps the entries of parked blocks, so a soak of ~1000
+    # keyframes runs its excess list dry, as upstream's would: DSLAM_SOAK_KEYFRAMES)
+    assert st["alloc_failures"] == 0 or st["last_free_excess_id"] < 0 or st["last_free_block_id"] < 0, \
+        f"{label}: {st['alloc_failures']} requests failed with {st['last_free_excess_id'] + 1} excess entries and {st['last_free_block_id'] + 1} blocks free"
     return len(used), len(ids), int((ptr == -1).sum())
 
 
@@ -86,7 +91,7 @@ def test_map_invariants_over_a_long_run(pkg, synth, gpu, swapping):
                         **wl.scene_kwargs)   # upstream's defaults
     scene = gpu.create_scene(p)
     rs, free_rs, view = gpu.create_render_state(scene, wl.W, wl.H), gpu.create_render_state(scene, wl.W, wl.H), gpu.create_view(wl.W, wl.H)
-    n, max_age = 150, 50
+    n, max_age = int(os.environ.get("DSLAM_SOAK_KEYFRAMES", "150")), 50   # (one-off soaks: e.g. 1500 keyframes)
     held, seen_peak, parked = [], 0, 0
     gpu.set_async(True)
     try:
