@@ -844,6 +844,9 @@ __global__ __launch_bounds__(WAVES * 64, 5) void k_render(RenderParams p) {
     const bool split = (mm.y - mm.x) * p.one_over_vs > p.split_len;
     if (split ? (lane >= 32) : (sub != 0)) return;
     y = ty * 8 + (split ? sub * 4 : 0) + (lane >> 3);
+    // (the launch ends with these wavefronts: while short tiles share their SIMDs they issue first -- 138.2 -> 137.5 us per frame,
+    // four alternations, every run of the one below every run of the other)
+    if (split) __builtin_amdgcn_s_setprio(3);   // (a second level -- tiles half as long at priority 2 -- measures the same)
   }
   if (x >= p.W || y >= p.H) return;
   const int loc = x + y * p.W;
